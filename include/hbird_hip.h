@@ -1,0 +1,121 @@
+/*
+ * hbird_hip.h -- C ABI of libhbird_hip.so: the MI355X (gfx950) drop-in for the kNN backend plugin and
+ * the bank-build / label-aggregation hot path of vpariza/open-hummingbird-eval.
+ *
+ * The reference's boundary for this path is a Python class (hbird/nn/search_base.py:3-31) constructed
+ * by HbirdEvaluation._create_nn (hbird/hbird_eval.py:267-281) and called once per validation batch from
+ * _find_nearest_key_to_query (hbird_eval.py:628).  Its Faiss implementation (hbird/nn/search_faiss.py)
+ * binds the third-party faiss-gpu C++/CUDA library; the entry points below are what that binding is
+ * replaced with.  Citations are file:line under the reference tree.
+ *
+ * Conventions: every function returns 0 on success and a negative status on failure, in which case
+ * hb_last_error() (thread-local) describes it.  All matrices are dense row-major fp32 / int64.  One
+ * index handle lives on ONE GPU (one process per GPU; shards and replicas are composed above this ABI
+ * with RCCL).  Calls on one handle must be serialised by the caller; work is
+ * enqueued on the handle's stream (hb_index_set_stream) and host-pointer variants synchronise it.
+ * `*_on_device` = 1 means the pointer is device memory of the handle's GPU, 0 means host memory.
+ */
+#ifndef HBIRD_HIP_H
+#define HBIRD_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hb_index hb_index_t;
+
+#define HB_METRIC_IP 0 /* faiss.GpuIndexFlatIP, search_faiss.py:43-44 ("dot_product")        */
+#define HB_METRIC_L2 1 /* faiss.GpuIndexFlatL2, search_faiss.py:45-46 ("l2" / "euclidean")   */
+#define HB_MAX_K 32    /* neighbours per query on the fused path (reference default k = 30)  */
+
+const char* hb_last_error(void);
+/* faiss.get_num_gpus(), search_faiss.py:14 */
+int hb_device_count(int* n);
+
+/* faiss.StandardGpuResources + GpuIndexFlatConfig{device} + GpuIndexFlat{IP,L2}(res, d, config),
+ * search_faiss.py:34-48.  `device` is validated like gpu_ids at search_faiss.py:23-25. */
+int hb_index_create(int d, int metric, int device, hb_index_t** out);
+int hb_index_free(hb_index_t* ix);
+/* hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream); NULL = default stream. */
+int hb_index_set_stream(hb_index_t* ix, void* hip_stream);
+/* Pre-size the device-resident bank (rows); optional, add() grows geometrically otherwise. */
+int hb_index_reserve(hb_index_t* ix, int64_t n_rows);
+/* index.add(np.float32[n, d]), search_faiss.py:78-81.  Appendable (successive ids, like
+ * faiss.IndexShards' successive-id convention, search_faiss.py:56-63).  normalize = 1 fuses
+ * `features / torch.norm(features, dim=2, keepdim=True)` (hbird_eval.py:324, 335: no eps) into the append
+ * so the per-batch device->host copy of hbird_eval.py:328 disappears. */
+int hb_index_add(hb_index_t* ix, const float* x, int64_t n, int x_on_device, int normalize);
+/* label_memory rows (hbird_eval.py:329, 354), co-indexed with the bank rows. */
+int hb_index_add_labels(hb_index_t* ix, const float* labels, int64_t n, int c, int on_device);
+int64_t hb_index_ntotal(const hb_index_t* ix);
+int64_t hb_index_nlabels(const hb_index_t* ix);
+/* Drop all rows and labels (keeps allocations). */
+int hb_index_reset(hb_index_t* ix);
+
+/* index.search(np.float32[nq, d], k) -> (D, I), search_faiss.py:84-90.  out_idx[nq, k] int64 (id_base +
+ * local row, -1 when fewer than k rows exist), out_dist[nq, k] fp32 (inner product, descending, or
+ * squared L2, ascending), rows best-first, ties by lower id.  1 <= k <= HB_MAX_K. */
+int hb_index_search(hb_index_t* ix, const float* q, int64_t nq, int k, int64_t id_base, int64_t* out_idx,
+                    float* out_dist, int io_on_device);
+/* search + hbird_eval.py:632-633 (label gather) + 575-609 (_cross_attention, beta = 0.02) fused:
+ * out_label_hat[nq, c].  out_idx_opt / out_dist_opt may be NULL. */
+int hb_index_search_aggregate(hb_index_t* ix, const float* q, int64_t nq, int k, int64_t id_base, float beta,
+                              float* out_label_hat, int64_t* out_idx_opt, float* out_dist_opt, int io_on_device);
+/* The aggregation step alone, on given (merged) neighbours -- used after a multi-GPU top-k merge.
+ * idx are global ids; rows outside [id_base, id_base + ntotal) contribute nothing, so per-shard partial
+ * results can be summed (partial = 1: un-normalised numerators out[nq, c] and denominators den[nq], both
+ * relative to the per-query maximum logit of the given list). */
+int hb_index_aggregate(hb_index_t* ix, const float* q, int64_t nq, const int64_t* idx, const float* dist, int k,
+                       int64_t id_base, float beta, float* out_label_hat, int io_on_device);
+/* feature_memory.index_select(0, idx) (hbird_eval.py:632) for return_knn_details; out[n, d]. */
+int hb_index_reconstruct(hb_index_t* ix, const int64_t* ids, int64_t n, int64_t id_base, float* out,
+                         int io_on_device);
+/* label_memory.index_select(0, idx) (hbird_eval.py:633); out[n, c]. */
+int hb_index_gather_labels(hb_index_t* ix, const int64_t* ids, int64_t n, int64_t id_base, float* out,
+                           int io_on_device);
+
+/* k-way merge of per-shard results laid out [parts][nq][k] (faiss.IndexShards' merge, search_faiss.py:
+ * 53-63; here fed by an RCCL all-gather).  Device pointers. */
+int hb_merge_topk(const float* dist_parts, const int64_t* idx_parts, int parts, int64_t nq, int k, int metric,
+                  int64_t* out_idx, float* out_dist, void* hip_stream);
+
+/* ---- bank build (device pointers, enqueued on hip_stream) -------------------------------------- */
+/* features / torch.norm(features, dim=-1, keepdim=True), hbird_eval.py:324, 335. */
+int hb_normalize_rows(const float* x, int64_t n, int d, float* out, void* hip_stream);
+/* _patchify_gt + one_hot(...).float().mean(dim=3), hbird_eval.py:555-573, 319-320; y[B,1,H,W] int64 ->
+ * out[B, H/ps, W/ps, C]; map255 = 1 applies `y[y == 255] = 0` (hbird_eval.py:310) on the fly. */
+int hb_patch_label_hist(const int64_t* y, int64_t B, int H, int W, int ps, int C, int map255, float* out,
+                        void* hip_stream);
+/* _sample_features scores, hbird_eval.py:471-493 (presence read from the soft labels). */
+int hb_patch_scores(const float* label, int64_t B, int SS, int C, float* scores, int* nonempty, int* nz_count,
+                    void* hip_stream);
+/* noise multiply + K smallest, hbird_eval.py:497-511; r drawn by the caller from torch's CPU generator. */
+int hb_patch_select(const float* scores, const int* nonempty, const float* r, const int64_t* r_off, int64_t B,
+                    int SS, int K, int64_t* out_idx, float* out_scores, void* hip_stream);
+/* out[i, :] = src[ids[i], :] (features.gather / label.gather, hbird_eval.py:515, 344-346). */
+int hb_gather_rows(const float* src, int64_t src_rows, int width, const int64_t* ids, int64_t n, float* out,
+                   void* hip_stream);
+
+/* ---- after the aggregation ------------------------------------------------------------------------ */
+/* reshape/permute + F.interpolate(bilinear) + argmax, hbird_eval.py:235-243; label_hat[B, S*S, C] ->
+ * out[B, 1, h, w] int64. */
+int hb_upsample_argmax(const float* label_hat, int64_t B, int S, int C, int h, int w, int64_t* out,
+                       void* hip_stream);
+/* PredsmIoU.update, hbird/utils/eval_metrics.py:73-104; conf[num_gt, num_pred] uint64 accumulated. */
+int hb_confusion_update(const int64_t* gt, const int64_t* pred, int64_t n, int num_gt, int num_pred,
+                        int64_t ignore_index, int has_ignore, uint64_t* conf, void* hip_stream);
+
+/* ---- measurement / tuning ------------------------------------------------------------------------- */
+/* When enabled, every search brackets the kNN kernel with HIP events on the handle's stream. */
+int hb_index_set_timing(hb_index_t* ix, int enable);
+int hb_index_last_knn_ms(const hb_index_t* ix, double* ms);
+/* Overrides for tests: number of workgroups (0 = one per CU) and bank tiles per panel (0 = auto). */
+int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_tiles);
+/* Work-list statistics of the last search: out[0]=workgroups, [1]=segments, [2]=slots, [3]=panel tiles,
+ * [4]=max slots per query tile, [5]=query tiles, [6]=bank tiles. */
+int hb_index_schedule_info(const hb_index_t* ix, int64_t out[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HBIRD_HIP_H */

@@ -1,0 +1,69 @@
+// K5 of SURVEY.md 2.3: soft-label aggregation over the k neighbours of every query patch
+// (reference hbird_eval.py:575-609 `_cross_attention` after the CPU index_select of 632-633).
+//
+//   q^ = q / max(||q||, 1e-12), k^_j = b_j / max(||b_j||, 1e-12)           (F.normalize, 594-595)
+//   attn = softmax_j( (q^ . k^_j) / beta ),  label_hat = sum_j attn_j * label_j   (603-608)
+//
+// The kNN kernel already produced ip_j = q . b_j for the k neighbours, so q^.k^_j = ip_j / (||q|| ||b_j||)
+// and only the k label rows (k*C*4 bytes per query) are gathered -- the k x D neighbour features
+// the reference gathers on the CPU are never touched.  HBM-bound gather: one wave per query.
+#include "hbird_internal.h"
+
+__global__ __launch_bounds__(256) void aggregate_kernel(const float* __restrict__ labels, int64_t nlabels, int C,
+                                                        const float* __restrict__ bnorm,
+                                                        const float* __restrict__ qnorm,
+                                                        const int64_t* __restrict__ idx,
+                                                        const float* __restrict__ dist, int64_t nq, int k,
+                                                        int64_t id_base, int metric, const float* __restrict__ qn2,
+                                                        float beta, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;   // whole wave exits together
+    // lanes j < k: logit of neighbour j  (k <= 64)
+    float logit = -INFINITY;
+    int64_t row = -1;
+    if (lane < k) {
+        const int64_t gid = idx[q * (int64_t)k + lane];
+        row = gid - id_base;
+        if (gid >= 0 && row >= 0 && row < nlabels) {
+            const float bn = fmaxf(bnorm[row], 1e-12f);
+            const float qn = fmaxf(qnorm[q], 1e-12f);
+            float ip = dist[q * (int64_t)k + lane];
+            if (metric == 1) {
+                // squared L2 -> inner product: ip = (||q||^2 + ||b||^2 - d2) / 2
+                ip = 0.5f * (qn2[q] + bnorm[row] * bnorm[row] - ip);
+            }
+            logit = (ip / (qn * bn)) / beta;
+        } else {
+            row = -1;
+        }
+    }
+    float mx = logit;
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float wgt = (row >= 0) ? expf(logit - mx) : 0.0f;
+    float den = wgt;
+    for (int o = 32; o > 0; o >>= 1) den += __shfl_xor(den, o);
+    wgt = den > 0.0f ? wgt / den : 0.0f;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + lane;
+        float accv = 0.0f;
+        for (int j = 0; j < k; ++j) {
+            const float wj = __shfl(wgt, j);
+            const int64_t rj = __shfl(row, j);
+            if (rj >= 0 && c < C) accv = fmaf(wj, labels[rj * (int64_t)C + c], accv);
+        }
+        if (c < C) out[q * (int64_t)C + c] = accv;
+    }
+}
+
+int hb_launch_aggregate(const hb_index* ix, const float* qnorm, const int64_t* idx, const float* dist, int64_t nq,
+                        int k, int64_t id_base, float beta, float* out, hipStream_t s) {
+    if (nq == 0) return 0;
+    if (k > 64) return hb_fail("hb_index_search_aggregate: k must be <= 64");
+    if (!ix->labels || ix->nlabels < ix->ntotal) return hb_fail("hb_index_search_aggregate: label rows missing (hb_index_add_labels)");
+    aggregate_kernel<<<dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s>>>(ix->labels, ix->nlabels, ix->c, ix->bnorm, qnorm,
+                                                                         idx, dist, nq, k, id_base, ix->metric,
+                                                                         ix->q_aux, beta, out);
+    HB_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,312 @@
+// extern "C" surface of libhbird_hip.so (declared in include/hbird_hip.h).
+#include "../../include/hbird_hip.h"
+#include "hbird_internal.h"
+#include <cmath>
+#include <cstring>
+
+static thread_local std::string g_err;
+void hb_set_error(const std::string& msg) { g_err = msg; }
+int hb_fail(const std::string& msg) { g_err = msg; return -1; }
+
+extern "C" const char* hb_last_error(void) { return g_err.c_str(); }
+
+extern "C" int hb_device_count(int* n) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { c = 0; (void)hipGetLastError(); }
+    *n = c;
+    return 0;
+}
+
+extern "C" int hb_index_create(int d, int metric, int device, hb_index_t** out) {
+    if (!out) return hb_fail("hb_index_create: out is NULL");
+    *out = nullptr;
+    if (d <= 0) return hb_fail("hb_index_create: d must be positive");
+    if (metric != HB_METRIC_IP && metric != HB_METRIC_L2) return hb_fail("hb_index_create: unsupported metric");
+    int ndev = 0;
+    hb_device_count(&ndev);
+    if (ndev < 1) return hb_fail("hb_index_create: no GPUs available");
+    if (device < 0 || device >= ndev)
+        return hb_fail("hb_index_create: invalid GPU id " + std::to_string(device) + ", available 0-" + std::to_string(ndev - 1));
+    HB_HIP(hipSetDevice(device));
+    hb_index* ix = new hb_index();
+    ix->d = d; ix->dp = (d + HB_KC - 1) / HB_KC * HB_KC; ix->g8 = ix->dp / 8; ix->metric = metric; ix->device = device;
+    hipDeviceProp_t prop;
+    HB_HIP(hipGetDeviceProperties(&prop, device));
+    ix->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HB_HIP(hipEventCreate(&ix->ev0));
+    HB_HIP(hipEventCreate(&ix->ev1));
+    *out = ix;
+    return 0;
+}
+
+extern "C" int hb_index_free(hb_index_t* ix) {
+    if (!ix) return 0;
+    (void)hipSetDevice(ix->device);
+    (void)hipStreamSynchronize(ix->stream);
+    void* ptrs[] = {ix->tiles, ix->binit, ix->bnorm, ix->labels, ix->q_tiles, ix->q_aux, ix->state, ix->sched_dev, ix->tmp};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (ix->ev0) (void)hipEventDestroy(ix->ev0);
+    if (ix->ev1) (void)hipEventDestroy(ix->ev1);
+    delete ix;
+    return 0;
+}
+
+extern "C" int hb_index_set_stream(hb_index_t* ix, void* s) { ix->stream = (hipStream_t)s; return 0; }
+extern "C" int64_t hb_index_ntotal(const hb_index_t* ix) { return ix->ntotal; }
+extern "C" int64_t hb_index_nlabels(const hb_index_t* ix) { return ix->nlabels; }
+extern "C" int hb_index_set_timing(hb_index_t* ix, int enable) { ix->time_kernels = enable; return 0; }
+extern "C" int hb_index_last_knn_ms(const hb_index_t* ix, double* ms) { *ms = ix->last_knn_ms; return 0; }
+extern "C" int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_tiles) {
+    ix->force_G = workgroups; ix->force_panel = panel_tiles; ix->sched = hb_schedule(); return 0;
+}
+extern "C" int hb_index_schedule_info(const hb_index_t* ix, int64_t out[8]) {
+    const hb_schedule& s = ix->sched;
+    out[0] = s.G; out[1] = (int64_t)s.segs.size(); out[2] = s.n_slots; out[3] = s.panel; out[4] = s.max_slots_per_qt;
+    out[5] = s.nqt; out[6] = s.nbt; out[7] = 0;
+    return 0;
+}
+
+static int grow(void** p, size_t* have, size_t need) {
+    if (*have >= need) return 0;
+    if (*p) HB_HIP(hipFree(*p));
+    *p = nullptr; *have = 0;
+    HB_HIP(hipMalloc(p, need));
+    *have = need;
+    return 0;
+}
+
+extern "C" int hb_index_reserve(hb_index_t* ix, int64_t n_rows) {
+    HB_HIP(hipSetDevice(ix->device));
+    int64_t cap = (n_rows + HB_BT - 1) / HB_BT * HB_BT;
+    if (cap <= ix->cap_rows) return 0;
+    hipStream_t s = ix->stream;
+    float *tiles = nullptr, *binit = nullptr, *bnorm = nullptr;
+    const size_t tb = (size_t)cap * ix->dp * 4;
+    HB_HIP(hipMalloc((void**)&tiles, tb));
+    HB_HIP(hipMalloc((void**)&binit, (size_t)cap * 4));
+    HB_HIP(hipMalloc((void**)&bnorm, (size_t)cap * 4));
+    const size_t old_tb = (size_t)ix->cap_rows * ix->dp * 4;
+    if (ix->cap_rows > 0) {
+        // fragment tiles are row-tile major, so the old bank is a prefix of the new one
+        HB_HIP(hipMemcpyAsync(tiles, ix->tiles, old_tb, hipMemcpyDeviceToDevice, s));
+        HB_HIP(hipMemcpyAsync(binit, ix->binit, (size_t)ix->cap_rows * 4, hipMemcpyDeviceToDevice, s));
+        HB_HIP(hipMemcpyAsync(bnorm, ix->bnorm, (size_t)ix->cap_rows * 4, hipMemcpyDeviceToDevice, s));
+    }
+    HB_HIP(hipMemsetAsync((char*)tiles + old_tb, 0, tb - old_tb, s));
+    // padding rows start from -inf so they can never enter a top-k list
+    HB_HIP(hipMemsetD32Async((hipDeviceptr_t)(binit + ix->cap_rows), 0xFF800000u, (size_t)(cap - ix->cap_rows), s));
+    HB_HIP(hipMemsetAsync(bnorm + ix->cap_rows, 0, (size_t)(cap - ix->cap_rows) * 4, s));
+    HB_HIP(hipStreamSynchronize(s));
+    if (ix->tiles) { HB_HIP(hipFree(ix->tiles)); HB_HIP(hipFree(ix->binit)); HB_HIP(hipFree(ix->bnorm)); }
+    ix->tiles = tiles; ix->binit = binit; ix->bnorm = bnorm; ix->cap_rows = cap;
+    return 0;
+}
+
+extern "C" int hb_index_reset(hb_index_t* ix) {
+    HB_HIP(hipSetDevice(ix->device));
+    hipStream_t s = ix->stream;
+    if (ix->cap_rows > 0) {
+        HB_HIP(hipMemsetAsync(ix->tiles, 0, (size_t)ix->cap_rows * ix->dp * 4, s));
+        HB_HIP(hipMemsetD32Async((hipDeviceptr_t)ix->binit, 0xFF800000u, (size_t)ix->cap_rows, s));
+        HB_HIP(hipMemsetAsync(ix->bnorm, 0, (size_t)ix->cap_rows * 4, s));
+        HB_HIP(hipStreamSynchronize(s));
+    }
+    ix->ntotal = 0; ix->nlabels = 0;
+    return 0;
+}
+
+static int stage_in(hb_index* ix, const void* host, size_t bytes, size_t offset) {
+    HB_HIP(hipMemcpyAsync(ix->tmp + offset, host, bytes, hipMemcpyHostToDevice, ix->stream));
+    return 0;
+}
+
+extern "C" int hb_index_add(hb_index_t* ix, const float* x, int64_t n, int x_on_device, int normalize) {
+    if (n < 0) return hb_fail("hb_index_add: negative row count");
+    if (n == 0) return 0;
+    if (!x) return hb_fail("hb_index_add: x is NULL");
+    HB_HIP(hipSetDevice(ix->device));
+    if (ix->ntotal + n > ix->cap_rows) {
+        int64_t want = std::max<int64_t>(ix->ntotal + n, ix->cap_rows + ix->cap_rows / 2);
+        if (hb_index_reserve(ix, want)) return -1;
+    }
+    const float* src = x;
+    if (!x_on_device) {
+        // host rows are staged in chunks of <= 256 MiB
+        const int64_t chunk = std::max<int64_t>(1, ((int64_t)256 << 20) / ((int64_t)ix->d * 4));
+        if (grow((void**)&ix->tmp, &ix->tmp_bytes, (size_t)std::min(chunk, n) * ix->d * 4)) return -1;
+        for (int64_t r = 0; r < n; r += chunk) {
+            const int64_t m = std::min(chunk, n - r);
+            if (stage_in(ix, x + r * (int64_t)ix->d, (size_t)m * ix->d * 4, 0)) return -1;
+            if (hb_launch_rows_to_tiles((const float*)ix->tmp, m, ix->d, ix->dp, ix->ntotal + r, ix->tiles, ix->binit, ix->bnorm,
+                                        ix->metric, normalize, 1, ix->stream)) return -1;
+            HB_HIP(hipStreamSynchronize(ix->stream));
+        }
+    } else {
+        // rows_to_tiles reads 32 source rows per block starting at row 0 of src; destination offset = ntotal
+        if (hb_launch_rows_to_tiles(src, n, ix->d, ix->dp, ix->ntotal, ix->tiles, ix->binit, ix->bnorm, ix->metric,
+                                    normalize, 1, ix->stream)) return -1;
+    }
+    ix->ntotal += n;
+    return 0;
+}
+
+extern "C" int hb_index_add_labels(hb_index_t* ix, const float* labels, int64_t n, int c, int on_device) {
+    if (n < 0 || c <= 0) return hb_fail("hb_index_add_labels: bad shape");
+    if (n == 0) return 0;
+    HB_HIP(hipSetDevice(ix->device));
+    if (ix->c != 0 && ix->c != c && ix->nlabels > 0) return hb_fail("hb_index_add_labels: class count changed");
+    ix->c = c;
+    if (ix->nlabels + n > ix->lab_cap) {
+        int64_t cap = std::max<int64_t>(ix->nlabels + n, std::max<int64_t>(ix->cap_rows, ix->lab_cap + ix->lab_cap / 2));
+        float* nl = nullptr;
+        HB_HIP(hipMalloc((void**)&nl, (size_t)cap * c * 4));
+        if (ix->nlabels > 0) HB_HIP(hipMemcpyAsync(nl, ix->labels, (size_t)ix->nlabels * c * 4, hipMemcpyDeviceToDevice, ix->stream));
+        HB_HIP(hipStreamSynchronize(ix->stream));
+        if (ix->labels) HB_HIP(hipFree(ix->labels));
+        ix->labels = nl; ix->lab_cap = cap;
+    }
+    HB_HIP(hipMemcpyAsync(ix->labels + ix->nlabels * (int64_t)c, labels, (size_t)n * c * 4,
+                          on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ix->stream));
+    if (!on_device) HB_HIP(hipStreamSynchronize(ix->stream));
+    ix->nlabels += n;
+    return 0;
+}
+
+static inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
+
+static int search_impl(hb_index* ix, const float* q, int64_t nq, int k, int64_t id_base, float beta, float* out_lab,
+                       int64_t* out_idx, float* out_dist, int io_on_device, bool aggregate) {
+    if (nq < 0) return hb_fail("hb_index_search: negative query count");
+    if (k < 1 || k > HB_MAX_K) return hb_fail("hb_index_search: k must be in [1, " + std::to_string(HB_MAX_K) + "]");
+    if (nq == 0) return 0;
+    if (!q) return hb_fail("hb_index_search: q is NULL");
+    HB_HIP(hipSetDevice(ix->device));
+    const int64_t nqp = (nq + HB_QT - 1) / HB_QT * HB_QT;
+    if (grow((void**)&ix->q_tiles, &ix->q_tiles_bytes, (size_t)nqp * ix->dp * 4)) return -1;
+    if (grow((void**)&ix->q_aux, &ix->q_aux_bytes, (size_t)nq * 2 * 4)) return -1;
+    // staging area in ix->tmp: [queries (host path)] [idx] [dist] [label_hat (host path)]
+    const size_t b_q = io_on_device ? 0 : al256((size_t)nq * ix->d * 4);
+    const size_t b_idx = al256((size_t)nq * k * 8), b_dist = al256((size_t)nq * k * 4);
+    const size_t b_lab = (aggregate && !io_on_device) ? al256((size_t)nq * ix->c * 4) : 0;
+    const bool t_idx = !io_on_device || !out_idx, t_dist = !io_on_device || !out_dist;
+    const size_t need = b_q + (t_idx ? b_idx : 0) + (t_dist ? b_dist : 0) + b_lab;
+    if (need && grow((void**)&ix->tmp, &ix->tmp_bytes, need)) return -1;
+    char* cur = ix->tmp;
+    const float* qd = q;
+    if (!io_on_device) {
+        HB_HIP(hipMemcpyAsync(cur, q, (size_t)nq * ix->d * 4, hipMemcpyHostToDevice, ix->stream));
+        qd = (const float*)cur;
+        cur += b_q;
+    }
+    int64_t* d_idx = out_idx;
+    float* d_dist = out_dist;
+    float* d_lab = out_lab;
+    if (t_idx) { d_idx = (int64_t*)cur; cur += b_idx; }
+    if (t_dist) { d_dist = (float*)cur; cur += b_dist; }
+    if (b_lab) { d_lab = (float*)cur; cur += b_lab; }
+    if (hb_launch_rows_to_tiles(qd, nq, ix->d, ix->dp, 0, ix->q_tiles, nullptr, nullptr, ix->metric, 0, 0, ix->stream)) return -1;
+    if (hb_launch_query_aux(qd, nq, ix->d, ix->q_aux, ix->q_aux + nq, ix->stream)) return -1;
+    if (hb_launch_knn(ix, nq, k, id_base, d_idx, d_dist)) return -1;
+    if (aggregate) {
+        if (hb_launch_aggregate(ix, ix->q_aux + nq, d_idx, d_dist, nq, k, id_base, beta, d_lab, ix->stream)) return -1;
+    }
+    if (!io_on_device) {
+        if (out_idx) HB_HIP(hipMemcpyAsync(out_idx, d_idx, (size_t)nq * k * 8, hipMemcpyDeviceToHost, ix->stream));
+        if (out_dist) HB_HIP(hipMemcpyAsync(out_dist, d_dist, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ix->stream));
+        if (aggregate) HB_HIP(hipMemcpyAsync(out_lab, d_lab, (size_t)nq * ix->c * 4, hipMemcpyDeviceToHost, ix->stream));
+        HB_HIP(hipStreamSynchronize(ix->stream));
+    }
+    return 0;
+}
+
+extern "C" int hb_index_search(hb_index_t* ix, const float* q, int64_t nq, int k, int64_t id_base, int64_t* out_idx,
+                               float* out_dist, int io_on_device) {
+    if (nq > 0 && (!out_idx || !out_dist)) return hb_fail("hb_index_search: output pointers are NULL");
+    return search_impl(ix, q, nq, k, id_base, 0.f, nullptr, out_idx, out_dist, io_on_device, false);
+}
+
+extern "C" int hb_index_search_aggregate(hb_index_t* ix, const float* q, int64_t nq, int k, int64_t id_base, float beta,
+                                         float* out_label_hat, int64_t* out_idx_opt, float* out_dist_opt,
+                                         int io_on_device) {
+    if (nq > 0 && !out_label_hat) return hb_fail("hb_index_search_aggregate: out_label_hat is NULL");
+    if (!(beta > 0.f)) return hb_fail("hb_index_search_aggregate: beta must be positive");
+    if (!ix->labels || ix->nlabels < ix->ntotal) return hb_fail("hb_index_search_aggregate: label rows missing (hb_index_add_labels)");
+    return search_impl(ix, q, nq, k, id_base, beta, out_label_hat, out_idx_opt, out_dist_opt, io_on_device, true);
+}
+
+extern "C" int hb_index_aggregate(hb_index_t* ix, const float* q, int64_t nq, const int64_t* idx, const float* dist,
+                                  int k, int64_t id_base, float beta, float* out_label_hat, int io_on_device) {
+    if (nq == 0) return 0;
+    if (!io_on_device) return hb_fail("hb_index_aggregate: host pointers are not supported, pass device memory");
+    if (!(beta > 0.f)) return hb_fail("hb_index_aggregate: beta must be positive");
+    HB_HIP(hipSetDevice(ix->device));
+    if (grow((void**)&ix->q_aux, &ix->q_aux_bytes, (size_t)nq * 2 * 4)) return -1;
+    if (hb_launch_query_aux(q, nq, ix->d, ix->q_aux, ix->q_aux + nq, ix->stream)) return -1;
+    return hb_launch_aggregate(ix, ix->q_aux + nq, idx, dist, nq, k, id_base, beta, out_label_hat, ix->stream);
+}
+
+static int gather_impl(hb_index* ix, const int64_t* ids, int64_t n, int64_t id_base, float* out, int io_on_device,
+                       bool labels) {
+    if (n == 0) return 0;
+    HB_HIP(hipSetDevice(ix->device));
+    const int width = labels ? ix->c : ix->d;
+    if (labels && !ix->labels) return hb_fail("hb_index_gather_labels: no labels stored");
+    const int64_t* d_ids = ids;
+    float* d_out = out;
+    if (!io_on_device) {
+        const size_t b_ids = ((size_t)n * 8 + 255) / 256 * 256;
+        if (grow((void**)&ix->tmp, &ix->tmp_bytes, b_ids + (size_t)n * width * 4)) return -1;
+        if (stage_in(ix, ids, (size_t)n * 8, 0)) return -1;
+        d_ids = (const int64_t*)ix->tmp;
+        d_out = (float*)(ix->tmp + b_ids);
+    }
+    if (labels) {
+        // shift global ids to local rows inside the kernel via src offset: ids are global, rows local
+        if (id_base != 0) return hb_fail("hb_index_gather_labels: id_base != 0 is not supported yet");
+        if (hb_launch_gather_rows(ix->labels, ix->nlabels, width, d_ids, n, d_out, ix->stream)) return -1;
+    } else {
+        if (hb_launch_tiles_to_rows(ix->tiles, ix->g8, ix->d, d_ids, n, id_base, d_out, ix->stream)) return -1;
+    }
+    if (!io_on_device) {
+        HB_HIP(hipMemcpyAsync(out, d_out, (size_t)n * width * 4, hipMemcpyDeviceToHost, ix->stream));
+        HB_HIP(hipStreamSynchronize(ix->stream));
+    }
+    return 0;
+}
+
+extern "C" int hb_index_reconstruct(hb_index_t* ix, const int64_t* ids, int64_t n, int64_t id_base, float* out,
+                                    int io_on_device) {
+    return gather_impl(ix, ids, n, id_base, out, io_on_device, false);
+}
+extern "C" int hb_index_gather_labels(hb_index_t* ix, const int64_t* ids, int64_t n, int64_t id_base, float* out,
+                                      int io_on_device) {
+    return gather_impl(ix, ids, n, id_base, out, io_on_device, true);
+}
+
+extern "C" int hb_merge_topk(const float* dist_parts, const int64_t* idx_parts, int parts, int64_t nq, int k, int metric,
+                             int64_t* out_idx, float* out_dist, void* stream) {
+    if (parts < 1 || k < 1) return hb_fail("hb_merge_topk: bad shape");
+    return hb_launch_merge_parts(dist_parts, idx_parts, parts, nq, k, metric, out_idx, out_dist, (hipStream_t)stream);
+}
+
+extern "C" int hb_normalize_rows(const float* x, int64_t n, int d, float* out, void* stream) {
+    return hb_launch_normalize_rows(x, n, d, out, (hipStream_t)stream);
+}
+extern "C" int hb_patch_label_hist(const int64_t* y, int64_t B, int H, int W, int ps, int C, int map255, float* out,
+                                   void* stream) {
+    return hb_launch_patch_label_hist(y, B, H, W, ps, C, map255, out, (hipStream_t)stream);
+}
+extern "C" int hb_gather_rows(const float* src, int64_t src_rows, int width, const int64_t* ids, int64_t n, float* out,
+                              void* stream) {
+    return hb_launch_gather_rows(src, src_rows, width, ids, n, out, (hipStream_t)stream);
+}
+extern "C" int hb_upsample_argmax(const float* label_hat, int64_t B, int S, int C, int h, int w, int64_t* out,
+                                  void* stream) {
+    return hb_launch_upsample_argmax(label_hat, B, S, C, h, w, out, (hipStream_t)stream);
+}
+extern "C" int hb_confusion_update(const int64_t* gt, const int64_t* pred, int64_t n, int num_gt, int num_pred,
+                                   int64_t ignore_index, int has_ignore, uint64_t* conf, void* stream) {
+    return hb_launch_confusion(gt, pred, n, num_gt, num_pred, ignore_index, has_ignore, (unsigned long long*)conf,
+                               (hipStream_t)stream);
+}

@@ -1,0 +1,98 @@
+// Internal declarations shared by the HIP translation units of libhbird_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+// ---- tile geometry of the kNN kernel (see DESIGN.md "Data layout in HBM") -------------------
+#define HB_QT 256        // query rows per workgroup tile (8 waves x 32 query columns)
+#define HB_BT 256        // bank rows per tile (8 MFMA row tiles of 32)
+#define HB_RT 32         // rows per fragment tile (MFMA 32x32x2)
+#define HB_KC 16         // k extent of one LDS stage (two 8-wide fragment groups)
+#define HB_KL 32         // per-query list capacity kept in LDS (k <= HB_KL on the fused path)
+#define HB_THREADS 512
+#define HB_WAVES 8
+#define HB_BLK 256       // floats per fragment block (32 rows x 8 k) = 1 KiB
+
+#define HB_STAGE_BYTES (16384 + 16384 + 1024)   // A fragments, B fragments, bank-row init values
+#define HB_LDS_LISTS (2 * HB_STAGE_BYTES)
+#define HB_LDS_SCRATCH (HB_LDS_LISTS + 2 * HB_QT * HB_KL * 4)
+#define HB_LDS_TOTAL (HB_LDS_SCRATCH + HB_WAVES * 8 * 64 * 4)
+
+#define HB_ID_NONE 0xFFFFFFFFu
+
+struct hb_seg {
+    int q_tile;    // query tile index (HB_QT rows)
+    int b_tile0;   // first bank tile (HB_BT rows)
+    int n_tiles;   // consecutive bank tiles
+    int slot;      // partial-list slot this segment accumulates into
+    int first;     // 1: slot starts empty, 0: continue from the stored lists
+};
+
+struct hb_schedule {
+    int nqt = 0, nbt = 0, G = 0, panel = 0;
+    std::vector<hb_seg> segs;        // grouped by workgroup
+    std::vector<int> wg_off;         // G+1 offsets into segs
+    std::vector<int> qt_off;         // nqt+1 offsets into qt_slots
+    std::vector<int> qt_slots;       // slots that hold partial lists of each query tile
+    int n_slots = 0;
+    int max_slots_per_qt = 0;
+};
+
+void hb_build_schedule(int nqt, int nbt, int G, int panel_tiles, hb_schedule& out);
+int hb_default_panel(int nqt, int G, size_t tile_bytes);
+
+struct hb_index {
+    int d = 0, dp = 0, g8 = 0, metric = 0, device = 0;
+    hipStream_t stream = nullptr;
+    int64_t ntotal = 0, cap_rows = 0;      // cap_rows is a multiple of HB_BT
+    float* tiles = nullptr;                // fragment-tiled bank  [cap_rows/32][g8][256]
+    float* binit = nullptr;                // per-row accumulator init [cap_rows]
+    float* bnorm = nullptr;                // per-row L2 norm (fp32)  [cap_rows]
+    float* labels = nullptr;               // [lab_cap][c]
+    int c = 0;
+    int64_t nlabels = 0, lab_cap = 0;
+    int num_cu = 256;
+    // search workspace (grown on demand, reused)
+    float* q_tiles = nullptr; size_t q_tiles_bytes = 0;
+    float* q_aux = nullptr; size_t q_aux_bytes = 0;      // qn2 (chain) and qnorm (fp32), 2*nq floats
+    char* state = nullptr; size_t state_bytes = 0;
+    char* sched_dev = nullptr; size_t sched_bytes = 0;
+    char* tmp = nullptr; size_t tmp_bytes = 0;           // staging for host<->device convenience paths
+    hb_schedule sched;                                   // cached for (nqt, nbt)
+    int force_G = 0, force_panel = 0;                    // test/tuning overrides
+    double last_knn_ms = 0.0;                            // HIP-event time of the last knn kernel launch
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int time_kernels = 0;
+};
+
+void hb_set_error(const std::string& msg);
+int hb_fail(const std::string& msg);
+#define HB_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (call);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return hb_fail(std::string(#call) + ": " + hipGetErrorString(_e));               \
+    } while (0)
+
+// kernels/launchers (each returns 0 or a negative status after hb_set_error)
+int hb_launch_rows_to_tiles(const float* src, int64_t n_rows, int d, int dp, int64_t row0, float* tiles,
+                            float* binit, float* bnorm, int metric, int normalize, int is_bank, hipStream_t s);
+int hb_launch_query_aux(const float* q, int64_t nq, int d, float* qn2, float* qnorm, hipStream_t s);
+int hb_launch_tiles_to_rows(const float* tiles, int g8, int d, const int64_t* ids, int64_t n, int64_t id_base,
+                            float* out, hipStream_t s);
+int hb_launch_knn(hb_index* ix, int64_t nq, int k, int64_t id_base, int64_t* out_idx, float* out_dist);
+int hb_launch_aggregate(const hb_index* ix, const float* qnorm, const int64_t* idx, const float* dist, int64_t nq,
+                        int k, int64_t id_base, float beta, float* out, hipStream_t s);
+int hb_launch_merge_parts(const float* dist_parts, const int64_t* idx_parts, int parts, int64_t nq, int k, int metric,
+                          int64_t* out_idx, float* out_dist, hipStream_t s);
+int hb_launch_patch_label_hist(const int64_t* y, int64_t B, int H, int W, int ps, int C, int map255, float* out,
+                               hipStream_t s);
+int hb_launch_normalize_rows(const float* x, int64_t n, int d, float* out, hipStream_t s);
+int hb_launch_gather_rows(const float* src, int64_t src_rows, int width, const int64_t* ids, int64_t n, float* out,
+                          hipStream_t s);
+int hb_launch_upsample_argmax(const float* label_hat, int64_t B, int S, int C, int h, int w, int64_t* out,
+                              hipStream_t s);
+int hb_launch_confusion(const int64_t* gt, const int64_t* pred, int64_t n, int num_gt, int num_pred, int64_t ignore,
+                        int has_ignore, unsigned long long* conf, hipStream_t s);

@@ -1,0 +1,218 @@
+// Layout kernels: row-major fp32 rows <-> MFMA-fragment tiles, plus the per-row constants the
+// kNN kernel needs (accumulator init, norms).  gfx950 only.
+//
+// K1 of SURVEY.md 2.3 ("bank_normalize_append"): `features / torch.norm(features, dim=2,
+// keepdim=True)` (reference hbird_eval.py:324, 335 -- no eps) is fused into the append: rows are
+// read once from the extractor's output and written straight into the index's device-resident,
+// fragment-tiled bank (no host round trip, reference 328-329/353).
+//
+// Fragment-tile layout (one 1 KiB block = 32 rows x 8 k):
+//   block(rt, g) at float offset ((rt * G8) + g) * 256,  rt = row / 32, g = k / 8, G8 = Dp / 8
+//   element (i = row % 32, kk = k % 8) at  ((kk & 1) * 32 + i) * 4 + (kk >> 1)
+// so that lane l = h*32 + i of a wave reads ONE float4 at 16*l bytes holding k = 8g + {h, 2+h, 4+h,
+// 6+h}; four successive v_mfma_f32_32x32x2_f32 then consume k = (8g, 8g+1), (8g+2, 8g+3), ... in
+// ascending order, i.e. every score is a k-ascending fmaf chain (bit-exact oracle definition).
+#include "hbird_internal.h"
+
+__device__ __forceinline__ double wave8_sum(double v) {
+    // reduce over aligned groups of 8 lanes
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    return v;
+}
+
+// One block = 32 consecutive source rows. 256 threads: 8 per row for the reductions.
+// src may be null (zero fill only) for rows >= n_valid. Destination rows are row0 + local row.
+template <bool NORMALIZE, bool IS_BANK>
+__global__ __launch_bounds__(256) void rows_to_tiles_kernel(const float* __restrict__ src, int64_t n_valid,
+                                                            int64_t n_cover, int d, int dp, int64_t row0,
+                                                            float* __restrict__ tiles, float* __restrict__ binit,
+                                                            float* __restrict__ bnorm, int metric) {
+    __shared__ float s_scale[32];
+    const int tid = threadIdx.x;
+    const int64_t r_base = (int64_t)blockIdx.x * 32;
+    const int g8 = dp >> 3;
+
+    // ---- pass 1: row norms (double accumulation, one rounding to fp32) ----
+    {
+        const int i = tid >> 3, sub = tid & 7;
+        const int64_t r = r_base + i;
+        double acc = 0.0;
+        if (r < n_valid) {
+            const float* row = src + r * (int64_t)d;
+            if ((d & 3) == 0) {
+                const float4* row4 = reinterpret_cast<const float4*>(row);
+                for (int k4 = sub; k4 < (d >> 2); k4 += 8) {
+                    float4 v = row4[k4];
+                    acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+                }
+            } else {
+                for (int k = sub; k < d; k += 8) { float v = row[k]; acc += (double)v * v; }
+            }
+        }
+        acc = wave8_sum(acc);
+        float nrm = (float)sqrt(acc);
+        float scale_div = NORMALIZE ? nrm : 1.0f;   // stored value = x / scale_div
+        if (sub == 0) s_scale[i] = scale_div;
+        if (IS_BANK) {
+            // norm of the STORED row (what F.normalize(k) of hbird_eval.py:595 would recompute)
+            float stored_nrm = nrm;
+            if (NORMALIZE) {
+                double a2 = 0.0;
+                if (r < n_valid) {
+                    const float* row = src + r * (int64_t)d;
+                    for (int k = sub; k < d; k += 8) { float v = row[k] / nrm; a2 += (double)v * v; }
+                }
+                a2 = wave8_sum(a2);
+                stored_nrm = (float)sqrt(a2);
+            }
+            if (sub == 0 && r < n_valid) bnorm[row0 + r] = stored_nrm;
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 2: scatter into fragment tiles ----
+    {
+        const int s = tid & 3, i = (tid >> 2) & 31, h = tid >> 7;
+        const int kk = 2 * s + h;
+        const int64_t r = r_base + i;
+        if (r < n_cover) {
+            const int64_t dr = row0 + r;
+            const bool valid = r < n_valid;
+            const float sc = s_scale[i];
+            const float* row = valid ? src + r * (int64_t)d : nullptr;
+            float* dst = tiles + ((dr >> 5) * (int64_t)g8) * HB_BLK + ((kk & 1) * 32 + (int)(dr & 31)) * 4 + (kk >> 1);
+            for (int g = 0; g < g8; ++g) {
+                const int k = 8 * g + kk;
+                float v = 0.0f;
+                if (valid && k < d) { v = row[k]; if (NORMALIZE) v = v / sc; }
+                dst[(int64_t)g * HB_BLK] = v;
+            }
+        }
+    }
+
+    // ---- pass 3 (bank): accumulator init value per row ----
+    if (IS_BANK && tid < 32) {
+        const int64_t r = r_base + tid;
+        if (r < n_valid) {
+            float init = 0.0f;
+            if (metric == 1) {
+                // -0.5 * ||b||^2 with ||b||^2 as ONE k-ascending fmaf chain over the stored values
+                const float* row = src + r * (int64_t)d;
+                const float sc = s_scale[tid];
+                float acc = 0.0f;
+                for (int k = 0; k < d; ++k) { float v = row[k]; if (NORMALIZE) v = v / sc; acc = fmaf(v, v, acc); }
+                init = -0.5f * acc;
+            }
+            binit[row0 + r] = init;
+        }
+    }
+}
+
+int hb_launch_rows_to_tiles(const float* src, int64_t n_rows, int d, int dp, int64_t row0, float* tiles, float* binit,
+                            float* bnorm, int metric, int normalize, int is_bank, hipStream_t s) {
+    // queries: cover up to the next HB_QT boundary with zeros so that stale workspace never leaks in
+    int64_t n_cover = is_bank ? n_rows : ((n_rows + HB_QT - 1) / HB_QT) * HB_QT;
+    if (n_cover == 0) return 0;
+    dim3 grid((unsigned)((n_cover + 31) / 32)), block(256);
+    if (is_bank) {
+        if (normalize) rows_to_tiles_kernel<true, true><<<grid, block, 0, s>>>(src, n_rows, n_cover, d, dp, row0, tiles, binit, bnorm, metric);
+        else rows_to_tiles_kernel<false, true><<<grid, block, 0, s>>>(src, n_rows, n_cover, d, dp, row0, tiles, binit, bnorm, metric);
+    } else {
+        rows_to_tiles_kernel<false, false><<<grid, block, 0, s>>>(src, n_rows, n_cover, d, dp, row0, tiles, nullptr, nullptr, metric);
+    }
+    HB_HIP(hipGetLastError());
+    return 0;
+}
+
+// Per-query constants: qn2 = k-ascending fmaf chain of q_k^2 (L2 distances), qnorm = fp32 L2 norm
+// (double accumulation) used by the cosine aggregation (F.normalize(q), hbird_eval.py:594).
+__global__ __launch_bounds__(256) void query_aux_kernel(const float* __restrict__ q, int64_t nq, int d,
+                                                        float* __restrict__ qn2, float* __restrict__ qnorm) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nq) return;
+    const float* row = q + r * (int64_t)d;
+    float acc = 0.0f;
+    double a2 = 0.0;
+    for (int k = 0; k < d; ++k) { float v = row[k]; acc = fmaf(v, v, acc); a2 += (double)v * v; }
+    qn2[r] = acc;
+    qnorm[r] = (float)sqrt(a2);
+}
+
+int hb_launch_query_aux(const float* q, int64_t nq, int d, float* qn2, float* qnorm, hipStream_t s) {
+    if (nq == 0) return 0;
+    query_aux_kernel<<<dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s>>>(q, nq, d, qn2, qnorm);
+    HB_HIP(hipGetLastError());
+    return 0;
+}
+
+// Gather bank rows back to row-major (return_knn_details: key_features of hbird_eval.py:632,635).
+// ids < 0 (missing neighbour) produce zero rows.  One wave per output row.
+__global__ __launch_bounds__(256) void tiles_to_rows_kernel(const float* __restrict__ tiles, int g8, int d,
+                                                            const int64_t* __restrict__ ids, int64_t n,
+                                                            int64_t id_base, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= n) return;
+    const int64_t gid = ids[o];
+    float* dst = out + o * (int64_t)d;
+    if (gid < 0) { for (int k = lane; k < d; k += 64) dst[k] = 0.0f; return; }
+    const int64_t r = gid - id_base;
+    const float* base = tiles + ((r >> 5) * (int64_t)g8) * HB_BLK;
+    const int i = (int)(r & 31);
+    for (int k = lane; k < d; k += 64) {
+        const int g = k >> 3, kk = k & 7;
+        dst[k] = base[(int64_t)g * HB_BLK + ((kk & 1) * 32 + i) * 4 + (kk >> 1)];
+    }
+}
+
+int hb_launch_tiles_to_rows(const float* tiles, int g8, int d, const int64_t* ids, int64_t n, int64_t id_base,
+                            float* out, hipStream_t s) {
+    if (n == 0) return 0;
+    tiles_to_rows_kernel<<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s>>>(tiles, g8, d, ids, n, id_base, out);
+    HB_HIP(hipGetLastError());
+    return 0;
+}
+
+// Standalone row normalisation (row-major in, row-major out) -- used by the bounded-memory build
+// where sampled rows are normalised before the label gather (hbird_eval.py:335).
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ x, int64_t n, int d,
+                                                             float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const float* row = x + r * (int64_t)d;
+    double acc = 0.0;
+    for (int k = lane; k < d; k += 64) { float v = row[k]; acc += (double)v * v; }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    const float nrm = (float)sqrt(acc);
+    for (int k = lane; k < d; k += 64) out[r * (int64_t)d + k] = row[k] / nrm;
+}
+
+int hb_launch_normalize_rows(const float* x, int64_t n, int d, float* out, hipStream_t s) {
+    if (n == 0) return 0;
+    normalize_rows_kernel<<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s>>>(x, n, d, out);
+    HB_HIP(hipGetLastError());
+    return 0;
+}
+
+// out[i, :] = src[ids[i], :] for row-major fp32 tables (label rows: hbird_eval.py:344-346, 633).
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int64_t src_rows, int width,
+                                                          const int64_t* __restrict__ ids, int64_t n,
+                                                          float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= n) return;
+    const int64_t r = ids[o];
+    const bool ok = r >= 0 && r < src_rows;
+    for (int c = lane; c < width; c += 64) out[o * (int64_t)width + c] = ok ? src[r * (int64_t)width + c] : 0.0f;
+}
+
+int hb_launch_gather_rows(const float* src, int64_t src_rows, int width, const int64_t* ids, int64_t n, float* out,
+                          hipStream_t s) {
+    if (n == 0) return 0;
+    gather_rows_kernel<<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s>>>(src, src_rows, width, ids, n, out);
+    HB_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,88 @@
+"""ctypes binding of lib/libhbird_hip.so (C ABI: include/hbird_hip.h).
+
+This is the only way the Python side reaches the HIP kernels.  There is no CPU fallback: if the
+shared library is missing, or no GPU is visible when an index is created, the call fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_uint64, c_void_p
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libhbird_hip.so")
+CSRC_DIR = os.path.join(_PKG_ROOT, "csrc")
+
+_lib = None
+
+# name -> (restype, argtypes); mirrors include/hbird_hip.h one to one
+SIGNATURES = {
+    "hb_last_error": (c_char_p, []),
+    "hb_device_count": (c_int, [POINTER(c_int)]),
+    "hb_index_create": (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
+    "hb_index_free": (c_int, [c_void_p]),
+    "hb_index_set_stream": (c_int, [c_void_p, c_void_p]),
+    "hb_index_reserve": (c_int, [c_void_p, c_int64]),
+    "hb_index_add": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int]),
+    "hb_index_add_labels": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int]),
+    "hb_index_ntotal": (c_int64, [c_void_p]),
+    "hb_index_nlabels": (c_int64, [c_void_p]),
+    "hb_index_reset": (c_int, [c_void_p]),
+    "hb_index_search": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_int]),
+    "hb_index_search_aggregate": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_float, c_void_p, c_void_p,
+                                          c_void_p, c_int]),
+    "hb_index_aggregate": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64, c_float,
+                                   c_void_p, c_int]),
+    "hb_index_reconstruct": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int]),
+    "hb_index_gather_labels": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int]),
+    "hb_merge_topk": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "hb_normalize_rows": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "hb_patch_label_hist": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "hb_patch_scores": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "hb_patch_select": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
+                                c_void_p]),
+    "hb_gather_rows": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
+    "hb_upsample_argmax": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "hb_confusion_update": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int, c_void_p, c_void_p]),
+    "hb_index_set_timing": (c_int, [c_void_p, c_int]),
+    "hb_index_last_knn_ms": (c_int, [c_void_p, POINTER(c_double)]),
+    "hb_index_set_tuning": (c_int, [c_void_p, c_int, c_int]),
+    "hb_index_schedule_info": (c_int, [c_void_p, POINTER(c_int64)]),
+}
+
+
+class HbirdHipError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load libhbird_hip.so (built by __graft_entry__.build() / `make -C csrc`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HbirdHipError(
+                f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+                f"g.build()' or make -C {CSRC_DIR}). There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = header and library disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    msg = lib().hb_last_error()
+    return msg.decode() if msg else ""
+
+
+def check(rc: int, exc=HbirdHipError):
+    if rc != 0:
+        raise exc(last_error() or f"libhbird_hip call failed with status {rc}")
+
+
+def device_count() -> int:
+    n = c_int(0)
+    lib().hb_device_count(ctypes.byref(n))
+    return int(n.value)

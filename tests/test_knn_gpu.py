@@ -1,0 +1,164 @@
+"""Parity of the fused HIP kNN kernel (through the C ABI) against the CPU oracle.
+
+Bit-exact target: oracle.knn_chain_f32 (every score one k-ascending fp32 fmaf chain, ties by lower
+id) -- indices AND distances must be identical.  The float64 definition is checked modulo near-ties.
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+import oracle
+from hbird_mi.nn.search_hip import HipFlatIndex, NearestNeighborSearchHIP
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_exact(idx, dist, q, bank, k, metric, id_base=0):
+    ridx, rdist = oracle.knn_chain_f32(q, bank, k, metric, id_base)
+    idx = idx.cpu().numpy() if isinstance(idx, torch.Tensor) else idx
+    dist = dist.cpu().numpy() if isinstance(dist, torch.Tensor) else dist
+    assert idx.dtype == np.int64 and dist.dtype == np.float32
+    bad = np.argwhere(idx != ridx)
+    assert bad.size == 0, f"{len(bad)} index mismatches, first {bad[:5].tolist()}: got {idx[tuple(bad[0])]} want {ridx[tuple(bad[0])]}"
+    # bit-exact distances (compare the raw bits; -inf/+inf sentinels included)
+    assert np.array_equal(dist.view(np.uint32), rdist.view(np.uint32)), \
+        f"distance bits differ, max abs diff {np.nanmax(np.abs(dist - rdist))}"
+
+
+@pytest.mark.parametrize("M,D,nq,k,metric", [
+    (1000, 32, 100, 30, "dot_product"),
+    (1000, 32, 100, 30, "l2"),
+    (5000, 64, 257, 1, "dot_product"),
+    (777, 20, 33, 32, "dot_product"),        # D not a multiple of 16, M and nq ragged, k = HB_MAX_K
+    (20000, 384, 300, 30, "dot_product"),    # ViT-S width
+    (20000, 384, 300, 30, "euclidean"),
+    (9000, 768, 520, 30, "dot_product"),     # ViT-B width, 3 query tiles
+])
+def test_search_bit_exact_host_path(cuda_device, M, D, nq, k, metric):
+    bank = gi.unit_bank(M, D, seed=M + D)
+    q = gi.vit_like_queries(nq, D, seed=nq + D)
+    nn = NearestNeighborSearchHIP(torch.from_numpy(bank), n_neighbors=k, distance_measure=metric, gpu_ids=[0])
+    idx, dist = nn.find_nearest_neighbors(torch.from_numpy(q))
+    assert isinstance(idx, np.ndarray) and idx.shape == (nq, k)
+    _check_exact(idx, dist, q, bank, k, metric)
+
+
+def test_search_device_path_and_k_override(cuda_device):
+    M, D, nq = 6000, 128, 300
+    bank = gi.unit_bank(M, D, seed=1)
+    q = gi.vit_like_queries(nq, D, seed=2)
+    nn = NearestNeighborSearchHIP(torch.from_numpy(bank), n_neighbors=30, gpu_ids=[0])
+    idx, dist = nn.find_nearest_neighbors(torch.from_numpy(q).cuda(), k=7)   # k override, search_faiss.py:84-85
+    assert idx.is_cuda and idx.shape == (nq, 7)
+    _check_exact(idx, dist, q, bank, 7, "dot_product")
+
+
+@pytest.mark.parametrize("G,panel", [(1, 1), (3, 2), (7, 1), (16, 5), (64, 3)])
+def test_search_any_work_partition(cuda_device, G, panel):
+    """The result must not depend on how the (query tile, bank tile) pairs are cut into workgroup segments."""
+    M, D, nq, k = 4000, 48, 700, 30
+    bank = gi.unit_bank(M, D, seed=5)
+    q = gi.vit_like_queries(nq, D, seed=6)
+    ix = HipFlatIndex(D, 0, 0)
+    ix.add(bank)
+    ix.set_tuning(G, panel)
+    idx, dist = ix.search(q, k)
+    info = ix.schedule_info()
+    assert info["workgroups"] == min(G, info["query_tiles"] * info["bank_tiles"])
+    _check_exact(idx, dist, q, bank, k, "dot_product")
+
+
+def test_incremental_add_and_id_base(cuda_device):
+    """Appending in ragged chunks (device and host rows mixed) == adding once; id_base offsets the ids."""
+    M, D, nq, k = 3001, 64, 64, 30
+    bank = gi.unit_bank(M, D, seed=9)
+    q = gi.vit_like_queries(nq, D, seed=10)
+    ix = HipFlatIndex(D, 0, 0)
+    cuts = [0, 17, 300, 301, 1500, 3001]
+    for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        chunk = torch.from_numpy(bank[a:b])
+        ix.add(chunk.cuda() if i % 2 else chunk)
+    assert ix.ntotal == M
+    idx, dist = ix.search(q, k, id_base=1_000_000_000_000)
+    _check_exact(idx, dist, q, bank, k, "dot_product", id_base=1_000_000_000_000)
+
+
+def test_fewer_rows_than_k_and_empty(cuda_device):
+    D, k = 16, 30
+    bank = gi.unit_bank(10, D, seed=3)
+    q = gi.vit_like_queries(5, D, seed=4)
+    ix = HipFlatIndex(D, 0, 0)
+    idx, dist = ix.search(q, k)                      # empty index: all -1 (faiss convention)
+    assert (idx == -1).all() and np.isneginf(dist).all()
+    ix.add(bank)
+    idx, dist = ix.search(q, k)
+    _check_exact(idx, dist, q, bank, k, "dot_product")
+    assert (idx[:, 10:] == -1).all()
+    idx0, _ = ix.search(q[:0], k)
+    assert idx0.shape == (0, k)
+
+
+def test_exact_ties_lower_id_first(cuda_device):
+    """Duplicate bank rows score identically; the lower row id must come first and none may be dropped."""
+    M, D, k = 2048, 32, 30
+    bank = gi.unit_bank(M, D, seed=11)
+    for dup in (5, 300, 301, 1029, 2047):
+        bank[dup] = bank[77]
+    q = gi.vit_like_queries(40, D, seed=12)
+    q[0] = 5.0 * bank[77]
+    ix = HipFlatIndex(D, 0, 0)
+    ix.add(bank)
+    idx, dist = ix.search(q, k)
+    _check_exact(idx, dist, q, bank, k, "dot_product")
+    assert idx[0, :6].tolist() == [5, 77, 300, 301, 1029, 2047]
+    # a bank made of ONE repeated row: every score ties, ids must be 0..k-1
+    ix2 = HipFlatIndex(D, 0, 0)
+    ix2.add(np.repeat(bank[:1], 1000, axis=0))
+    idx2, _ = ix2.search(q[:3], k)
+    assert (idx2 == np.arange(k)[None, :]).all()
+
+
+def test_golden_g4_replay(cuda_device, golden_dir):
+    """Fixture produced by the reference's _find_nearest_key_to_query over the float64 exact backend."""
+    g = np.load(f"{golden_dir}/g4_knn.npz")
+    for name in ("ip32", "l2_32", "ip384"):
+        M, D, B, N, k, C = g[f"shape_{name}"].tolist()
+        metric = str(g[f"metric_{name}"])
+        bank = gi.unit_bank(M, D, seed=41)
+        q = gi.vit_like_queries(B * N, D, seed=43)
+        if name == "ip32":
+            bank[1234] = bank[77]; bank[4000] = bank[77]; q[0] = 5.0 * bank[77]
+        nn = NearestNeighborSearchHIP(torch.from_numpy(bank), n_neighbors=k, distance_measure=metric, gpu_ids=[0])
+        idx, dist = nn.find_nearest_neighbors(torch.from_numpy(q))
+        _check_exact(idx, dist, q, bank, k, metric)
+        rep = oracle.near_tie_report(idx, g[f"idx_{name}"], (-1 if metric != "dot_product" else 1) * g[f"dist_{name}"].astype(np.float64))
+        assert rep["set_rate"] >= 0.99 and rep["excused_rate"] == 1.0, rep
+        if name == "ip32":
+            assert idx[0, :3].tolist() == [77, 1234, 4000]
+
+
+def test_plugin_errors(cuda_device):
+    fm = torch.from_numpy(gi.unit_bank(64, 16, seed=0))
+    with pytest.raises(ValueError):
+        NearestNeighborSearchHIP(fm, distance_measure="cosine")          # search_faiss.py:48
+    with pytest.raises(ValueError):
+        NearestNeighborSearchHIP(fm, gpu_ids=[99])                       # search_faiss.py:25
+    nn = NearestNeighborSearchHIP(fm, n_neighbors=5, some_unknown_kwarg=1)   # **kwargs swallowed
+    with pytest.raises(ValueError):
+        nn.find_nearest_neighbors(fm[:2], k=64)
+
+
+def test_mid_size_vs_float64_definition(cuda_device):
+    """300k x 128 bank: fp32 chain result equals the float64 definition except at near-ties."""
+    M, D, nq, k = 300_000, 128, 512, 30
+    bank = gi.unit_bank(M, D, seed=21)
+    q = gi.vit_like_queries(nq, D, seed=22)
+    ix = HipFlatIndex(D, 0, 0)
+    ix.add(torch.from_numpy(bank).cuda())
+    idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    _check_exact(idx, dist, q, bank, k, "dot_product")
+    i64, d64 = oracle.knn_f64(q, bank, k)
+    rep = oracle.near_tie_report(idx, i64, d64)
+    assert rep["excused_rate"] == 1.0 and rep["set_rate"] > 0.98, rep
