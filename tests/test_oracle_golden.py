@@ -1,0 +1,218 @@
+"""Pins the CPU oracle against fixtures produced by the reference's own Python (tools/gen_golden.py).
+
+CPU only.  These tests are what makes the oracle trustworthy as the checker of the HIP path.
+"""
+import numpy as np
+import pytest
+
+import golden_inputs as gi
+import oracle
+
+
+def _load(golden_dir, name):
+    return np.load(f"{golden_dir}/{name}")
+
+
+def test_g1_patchify(golden_dir):
+    g = _load(golden_dir, "g12_patchify_softlabels.npz")
+    for name in "abc":
+        for C in (21, 151):
+            y, ps = g[f"y_{name}_{C}"], int(g[f"ps_{name}_{C}"])
+            assert np.array_equal(oracle.patchify_gt(y, ps), g[f"patches_{name}_{C}"])
+
+
+def test_g2_soft_labels_bit_exact(golden_dir):
+    g = _load(golden_dir, "g12_patchify_softlabels.npz")
+    for name in "abc":
+        for C in (21, 151):
+            y, ps = g[f"y_{name}_{C}"], int(g[f"ps_{name}_{C}"])
+            lab = oracle.patch_label_hist(y, ps, C)
+            ref = g[f"label_{name}_{C}"]
+            assert lab.shape == ref.shape
+            assert np.array_equal(lab.view(np.uint32), ref.view(np.uint32))   # count/P rounding identical
+
+
+def test_patch_label_hist_rejects_out_of_range():
+    y = np.full((1, 1, 8, 8), 255, dtype=np.int64)
+    with pytest.raises(ValueError):
+        oracle.patch_label_hist(y, 4, 21)
+
+
+def test_g3_cross_attention(golden_dir):
+    g = _load(golden_dir, "g3_cross_attention.npz")
+    for name in ("small", "vitS"):
+        out = oracle.cross_attention(g[f"q_{name}"], g[f"k_{name}"], g[f"v_{name}"], beta=0.02)
+        ref = g[f"out_{name}"]
+        # the oracle works in float64; torch's fp32 bmm/softmax differs by rounding only
+        assert np.abs(out - ref).max() < 2e-5, np.abs(out - ref).max()
+        assert np.allclose(out.sum(-1), 1.0, atol=1e-5)
+
+
+def test_g4_knn_definition(golden_dir):
+    g = _load(golden_dir, "g4_knn.npz")
+    for name in ("ip32", "l2_32", "ip384"):
+        M, D, B, N, k, C = g[f"shape_{name}"].tolist()
+        metric = str(g[f"metric_{name}"])
+        bank = gi.unit_bank(M, D, seed=41)
+        lab = gi.labels_from_masks(M, C, 196, seed=42)
+        q = gi.vit_like_queries(B * N, D, seed=43)
+        if name == "ip32":
+            bank[1234] = bank[77]; bank[4000] = bank[77]; q[0] = 5.0 * bank[77]
+        i64, d64 = oracle.knn_f64(q, bank, k, metric)
+        assert np.array_equal(i64, g[f"idx_{name}"])
+        assert np.allclose(d64, g[f"dist_{name}"], rtol=1e-6, atol=1e-6)
+        # gather semantics of hbird_eval.py:631-637
+        kf, kl = oracle.gather_neighbours(i64, bank, lab, B, N)
+        assert np.array_equal(kl, g[f"kl_{name}"])
+        assert np.allclose(kf.sum(-1), g[f"kf_rowsum_{name}"], atol=1e-5)
+        # the fp32 chain flavour agrees with the float64 definition except at near-ties
+        i32, d32 = oracle.knn_chain_f32(q, bank, k, metric)
+        sign = 1.0 if metric == "dot_product" else -1.0
+        rep = oracle.near_tie_report(i32, i64, sign * d64)
+        assert rep["excused_rate"] == 1.0 and rep["set_rate"] >= 0.99, rep
+        if name == "ip32":   # exact ties resolved by lower id in both flavours
+            assert i64[0, :3].tolist() == [77, 1234, 4000] and i32[0, :3].tolist() == [77, 1234, 4000]
+
+
+def test_chain_oracle_is_a_sequential_fmaf_chain():
+    """The AVX2 kernel must equal the textbook definition: acc = fmaf(q_k, b_k, acc), k ascending."""
+    import math
+    if not hasattr(math, "fma"):
+        # python < 3.13: emulate fmaf via float64 (exact product of two fp32 fits in float64; the sum with an
+        # fp32 accumulator is then rounded twice only when the float64 sum is inexact, which we detect)
+        def fmaf(a, b, c):
+            p = np.float64(a) * np.float64(b)
+            s = p + np.float64(c)
+            return np.float32(s)
+    else:
+        def fmaf(a, b, c):
+            return np.float32(math.fma(float(a), float(b), float(c)))
+    rng = np.random.default_rng(0)
+    # small integers / dyadic values: every fma is exact in float64, so the emulation is exact too
+    bank = (rng.integers(-8, 9, size=(50, 24)) / 8.0).astype(np.float32)
+    q = (rng.integers(-16, 17, size=(7, 24)) / 4.0).astype(np.float32)
+    idx, dist = oracle.knn_chain_f32(q, bank, 5)
+    for i in range(q.shape[0]):
+        sc = []
+        for b in range(bank.shape[0]):
+            acc = np.float32(0)
+            for kk in range(q.shape[1]):
+                acc = fmaf(q[i, kk], bank[b, kk], acc)
+            sc.append(acc)
+        sc = np.array(sc, dtype=np.float32)
+        order = np.lexsort((np.arange(len(sc)), -sc))[:5]
+        assert np.array_equal(order, idx[i]) and np.array_equal(sc[order], dist[i])
+
+
+def test_knn_oracle_edge_cases():
+    bank = gi.unit_bank(10, 8, seed=1)
+    q = gi.vit_like_queries(3, 8, seed=2)
+    for fn in (oracle.knn_chain_f32, oracle.knn_f64):
+        idx, dist = fn(q, bank, 12)
+        assert (idx[:, 10:] == -1).all() and np.isneginf(dist[:, 10:]).all()
+        idx, dist = fn(q, bank, 12, "l2")
+        assert (idx[:, 10:] == -1).all() and np.isposinf(dist[:, 10:]).all()
+        assert (np.diff(dist[:, :10], axis=1) >= 0).all()
+        idx, _ = fn(q, bank, 3, "dot_product", 1000)
+        assert idx.min() >= 1000
+    idx, dist = oracle.knn_chain_f32(q[:0], bank, 4)
+    assert idx.shape == (0, 4)
+
+
+def test_g5_sample_features(golden_dir):
+    g = _load(golden_dir, "g5_sample.npz")
+    for name in "ab":
+        ps, C, K, seed = g[f"cfg_{name}"].tolist()
+        y, feats, r = g[f"y_{name}"], g[f"feats_{name}"], g[f"r_{name}"]
+        pt = oracle.patchify_gt(y, ps)
+        assert oracle.sample_num_nonempty(pt, C).sum() == r.shape[0]
+        sidx, _ = oracle.sample_patches(pt, C, K, r)
+        assert np.array_equal(sidx, g[f"sidx_{name}"])
+        sf = np.take_along_axis(feats, sidx[:, :, None], axis=1)
+        assert np.array_equal(sf, g[f"sfeat_{name}"])
+
+
+def _replay_memory(g, name):
+    """Rebuild the bank exactly as hbird_eval.py:283-369 does, with the oracle's pieces."""
+    C, D, H, ps, nb, B, k, mem, aug, ign = g[f"cfg_{name}"].tolist()
+    import torch
+    S = H // ps
+    K = None if mem < 0 else max(1, mem // max(1, nb * B * aug))
+    if K is not None:
+        torch.set_rng_state(torch.from_numpy(g[f"rng_state_{name}"]))
+    feats, labs = [], []
+    for _ in range(aug):
+        for i in range(nb):
+            y = np.rint(g[f"train_y_{name}_{i}"] * 255.0).astype(np.int64)     # (y*255).long(), 309
+            y[y == 255] = 0                                                      # 310
+            tok = g[f"train_tok_{name}_{i}"]
+            lab = oracle.patch_label_hist(y, ps, C).reshape(B, S * S, C)         # 317-320
+            if K is None:
+                feats.append(oracle.normalize_rows(tok).reshape(-1, D))          # 324-325
+                labs.append(lab.reshape(-1, C))
+            else:
+                pt = oracle.patchify_gt(y, ps)
+                nz = int(oracle.sample_num_nonempty(pt, C).sum())
+                r = torch.rand(nz).numpy()                                       # 500
+                sidx, _ = oracle.sample_patches(pt, C, K, r)
+                sf = np.take_along_axis(tok, sidx[:, :, None], axis=1)           # 515
+                feats.append(oracle.normalize_rows(sf).reshape(-1, D))           # 335
+                labs.append(np.take_along_axis(lab, sidx[:, :, None], axis=1).reshape(-1, C))   # 344
+    return np.concatenate(feats), np.concatenate(labs), (C, D, H, ps, nb, B, k, mem, aug, ign)
+
+
+@pytest.mark.parametrize("name", ["unb", "bnd", "trim", "ade"])
+def test_g6_create_memory(golden_dir, name):
+    g = _load(golden_dir, "g67_memory_evaluate.npz")
+    fm, lm, _ = _replay_memory(g, name)
+    ref_f, ref_l = g[f"feature_memory_{name}"], g[f"label_memory_{name}"]
+    assert fm.shape == ref_f.shape and lm.shape == ref_l.shape       # incl. the trimmed bounded case
+    assert np.array_equal(lm, ref_l)
+    # torch's fp32 norm reduction order differs from the oracle's float64 accumulation: <= 2 ulp
+    assert np.abs(fm - ref_f).max() <= 2.5e-7, np.abs(fm - ref_f).max()
+
+
+@pytest.mark.parametrize("name", ["unb", "bnd", "trim", "ade"])
+def test_g7_evaluate(golden_dir, name):
+    g = _load(golden_dir, "g67_memory_evaluate.npz")
+    C, D, H, ps, nb, B, k, mem, aug, ign = g[f"cfg_{name}"].tolist()
+    S = H // ps
+    fm, lm = g[f"feature_memory_{name}"], g[f"label_memory_{name}"]     # identical bank for both paths
+    metric = oracle.PredsMIoUOracle(C, C, ignore_index=ign)
+    lhs, cms = [], []
+    for i in range(2):
+        tok = g[f"val_tok_{name}_{i}"]
+        y = np.rint(g[f"val_y_{name}_{i}"] * 255.0).astype(np.int64)          # hbird_eval.py:219
+        idx, _ = oracle.knn_f64(tok.reshape(-1, D), fm, k)
+        kf, kl = oracle.gather_neighbours(idx, fm, lm, B, S * S)
+        lh = oracle.cross_attention(tok, kf, kl)
+        cm = oracle.upsample_argmax(lh, S, H, H)
+        metric.update(y, cm)
+        lhs.append(lh); cms.append(cm)
+    lh = np.concatenate(lhs)
+    assert np.abs(lh - g[f"label_hat_{name}"]).max() < 2e-5
+    cm = np.concatenate(cms)
+    agree = (cm == g[f"cluster_map_{name}"]).mean()
+    assert agree > 0.999, agree        # argmax can flip only where two classes are within rounding
+    if name == "unb":
+        up = oracle.upsample_bilinear(g[f"label_hat_{name}"].reshape(-1, S, S, C).transpose(0, 3, 1, 2), H, H)
+        assert np.abs(up - g[f"upsampled_{name}"]).max() < 1e-6
+    miou = metric.compute()[0]
+    assert abs(miou - float(g[f"jac_{name}"])) < 1e-4, (miou, float(g[f"jac_{name}"]))
+
+
+def test_g8_predsmiou(golden_dir):
+    g = _load(golden_dir, "g8_predsmiou.npz")
+    for name in ("c5", "c21", "ade"):
+        C, n, ign = g[f"cfg_{name}"].tolist()
+        gt, pred = g[f"gt_{name}"], g[f"pred_{name}"]
+        m = oracle.PredsMIoUOracle(C, C, ignore_index=ign)
+        m.update(gt.reshape(2, -1), pred.reshape(2, -1))
+        assert np.array_equal(m.conf, g[f"conf_{name}"])
+        for mode, kw in {"hung": {}, "m2o": {"many_to_one": True},
+                         "m2o_prec": {"many_to_one": True, "precision_based": True}, "lin": {"linear_probe": True}}.items():
+            miou, tp, fp, fn, _ = m.compute(**kw)
+            assert abs(miou - float(g[f"miou_{name}_{mode}"])) < 1e-12
+            assert tp == g[f"tp_{name}_{mode}"].tolist()
+            assert fp == g[f"fp_{name}_{mode}"].tolist()
+            assert fn == g[f"fn_{name}_{mode}"].tolist()
