@@ -62,9 +62,7 @@ int hb_index_search(hb_index_t* ix, const float* q, int64_t nq, int k, int64_t i
 int hb_index_search_aggregate(hb_index_t* ix, const float* q, int64_t nq, int k, int64_t id_base, float beta,
                               float* out_label_hat, int64_t* out_idx_opt, float* out_dist_opt, int io_on_device);
 /* The aggregation step alone, on given (merged) neighbours -- used after a multi-GPU top-k merge.
- * idx are global ids; rows outside [id_base, id_base + ntotal) contribute nothing, so per-shard partial
- * results can be summed (partial = 1: un-normalised numerators out[nq, c] and denominators den[nq], both
- * relative to the per-query maximum logit of the given list). */
+ * idx are global ids; q, idx, dist, out are device pointers (io_on_device must be 1). */
 int hb_index_aggregate(hb_index_t* ix, const float* q, int64_t nq, const int64_t* idx, const float* dist, int k,
                        int64_t id_base, float beta, float* out_label_hat, int io_on_device);
 /* feature_memory.index_select(0, idx) (hbird_eval.py:632) for return_knn_details; out[n, d]. */
@@ -73,6 +71,13 @@ int hb_index_reconstruct(hb_index_t* ix, const int64_t* ids, int64_t n, int64_t 
 /* label_memory.index_select(0, idx) (hbird_eval.py:633); out[n, c]. */
 int hb_index_gather_labels(hb_index_t* ix, const int64_t* ids, int64_t n, int64_t id_base, float* out,
                            int io_on_device);
+
+/* Multi-GPU aggregation tables: borrow device arrays labels[n, c] / norms[n] that cover the GLOBAL id range
+ * [id_base, id_base + n) (the all-gathered label_memory and bank-row norms); NULL restores the index's own
+ * tables.  hb_index_copy_norms exports this shard's row norms (ntotal floats) for that all-gather. */
+int hb_index_set_label_table(hb_index_t* ix, const float* labels, const float* norms, int64_t n, int c,
+                             int64_t id_base);
+int hb_index_copy_norms(hb_index_t* ix, float* out, int on_device);
 
 /* k-way merge of per-shard results laid out [parts][nq][k] (faiss.IndexShards' merge, search_faiss.py:
  * 53-63; here fed by an RCCL all-gather).  Device pointers. */

@@ -60,8 +60,10 @@ int hb_launch_aggregate(const hb_index* ix, const float* qnorm, const int64_t* i
                         int k, int64_t id_base, float beta, float* out, hipStream_t s) {
     if (nq == 0) return 0;
     if (k > 64) return hb_fail("hb_index_search_aggregate: k must be <= 64");
-    if (!ix->labels || ix->nlabels < ix->ntotal) return hb_fail("hb_index_search_aggregate: label rows missing (hb_index_add_labels)");
-    aggregate_kernel<<<dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s>>>(ix->labels, ix->nlabels, ix->c, ix->bnorm, qnorm,
+    const float* labels = ix->labels; const float* bnorm = ix->bnorm; int64_t nlab = ix->nlabels;
+    if (ix->ext_labels) { labels = ix->ext_labels; bnorm = ix->ext_bnorm; nlab = ix->ext_n; id_base = ix->ext_base; }
+    else if (!ix->labels || ix->nlabels < ix->ntotal) return hb_fail("hb_index_search_aggregate: label rows missing (hb_index_add_labels)");
+    aggregate_kernel<<<dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s>>>(labels, nlab, ix->c, bnorm, qnorm,
                                                                          idx, dist, nq, k, id_base, ix->metric,
                                                                          ix->q_aux, beta, out);
     HB_HIP(hipGetLastError());

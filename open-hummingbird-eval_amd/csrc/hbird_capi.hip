@@ -231,7 +231,7 @@ extern "C" int hb_index_search_aggregate(hb_index_t* ix, const float* q, int64_t
                                          int io_on_device) {
     if (nq > 0 && !out_label_hat) return hb_fail("hb_index_search_aggregate: out_label_hat is NULL");
     if (!(beta > 0.f)) return hb_fail("hb_index_search_aggregate: beta must be positive");
-    if (!ix->labels || ix->nlabels < ix->ntotal) return hb_fail("hb_index_search_aggregate: label rows missing (hb_index_add_labels)");
+    if (!ix->ext_labels && (!ix->labels || ix->nlabels < ix->ntotal)) return hb_fail("hb_index_search_aggregate: label rows missing (hb_index_add_labels)");
     return search_impl(ix, q, nq, k, id_base, beta, out_label_hat, out_idx_opt, out_dist_opt, io_on_device, true);
 }
 
@@ -282,6 +282,22 @@ extern "C" int hb_index_reconstruct(hb_index_t* ix, const int64_t* ids, int64_t 
 extern "C" int hb_index_gather_labels(hb_index_t* ix, const int64_t* ids, int64_t n, int64_t id_base, float* out,
                                       int io_on_device) {
     return gather_impl(ix, ids, n, id_base, out, io_on_device, true);
+}
+
+extern "C" int hb_index_set_label_table(hb_index_t* ix, const float* labels, const float* bnorm, int64_t n, int c,
+                                        int64_t id_base) {
+    if (labels && (!bnorm || n <= 0 || c <= 0)) return hb_fail("hb_index_set_label_table: bad arguments");
+    ix->ext_labels = labels; ix->ext_bnorm = bnorm; ix->ext_n = labels ? n : 0; ix->ext_base = labels ? id_base : 0;
+    if (labels) ix->c = c;
+    return 0;
+}
+
+extern "C" int hb_index_copy_norms(hb_index_t* ix, float* out, int on_device) {
+    if (ix->ntotal == 0) return 0;
+    HB_HIP(hipSetDevice(ix->device));
+    HB_HIP(hipMemcpyAsync(out, ix->bnorm, (size_t)ix->ntotal * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ix->stream));
+    if (!on_device) HB_HIP(hipStreamSynchronize(ix->stream));
+    return 0;
 }
 
 extern "C" int hb_merge_topk(const float* dist_parts, const int64_t* idx_parts, int parts, int64_t nq, int k, int metric,

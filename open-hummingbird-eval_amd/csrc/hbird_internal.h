@@ -54,6 +54,8 @@ struct hb_index {
     int c = 0;
     int64_t nlabels = 0, lab_cap = 0;
     int num_cu = 256;
+    // optional borrowed tables covering a GLOBAL id range (multi-GPU: all-gathered labels / norms)
+    const float* ext_labels = nullptr; const float* ext_bnorm = nullptr; int64_t ext_n = 0, ext_base = 0;
     // search workspace (grown on demand, reused)
     float* q_tiles = nullptr; size_t q_tiles_bytes = 0;
     float* q_aux = nullptr; size_t q_aux_bytes = 0;      // qn2 (chain) and qnorm (fp32), 2*nq floats

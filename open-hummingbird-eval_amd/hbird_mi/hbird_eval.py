@@ -1,0 +1,446 @@
+"""Hummingbird dense-retrieval evaluation on MI355X: the counterpart of the reference's
+hbird/hbird_eval.py (class HbirdEvaluation 54-637, hbird_evaluation 640-722), same public names,
+arguments, return values and error behaviour -- with the whole hot path device-resident:
+
+  bank build   ViT tokens -> fused L2-normalise + fragment-tiled append (K1), patch soft labels from the
+               mask histogram (K2), optional bounded-memory sampling (K3); nothing crosses to the host
+               except the uniform noise the reference draws from torch's CPU generator (hbird_eval.py:500).
+  query path   tokens -> exact brute-force kNN (K4, fused fp32-MFMA top-k) -> cosine-softmax label
+               aggregation (K5) -> bilinear upsample + argmax (K6) -> confusion matrix (K7); only the
+               [C,C] confusion matrix reaches the host, where the Hungarian mIoU tail runs.
+
+With torch.distributed initialised (one process per GPU, backend "nccl" = RCCL) the bank is row-sharded
+over the ranks in the reference's row order (contiguous ranges of training batches, successive ids), the
+validation batches are dealt round-robin to the ranks, and every search is: all-gather(queries) -> local
+shard search -> all-gather(top-k) -> merge -> aggregation against the all-gathered label table.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from typing import Any, Dict, List, Optional, Tuple
+
+import torch
+
+from hbird_mi import ops
+from hbird_mi.models import FeatureExtractor, FeatureExtractorSimple
+from hbird_mi.nn.search_hip import HipFlatIndex, MAX_K, merge_topk, _METRICS
+from hbird_mi.utils.eval_metrics import PredsmIoU
+
+try:
+    from tqdm import tqdm
+except ImportError:  # pragma: no cover
+    def tqdm(iterator, *args, **kwargs):
+        return iterator
+
+logger = logging.getLogger(__name__)
+if not logger.handlers:
+    _handler = logging.StreamHandler()
+    _handler.setFormatter(logging.Formatter(fmt="%(asctime)s | %(levelname)s | %(name)s: %(message)s",
+                                            datefmt="%H:%M:%S"))
+    logger.addHandler(_handler)
+    logger.setLevel(getattr(logging, os.environ.get("HBIRD_LOG_LEVEL", "WARNING").upper(), logging.WARNING))
+
+_NN_METHODS = ("hip", "faiss", "scann")
+
+
+def _dist_info() -> Tuple[int, int]:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return torch.distributed.get_rank(), torch.distributed.get_world_size()
+    return 0, 1
+
+
+class HbirdEvaluation:
+    """Same constructor as the reference (hbird_eval.py:97-111).
+
+    `nn_method`: "hip" (this engine), or the reference's names "faiss" (exact flat search: identical
+    semantics, served by the HIP engine) and "scann" (the reference's approximate CPU backend is not
+    re-implemented; the exact HIP search is used and a warning is logged).  `nn_params` keeps the Faiss
+    keywords: distance_measure, idx_shard, use_fp16, gpu_ids (search_faiss.py:7); ScaNN-only keywords are
+    accepted and ignored.
+    """
+
+    def __init__(self, feature_extractor: torch.nn.Module, train_loader, num_classes: int, n_neighbours: int = 30,
+                 augmentation_epoch: int = 1, device: torch.device | str = "cpu", nn_method: str = "scann",
+                 nn_params: Optional[Dict[str, Any]] = None, memory_size: Optional[int] = None,
+                 dataset_size: Optional[int] = None, f_mem_p: Optional[str] = None,
+                 l_mem_p: Optional[str] = None) -> None:
+        if nn_params is None:
+            nn_params = {}
+        self.nn_params = nn_params
+        self.device = device
+        self.nn_method = nn_method
+        assert self.nn_method in _NN_METHODS, "Only hip, faiss and scann are supported"   # hbird_eval.py:121
+        if self.nn_method == "scann":
+            logger.warning("nn_method='scann': the approximate ScaNN CPU backend is replaced by the exact HIP search")
+        if not torch.cuda.is_available():
+            raise RuntimeError("HbirdEvaluation needs an MI355X: the HIP path has no CPU fallback")
+        dev = torch.device(device)
+        self.gpu = dev.index if dev.type == "cuda" and dev.index is not None else torch.cuda.current_device()
+        self.gpu_device = torch.device("cuda", self.gpu)
+        self.feature_extractor = feature_extractor.to(device)
+        self.feature_extractor.eval()
+
+        self.augmentation_epoch = augmentation_epoch
+        self.memory_size = memory_size
+        self.n_neighbours = n_neighbours
+        self.num_classes = num_classes
+        self.f_mem_p = f_mem_p
+        self.l_mem_p = l_mem_p
+        self.num_sampled_features: Optional[int] = None
+        self.rank, self.world = _dist_info()
+
+        distance = str(nn_params.get("distance_measure", "dot_product")).lower()
+        if distance not in _METRICS:
+            raise ValueError(f"Unsupported distance measure: {distance}")                 # search_faiss.py:48
+        self.metric = _METRICS[distance]
+        gpu_ids = nn_params.get("gpu_ids")
+        if gpu_ids is not None:
+            n = torch.cuda.device_count()
+            for g in gpu_ids:
+                if g >= n or g < 0:
+                    raise ValueError(f"Invalid GPU ID: {g}. Available GPUs: 0-{n - 1}")    # search_faiss.py:25
+        if not 1 <= n_neighbours <= MAX_K:
+            raise ValueError(f"n_neighbours={n_neighbours} outside the supported range [1, {MAX_K}]")
+        # a sharded bank needs >1 rank; idx_shard=False with several ranks keeps full replicas per rank
+        self.sharded = self.world > 1 and bool(nn_params.get("idx_shard", True))
+
+        eval_spatial_resolution = self.feature_extractor.eval_spatial_resolution
+        logger.info("Initializing memory: nn_method=%s, memory_size=%s, augmentation_epoch=%s", self.nn_method,
+                    str(self.memory_size), self.augmentation_epoch)
+        if self.memory_size is not None:
+            if dataset_size is None:
+                raise ValueError("dataset_size must be provided when memory_size is set.")  # hbird_eval.py:144-145
+            denom = dataset_size * self.augmentation_epoch
+            self.num_sampled_features = max(1, self.memory_size // max(1, denom))           # 146-147
+
+        self.index = HipFlatIndex(self.feature_extractor.d_model, self.metric, self.gpu)
+        self.index.set_num_classes(num_classes)
+        self.id_base = 0            # global id of this rank's first bank row
+        self.total_rows = 0         # bank rows over all ranks
+        self._label_table = None    # all-gathered labels / norms in sharded mode
+        filled = self._create_memory(train_loader, num_classes=self.num_classes,
+                                     eval_spatial_resolution=eval_spatial_resolution)
+        logger.info("Memory rows: %s", filled)
+        self._save_memory()
+        self._finalize_shards()
+
+    # ------------------------------------------------------------------------------------------------
+    # bank build (reference _create_memory, hbird_eval.py:283-369)
+    # ------------------------------------------------------------------------------------------------
+    def _create_memory(self, train_loader, num_classes: int, eval_spatial_resolution: int) -> Optional[int]:
+        S = eval_spatial_resolution
+        try:
+            n_batches = len(train_loader)
+        except TypeError:
+            n_batches = None
+        total_flat = None if n_batches is None else n_batches * self.augmentation_epoch
+        if self.sharded:
+            if total_flat is None:
+                raise ValueError("a sharded bank build needs a train_loader with a length")
+            per = (total_flat + self.world - 1) // self.world
+            own_lo, own_hi = min(total_flat, self.rank * per), min(total_flat, (self.rank + 1) * per)
+        else:
+            own_lo, own_hi = 0, float("inf")
+        if self.memory_size is not None:
+            self.index.reserve(max(1, self.memory_size // max(1, self.world if self.sharded else 1)))
+        rows_before_me = 0
+        flat = 0
+        with torch.no_grad():
+            for _ in tqdm(range(self.augmentation_epoch), desc="Augmentation loop"):
+                for x, y in tqdm(train_loader, desc="Memory Creation loop"):
+                    mine = own_lo <= flat < own_hi
+                    flat += 1
+                    y = y.to(self.gpu_device)
+                    y = (y * 255).long()                                   # hbird_eval.py:309
+                    bs = y.shape[0]
+                    input_size = x.shape[-1]
+                    patch_size = input_size // S                          # 313-314
+                    if not mine and self.memory_size is None:
+                        if flat - 1 < own_lo:
+                            rows_before_me += bs * S * S
+                        continue
+                    # K2: `y[y == 255] = 0` (310) + patchify (317) + one-hot mean (319-320)
+                    label = ops.patch_label_hist(y, patch_size, num_classes, map255=True)   # [bs,S,S,C]
+                    if self.memory_size is None:
+                        feats = self._tokens(x)                            # [bs, S*S, D] on the GPU
+                        self.index.use_current_stream()
+                        self.index.add(feats.reshape(-1, feats.shape[-1]), normalize=True)   # K1 (324-329)
+                        self.index.add_labels(label.reshape(-1, num_classes))
+                    else:
+                        K = int(self.num_sampled_features)
+                        lab = label.reshape(bs, S * S, num_classes)
+                        scores, nonempty, nz = ops.patch_scores(lab)       # K3a (471-493)
+                        nz_host = nz.cpu().tolist()                        # 497 (.tolist() sync in the reference too)
+                        total_nz = sum(nz_host)
+                        # the CPU generator is consumed for EVERY batch, in loader order, so that all ranks
+                        # stay aligned with the single-process stream of the reference (500)
+                        r = torch.rand(total_nz) if total_nz > 0 else torch.zeros(0)
+                        if not mine:
+                            if flat - 1 < own_lo:
+                                rows_before_me += bs * K
+                            continue
+                        r_off = torch.tensor([0] + nz_host[:-1], dtype=torch.int64).cumsum(0)
+                        sidx = ops.patch_select(scores, nonempty, r.to(self.gpu_device), r_off.to(self.gpu_device), K)
+                        feats = self._tokens(x)
+                        D = feats.shape[-1]
+                        rows = (sidx + torch.arange(bs, device=sidx.device)[:, None] * (S * S)).reshape(-1)
+                        sampled = ops.gather_rows(feats.reshape(-1, D), rows)                  # 515
+                        self.index.use_current_stream()
+                        self.index.add(sampled, normalize=True)                                # 335, 352-353
+                        self.index.add_labels(ops.gather_rows(lab.reshape(-1, num_classes), rows))   # 344-354
+        self.id_base = rows_before_me if self.sharded else 0
+        return self.index.ntotal
+
+    def _tokens(self, x: torch.Tensor) -> torch.Tensor:
+        feats, _ = self.feature_extractor.forward_features(x.to(self.device))    # (BS, N, D)
+        return feats.to(self.gpu_device, dtype=torch.float32).contiguous()
+
+    def _finalize_shards(self) -> None:
+        """Sharded mode: learn every rank's row range and replicate the (small) label / norm tables."""
+        n_local = self.index.ntotal
+        if not self.sharded:
+            self.total_rows = n_local
+            return
+        counts = torch.zeros(self.world, dtype=torch.int64, device=self.gpu_device)
+        counts[self.rank] = n_local
+        torch.distributed.all_reduce(counts)
+        counts = counts.cpu().tolist()
+        self.id_base = sum(counts[:self.rank])
+        self.total_rows = sum(counts)
+        C = self.num_classes
+        mx = max(counts)
+        lab_local = torch.zeros((mx, C), dtype=torch.float32, device=self.gpu_device)
+        nrm_local = torch.zeros((mx,), dtype=torch.float32, device=self.gpu_device)
+        if n_local:
+            ids = torch.arange(n_local, device=self.gpu_device)
+            lab_local[:n_local] = self.index.gather_labels(ids)
+            from hbird_mi import _lib
+            import ctypes
+            self.index.use_current_stream()
+            _lib.check(_lib.lib().hb_index_copy_norms(self.index._h, ctypes.c_void_p(nrm_local.data_ptr()), 1))
+        lab_all = torch.empty((self.world, mx, C), dtype=torch.float32, device=self.gpu_device)
+        nrm_all = torch.empty((self.world, mx), dtype=torch.float32, device=self.gpu_device)
+        torch.distributed.all_gather_into_tensor(lab_all, lab_local)
+        torch.distributed.all_gather_into_tensor(nrm_all, nrm_local)
+        labels = torch.cat([lab_all[r, :counts[r]] for r in range(self.world)]).contiguous()
+        norms = torch.cat([nrm_all[r, :counts[r]] for r in range(self.world)]).contiguous()
+        self._label_table = (labels, norms)   # keep alive: the index borrows the pointers
+        from hbird_mi import _lib
+        import ctypes
+        _lib.check(_lib.lib().hb_index_set_label_table(self.index._h, ctypes.c_void_p(labels.data_ptr()),
+                                                       ctypes.c_void_p(norms.data_ptr()), labels.shape[0], C, 0))
+
+    # ------------------------------------------------------------------------------------------------
+    # bank persistence (reference 371-400): same two-tensor torch.save format
+    # ------------------------------------------------------------------------------------------------
+    @property
+    def feature_memory(self) -> torch.Tensor:
+        """This rank's bank rows as a CPU tensor [M_local, D] (the reference keeps it on the CPU, 178)."""
+        n = self.index.ntotal
+        if n == 0:
+            return torch.zeros((0, self.index.d))
+        ids = torch.arange(n, device=self.gpu_device)
+        return self.index.reconstruct(ids).cpu()
+
+    @property
+    def label_memory(self) -> torch.Tensor:
+        n = self.index.ntotal
+        if n == 0:
+            return torch.zeros((0, self.num_classes))
+        return self.index.gather_labels(torch.arange(n, device=self.gpu_device)).cpu()
+
+    def _save_memory(self) -> None:
+        sfx = f".rank{self.rank}" if self.sharded else ""
+        if self.f_mem_p is not None:
+            torch.save(self.feature_memory, self.f_mem_p + sfx)
+            logger.info("Saved feature memory to: %s", self.f_mem_p + sfx)
+        if self.l_mem_p is not None:
+            torch.save(self.label_memory, self.l_mem_p + sfx)
+            logger.info("Saved label memory to: %s", self.l_mem_p + sfx)
+
+    def load_memory(self) -> bool:
+        """Load a bank saved by `_save_memory` (or by the reference) and rebuild the index from it."""
+        sfx = f".rank{self.rank}" if self.sharded else ""
+        if (self.f_mem_p is not None and self.l_mem_p is not None and os.path.isfile(self.f_mem_p + sfx)
+                and os.path.isfile(self.l_mem_p + sfx)):
+            fm = torch.load(self.f_mem_p + sfx)
+            lm = torch.load(self.l_mem_p + sfx)
+            self.index.reset()
+            self.index.add(fm.to(self.gpu_device), normalize=False)
+            self.index.add_labels(lm.to(self.gpu_device))
+            self._finalize_shards()
+            logger.info("Loaded memory from disk.")
+            return True
+        logger.warning("Memory files not found or paths not provided; skipping load.")
+        return False
+
+    # ------------------------------------------------------------------------------------------------
+    # query path (reference evaluate 184-265, _find_nearest_key_to_query 611-637, _cross_attention 575-609)
+    # ------------------------------------------------------------------------------------------------
+    def find_neighbours(self, q_flat: torch.Tensor, k: Optional[int] = None):
+        """q_flat [nq, D] on the GPU -> (idx int64 [nq,k] global ids, dist [nq,k]); un-normalised queries (625)."""
+        k = self.n_neighbours if k is None else k
+        self.index.use_current_stream()
+        idx, dist = self.index.search(q_flat, k, id_base=self.id_base)
+        if self.sharded:
+            pi = torch.empty((self.world,) + tuple(idx.shape), dtype=idx.dtype, device=idx.device)
+            pd = torch.empty((self.world,) + tuple(dist.shape), dtype=dist.dtype, device=dist.device)
+            torch.distributed.all_gather_into_tensor(pi, idx)
+            torch.distributed.all_gather_into_tensor(pd, dist)
+            idx, dist = merge_topk(pd, pi, self.metric)
+        return idx, dist
+
+    def _label_hat(self, feats: torch.Tensor, want_details: bool):
+        """feats [B,N,D] -> label_hat [B,N,C] (+ neighbours when details are requested)."""
+        B, N, D = feats.shape
+        q = feats.reshape(B * N, D).contiguous()
+        k = self.n_neighbours
+        self.index.use_current_stream()
+        if not self.sharded and not want_details:
+            lh = self.index.search_aggregate(q, k, beta=0.02, id_base=0)
+            return lh.view(B, N, -1), None, None
+        idx, dist = self.find_neighbours(q, k)
+        lh = self.index.aggregate(q, idx, dist, beta=0.02, id_base=self.id_base)
+        return lh.view(B, N, -1), idx, dist
+
+    def _gather_details(self, idx: torch.Tensor, B: int, N: int):
+        k = idx.shape[1]
+        flat = idx.reshape(-1)
+        if self.sharded:
+            # rows live on their owners: every rank reconstructs its own rows, the sum fills the rest
+            own = (flat >= self.id_base) & (flat < self.id_base + self.index.ntotal)
+            kf = self.index.reconstruct(torch.where(own, flat, torch.full_like(flat, -1)), id_base=self.id_base)
+            torch.distributed.all_reduce(kf)
+            kl = ops.gather_rows(self._label_table[0], flat)
+        else:
+            kf = self.index.reconstruct(flat)
+            kl = self.index.gather_labels(flat)
+        return kf.view(B, N, k, -1), kl.view(B, N, k, -1)
+
+    def evaluate(self, val_loader, eval_spatial_resolution: int, return_knn_details: bool = False,
+                 ignore_index: int = 255):
+        metric = PredsmIoU(self.num_classes, self.num_classes, ignore_index=ignore_index, device=self.gpu_device,
+                           store_reordered_preds=False)
+        self.feature_extractor = self.feature_extractor.to(self.device)
+        S = eval_spatial_resolution
+        knns, knns_labels, knns_ca_labels = [], [], []
+        logger.info("Starting evaluation loop...")
+        with torch.no_grad():
+            if self.sharded:
+                self._evaluate_sharded(val_loader, S, metric, return_knn_details, knns, knns_labels, knns_ca_labels)
+            else:
+                for x, y in tqdm(val_loader, desc="Evaluation loop"):
+                    _, _, h, w = x.shape
+                    feats = self._tokens(x)                                       # 217 (stays on the GPU)
+                    y = (y.to(self.gpu_device) * 255).long()                       # 219 (255 is NOT remapped here)
+                    label_hat, idx, _ = self._label_hat(feats, return_knn_details)  # 224-227
+                    if return_knn_details:
+                        kf, kl = self._gather_details(idx, feats.shape[0], feats.shape[1])
+                        knns.append(kf.cpu()); knns_labels.append(kl.cpu()); knns_ca_labels.append(label_hat.cpu())
+                    cluster_map = ops.upsample_argmax(label_hat, S, h, w)           # 235-243
+                    metric.update(y, cluster_map)                                   # 252 (streamed per batch)
+        jac, tp, fp, fn, _, _ = metric.compute(is_global_zero=True, sync_distributed=self.sharded,
+                                               return_reordered=False)            # 253
+        if return_knn_details:
+            details = {"knns": torch.cat(knns), "knns_labels": torch.cat(knns_labels),
+                       "knns_ca_labels": torch.cat(knns_ca_labels)}
+            logger.info("Evaluation complete (with KNN details).")
+            return jac, details
+        logger.info("Evaluation complete.")
+        return jac
+
+    def _evaluate_sharded(self, val_loader, S, metric, want_details, knns, knns_labels, knns_ca_labels):
+        """Validation batches are dealt round-robin; all ranks step together so that every search sees all
+        shards.  A rank that has run out of batches contributes zero queries."""
+        it = iter(val_loader)
+        n_batches = len(val_loader)
+        D = self.index.d
+        steps = (n_batches + self.world - 1) // self.world
+        k = self.n_neighbours
+        bi = 0
+        for _ in range(steps):
+            mine = None
+            for r in range(self.world):
+                if bi < n_batches:
+                    batch = next(it)
+                    if r == self.rank:
+                        mine = batch
+                    bi += 1
+            if mine is not None:
+                x, y = mine
+                h, w = x.shape[-2:]
+                feats = self._tokens(x)
+                B, N, _ = feats.shape
+                q = feats.reshape(B * N, D)
+            else:
+                q = torch.zeros((0, D), dtype=torch.float32, device=self.gpu_device)
+            # all-gather of ragged query batches: sizes first, then zero-padded payload
+            nq = torch.zeros(self.world, dtype=torch.int64, device=self.gpu_device)
+            nq[self.rank] = q.shape[0]
+            torch.distributed.all_reduce(nq)
+            nq = nq.cpu().tolist()
+            mx = max(nq)
+            if mx == 0:
+                continue
+            qpad = torch.zeros((mx, D), dtype=torch.float32, device=self.gpu_device)
+            qpad[:q.shape[0]] = q
+            qall = torch.empty((self.world, mx, D), dtype=torch.float32, device=self.gpu_device)
+            torch.distributed.all_gather_into_tensor(qall, qpad)
+            idx, dist = self.find_neighbours(qall.view(self.world * mx, D), k)   # collective inside
+            kf_all = None
+            if want_details:
+                # neighbour features live on their owning shard: every rank fills in its own rows, the
+                # all-reduce (sum with zeros) completes them -- a collective, so all ranks take part
+                flat = idx.reshape(-1)
+                own = (flat >= self.id_base) & (flat < self.id_base + self.index.ntotal)
+                kf_all = self.index.reconstruct(torch.where(own, flat, torch.full_like(flat, -1)),
+                                                id_base=self.id_base)
+                torch.distributed.all_reduce(kf_all)
+                kf_all = kf_all.view(self.world * mx, k, D)
+            if mine is None:
+                continue
+            lo = self.rank * mx
+            my_idx, my_dist = idx[lo:lo + q.shape[0]].contiguous(), dist[lo:lo + q.shape[0]].contiguous()
+            self.index.use_current_stream()
+            label_hat = self.index.aggregate(q.contiguous(), my_idx, my_dist, beta=0.02).view(B, N, -1)
+            if want_details:
+                kl = ops.gather_rows(self._label_table[0], my_idx.reshape(-1)).view(B, N, k, -1)
+                knns.append(kf_all[lo:lo + q.shape[0]].reshape(B, N, k, D).cpu())
+                knns_labels.append(kl.cpu())
+                knns_ca_labels.append(label_hat.cpu())
+            y = (y.to(self.gpu_device) * 255).long()
+            metric.update(y, ops.upsample_argmax(label_hat, S, h, w))
+        if want_details and not knns:
+            z = torch.zeros(0)
+            knns.append(z); knns_labels.append(z); knns_ca_labels.append(z)
+
+
+def hbird_evaluation(model, d_model: int, patch_size: int, dataset_name: str, data_dir: str, batch_size: int = 64,
+                     input_size: int = 224, augmentation_epoch: int = 1, device: str | torch.device = "cpu",
+                     return_knn_details: bool = False, n_neighbours: int = 30, nn_method: str = "scann",
+                     nn_params: Optional[Dict[str, Any]] = None, ftr_extr_fn=None,
+                     memory_size: Optional[int] = None, num_workers: int = 8, ignore_index: int = 255,
+                     train_fs_path: Optional[str] = None, val_fs_path: Optional[str] = None):
+    """High-level entry point with the reference's signature (hbird_eval.py:640-660)."""
+    if nn_params is None:
+        nn_params = {}
+    eval_spatial_resolution = input_size // patch_size                                   # 671
+    if ftr_extr_fn is None:
+        feature_extractor = FeatureExtractor(model, eval_spatial_resolution=eval_spatial_resolution, d_model=d_model)
+    else:
+        feature_extractor = FeatureExtractorSimple(model, ftr_extr_fn=ftr_extr_fn,
+                                                   eval_spatial_resolution=eval_spatial_resolution, d_model=d_model)
+    from hbird_mi.data import get_dataset
+    dataset, ignore_index_local = get_dataset(dataset_name, data_dir, batch_size, num_workers, input_size,
+                                              train_fs_path, val_fs_path)
+    dataset_size = dataset.get_train_dataset_size()
+    num_classes = dataset.get_num_classes()
+    train_loader = dataset.train_dataloader()
+    val_loader = dataset.val_dataloader()
+    evaluator = HbirdEvaluation(feature_extractor, train_loader, num_classes=num_classes, n_neighbours=n_neighbours,
+                                augmentation_epoch=augmentation_epoch, device=device, nn_method=nn_method,
+                                nn_params=nn_params, memory_size=memory_size, dataset_size=dataset_size)
+    effective_ignore = ignore_index if ignore_index != 255 else ignore_index_local        # 715
+    return evaluator.evaluate(val_loader, eval_spatial_resolution=eval_spatial_resolution,
+                              return_knn_details=return_knn_details, ignore_index=effective_ignore)

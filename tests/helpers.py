@@ -1,0 +1,29 @@
+"""Shared test helpers (no reference imports)."""
+import numpy as np
+import torch
+
+
+class ReplayExtractor(torch.nn.Module):
+    """Fake extractor returning pre-computed tokens in call order (same as tools/gen_golden.py)."""
+
+    def __init__(self, tokens, eval_spatial_resolution, d_model):
+        super().__init__()
+        self.tokens = [torch.from_numpy(np.ascontiguousarray(t)) for t in tokens]
+        self.eval_spatial_resolution = eval_spatial_resolution
+        self.d_model = d_model
+        self.i = 0
+
+    def forward_features(self, x):
+        t = self.tokens[self.i]
+        self.i += 1
+        return t.clone().to(x.device), None
+
+
+def golden_case(g, name):
+    C, D, H, ps, nb, B, k, mem, aug, ign = g[f"cfg_{name}"].tolist()
+    train = [(torch.zeros((B, 3, H, H)), torch.from_numpy(g[f"train_y_{name}_{i}"])) for i in range(nb)]
+    val = [(torch.zeros((B, 3, H, H)), torch.from_numpy(g[f"val_y_{name}_{i}"])) for i in range(2)]
+    tr_tok = [g[f"train_tok_{name}_{i}"] for i in range(nb)] * aug
+    va_tok = [g[f"val_tok_{name}_{i}"] for i in range(2)]
+    return dict(C=C, D=D, H=H, ps=ps, nb=nb, B=B, k=k, mem=None if mem < 0 else mem, aug=aug, ign=ign,
+                train=train, val=val, tr_tok=tr_tok, va_tok=va_tok, S=H // ps)

@@ -1,0 +1,99 @@
+"""End-to-end HbirdEvaluation on the GPU against fixtures produced by the reference's HbirdEvaluation."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import ReplayExtractor, golden_case
+from hbird_mi.hbird_eval import HbirdEvaluation, hbird_evaluation
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["unb", "bnd", "trim", "ade"])
+def test_create_memory_and_evaluate_match_reference(cuda_device, golden_dir, name):
+    g = np.load(f"{golden_dir}/g67_memory_evaluate.npz")
+    c = golden_case(g, name)
+    ext = ReplayExtractor(c["tr_tok"] + c["va_tok"], c["S"], c["D"])
+    torch.set_rng_state(torch.from_numpy(g[f"rng_state_{name}"]))      # the reference run started from this state
+    ev = HbirdEvaluation(ext, c["train"], num_classes=c["C"], n_neighbours=c["k"], augmentation_epoch=c["aug"],
+                         device="cuda", nn_method="faiss", nn_params={}, memory_size=c["mem"],
+                         dataset_size=c["nb"] * c["B"])
+    # ---- bank (G6): same rows, same order, same trimming --------------------------------------------
+    fm, lm = ev.feature_memory.numpy(), ev.label_memory.numpy()
+    ref_f, ref_l = g[f"feature_memory_{name}"], g[f"label_memory_{name}"]
+    assert fm.shape == ref_f.shape and lm.shape == ref_l.shape
+    assert np.array_equal(lm, ref_l)
+    assert np.abs(fm - ref_f).max() <= 2.5e-7
+    # ---- evaluate (G7) ----------------------------------------------------------------------------------
+    jac, det = ev.evaluate(c["val"], eval_spatial_resolution=c["S"], return_knn_details=True, ignore_index=c["ign"])
+    assert isinstance(jac, float)
+    assert abs(jac - float(g[f"jac_{name}"])) < 1e-4, (jac, float(g[f"jac_{name}"]))
+    lh = det["knns_ca_labels"].numpy()
+    assert lh.shape == g[f"label_hat_{name}"].shape
+    close = np.abs(lh - g[f"label_hat_{name}"]) < 5e-5
+    assert close.mean() > 0.999, close.mean()     # a near-tie neighbour swap may move a few rows
+    assert det["knns"].shape[:3] == det["knns_labels"].shape[:3] == (2 * c["B"], c["S"] ** 2, c["k"])
+    same = (det["knns_labels"].numpy() == g[f"knns_labels_{name}"]).all(axis=-1)
+    assert same.mean() > 0.995
+    assert np.abs(det["knns"].numpy().sum(-1) - g[f"knns_rowsum_{name}"])[same].max() < 1e-4
+
+
+def test_evaluate_fused_path_equals_detail_path(cuda_device, golden_dir):
+    g = np.load(f"{golden_dir}/g67_memory_evaluate.npz")
+    c = golden_case(g, "ade")
+    mk = lambda: ReplayExtractor(c["tr_tok"] + c["va_tok"] + c["va_tok"], c["S"], c["D"])
+    ev = HbirdEvaluation(mk(), c["train"], num_classes=c["C"], n_neighbours=c["k"], device="cuda", nn_method="hip")
+    j1 = ev.evaluate(c["val"], c["S"], return_knn_details=False, ignore_index=c["ign"])
+    j2, _ = ev.evaluate(c["val"], c["S"], return_knn_details=True, ignore_index=c["ign"])
+    assert j1 == j2 and abs(j1 - float(g["jac_ade"])) < 1e-4
+
+
+def test_constructor_errors(cuda_device, golden_dir):
+    g = np.load(f"{golden_dir}/g67_memory_evaluate.npz")
+    c = golden_case(g, "unb")
+    mk = lambda: ReplayExtractor(c["tr_tok"], c["S"], c["D"])
+    with pytest.raises(AssertionError):
+        HbirdEvaluation(mk(), c["train"], num_classes=c["C"], nn_method="annoy", device="cuda")       # hbird_eval.py:121
+    with pytest.raises(ValueError):
+        HbirdEvaluation(mk(), c["train"], num_classes=c["C"], memory_size=100, device="cuda")         # 144-145
+    with pytest.raises(ValueError):
+        HbirdEvaluation(mk(), c["train"], num_classes=c["C"], nn_method="faiss", device="cuda",
+                        nn_params={"distance_measure": "cosine"})                                      # search_faiss.py:48
+    with pytest.raises(ValueError):
+        HbirdEvaluation(mk(), c["train"], num_classes=c["C"], nn_method="faiss", device="cuda",
+                        nn_params={"gpu_ids": [64]})                                                    # search_faiss.py:25
+
+
+def test_save_and_load_memory_roundtrip(cuda_device, golden_dir, tmp_path):
+    g = np.load(f"{golden_dir}/g67_memory_evaluate.npz")
+    c = golden_case(g, "unb")
+    fp, lp = str(tmp_path / "f.pt"), str(tmp_path / "l.pt")
+    ev = HbirdEvaluation(ReplayExtractor(c["tr_tok"] + c["va_tok"] * 2, c["S"], c["D"]), c["train"], num_classes=c["C"],
+                         n_neighbours=c["k"], device="cuda", nn_method="hip", f_mem_p=fp, l_mem_p=lp)
+    j1 = ev.evaluate(c["val"], c["S"], ignore_index=c["ign"])
+    saved = torch.load(fp)
+    assert torch.equal(saved, ev.feature_memory) and saved.shape == (c["nb"] * c["B"] * c["S"] ** 2, c["D"])
+    assert ev.load_memory() is True
+    j2 = ev.evaluate(c["val"], c["S"], ignore_index=c["ign"])
+    assert j1 == j2
+
+
+def test_hbird_evaluation_entry_point_synthetic(cuda_device):
+    """hbird_evaluation(...) with the reference's signature on the procedural dataset; a 'ViT' that
+    average-pools patches is enough for the labels to transfer."""
+    class PoolViT(torch.nn.Module):
+        def forward(self, x):
+            return x
+
+    def fn(model, imgs):
+        t = torch.nn.functional.avg_pool2d(imgs, 8)            # [B,3,S,S]
+        return t.flatten(2).transpose(1, 2).contiguous(), None
+
+    miou = hbird_evaluation(PoolViT(), d_model=3, patch_size=8, dataset_name="synthetic", data_dir="", batch_size=8,
+                            input_size=64, device="cuda", n_neighbours=30, nn_method="hip", ftr_extr_fn=fn)
+    assert isinstance(miou, float) and miou > 0.5
+    miou_b, det = hbird_evaluation(PoolViT(), d_model=3, patch_size=8, dataset_name="synthetic*0.5", data_dir="",
+                                   batch_size=8, input_size=64, device="cuda", nn_method="faiss", ftr_extr_fn=fn,
+                                   memory_size=640, return_knn_details=True)
+    assert det["knns_ca_labels"].shape == (16, 64, 6) and 0.0 < miou_b <= 1.0

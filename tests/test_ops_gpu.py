@@ -1,0 +1,178 @@
+"""HIP kernels K1, K2, K3, K5, K6, K7 (through the C ABI) against the oracle and the golden fixtures."""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+import oracle
+from hbird_mi import ops
+from hbird_mi.nn.search_hip import HipFlatIndex
+from hbird_mi.utils.eval_metrics import PredsmIoU
+
+pytestmark = pytest.mark.gpu
+
+
+def _ulp_diff(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float32); b = np.ascontiguousarray(b, dtype=np.float32)
+    ai = a.view(np.int32).astype(np.int64); bi = b.view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, -(ai & 0x7FFFFFFF), ai); bi = np.where(bi < 0, -(bi & 0x7FFFFFFF), bi)
+    return np.abs(ai - bi)
+
+
+def test_k2_patch_label_hist_golden_bit_exact(cuda_device, golden_dir):
+    g = np.load(f"{golden_dir}/g12_patchify_softlabels.npz")
+    for name in "abc":
+        for C in (21, 151):
+            y, ps = g[f"y_{name}_{C}"], int(g[f"ps_{name}_{C}"])
+            out = ops.patch_label_hist(torch.from_numpy(y).cuda(), ps, C).cpu().numpy()
+            ref = g[f"label_{name}_{C}"]
+            assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+
+
+def test_k2_map255_and_big_shapes(cuda_device):
+    y = gi.random_masks(3, 518, 518, 151, seed=4, with_255=True)
+    y0 = y.copy(); y0[y0 == 255] = 0                                   # hbird_eval.py:310
+    ref = oracle.patch_label_hist(y0, 14, 151)
+    out = ops.patch_label_hist(torch.from_numpy(y).cuda(), 14, 151, map255=True).cpu().numpy()
+    assert out.shape == (3, 37, 37, 151)
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+    assert np.allclose(out.sum(-1), 1.0, atol=1e-6)
+    with pytest.raises(Exception):
+        ops.patch_label_hist(torch.from_numpy(y).cuda(), 15, 151)      # 518 % 15 != 0
+
+
+@pytest.mark.parametrize("n,D", [(1000, 384), (333, 768), (70, 20), (4096, 1024)])
+def test_k1_normalize_append(cuda_device, n, D):
+    x = gi.vit_like_queries(n, D, seed=n)
+    ref = oracle.normalize_rows(x)
+    ix = HipFlatIndex(D, 0, 0)
+    ix.add(torch.from_numpy(x[: n // 3]).cuda(), normalize=True)       # ragged appends
+    ix.add(torch.from_numpy(x[n // 3:]).cuda(), normalize=True)
+    got = ix.reconstruct(np.arange(n))
+    assert _ulp_diff(got, ref).max() <= 1      # double-accumulated norm: differs from the oracle by rounding order only
+    assert (got == ref).mean() > 0.99
+    got2 = ops.normalize_rows(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert _ulp_diff(got2, ref).max() <= 1
+    # un-normalised append is an exact copy
+    ix2 = HipFlatIndex(D, 0, 0)
+    ix2.add(x)
+    assert np.array_equal(ix2.reconstruct(np.arange(n)), x)
+    assert np.array_equal(ix2.reconstruct(torch.arange(n).cuda()).cpu().numpy(), x)
+
+
+def test_k3_sampling_golden(cuda_device, golden_dir):
+    g = np.load(f"{golden_dir}/g5_sample.npz")
+    for name in "ab":
+        ps, C, K, seed = g[f"cfg_{name}"].tolist()
+        y, r = g[f"y_{name}"], g[f"r_{name}"]
+        B = y.shape[0]
+        lab = ops.patch_label_hist(torch.from_numpy(y).cuda(), ps, C)
+        SS = lab.shape[1] * lab.shape[2]
+        scores, nonempty, nz = ops.patch_scores(lab.view(B, SS, C))
+        assert nz.cpu().tolist() == [SS] * B
+        pt = oracle.patchify_gt(y, ps)
+        _, ref_scores = oracle.sample_patches(pt, C, K, np.ones_like(r))
+        assert np.array_equal(scores.cpu().numpy(), ref_scores)
+        r_off = torch.arange(B, dtype=torch.int64) * SS
+        sidx, noisy = ops.patch_select(scores, nonempty, torch.from_numpy(r).cuda(), r_off.cuda(), K, want_scores=True)
+        assert np.array_equal(sidx.cpu().numpy(), g[f"sidx_{name}"])
+        _, ref_noisy = oracle.sample_patches(pt, C, K, r)
+        assert np.array_equal(noisy.cpu().numpy(), ref_noisy)
+        feats = torch.from_numpy(g[f"feats_{name}"]).cuda()
+        rows = (sidx + torch.arange(B, device="cuda")[:, None] * SS).reshape(-1)
+        sf = ops.gather_rows(feats.reshape(B * SS, -1), rows).view(B, K, -1)
+        assert np.array_equal(sf.cpu().numpy(), g[f"sfeat_{name}"])
+
+
+def test_k5_aggregate_golden_g3(cuda_device, golden_dir):
+    """_cross_attention fixture: neighbours are given, so feed them as a bank + explicit (idx, ip)."""
+    g = np.load(f"{golden_dir}/g3_cross_attention.npz")
+    for name in ("small", "vitS"):
+        q, k, v, ref = g[f"q_{name}"], g[f"k_{name}"], g[f"v_{name}"], g[f"out_{name}"]
+        B, N, K, D = k.shape
+        C = v.shape[-1]
+        ix = HipFlatIndex(D, 0, 0)
+        ix.add(k.reshape(-1, D))
+        ix.add_labels(v.reshape(-1, C))
+        ix.set_num_classes(C)
+        idx = torch.arange(B * N * K, dtype=torch.int64).view(B * N, K).cuda()
+        ip = (q[:, :, None, :].astype(np.float64) * k.astype(np.float64)).sum(-1).astype(np.float32)
+        out = ix.aggregate(torch.from_numpy(q.reshape(B * N, D)).cuda(), idx,
+                           torch.from_numpy(ip.reshape(B * N, K)).cuda()).cpu().numpy().reshape(B, N, C)
+        assert np.abs(out - ref).max() < 2e-5, np.abs(out - ref).max()
+        assert np.abs(out - oracle.cross_attention(q, k, v)).max() < 2e-5
+
+
+def test_k4_k5_fused_vs_oracle(cuda_device):
+    M, D, C, nq, k = 30000, 384, 21, 500, 30
+    bank = gi.unit_bank(M, D, seed=1)
+    lab = gi.labels_from_masks(M, C, 196, seed=2)
+    q = gi.vit_like_queries(nq, D, seed=3)
+    ix = HipFlatIndex(D, 0, 0)
+    ix.add(bank); ix.add_labels(lab); ix.set_num_classes(C)
+    out, idx, dist = ix.search_aggregate(torch.from_numpy(q).cuda(), k, want_neighbours=True)
+    ridx, _ = oracle.knn_chain_f32(q, bank, k)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    kf, kl = oracle.gather_neighbours(ridx, bank, lab, 1, nq)
+    ref = oracle.cross_attention(q[None], kf, kl)[0]
+    assert np.abs(out.cpu().numpy() - ref).max() < 2e-5
+    out_host = ix.search_aggregate(q, k)                    # host-pointer path
+    assert np.array_equal(out_host, out.cpu().numpy())
+    # L2 index: the cosine logits are recovered from squared distances
+    ix2 = HipFlatIndex(D, 1, 0)
+    ix2.add(bank); ix2.add_labels(lab); ix2.set_num_classes(C)
+    out2 = ix2.search_aggregate(torch.from_numpy(q).cuda(), k).cpu().numpy()
+    r2, _ = oracle.knn_chain_f32(q, bank, k, "l2")
+    kf2, kl2 = oracle.gather_neighbours(r2, bank, lab, 1, nq)
+    assert np.abs(out2 - oracle.cross_attention(q[None], kf2, kl2)[0]).max() < 2e-4
+
+
+@pytest.mark.parametrize("B,S,C,h,w", [(2, 4, 5, 32, 32), (3, 14, 21, 224, 224), (2, 37, 151, 518, 518), (1, 7, 19, 100, 60)])
+def test_k6_upsample_argmax(cuda_device, B, S, C, h, w):
+    rng = np.random.default_rng(S)
+    lh = rng.random((B, S * S, C)).astype(np.float32)
+    lh /= lh.sum(-1, keepdims=True)
+    got = ops.upsample_argmax(torch.from_numpy(lh).cuda(), S, h, w).cpu().numpy()
+    ref = oracle.upsample_argmax(lh, S, h, w)
+    assert got.shape == (B, 1, h, w)
+    assert (got == ref).mean() > 0.9999
+
+
+def test_k6_golden_cluster_map(cuda_device, golden_dir):
+    g = np.load(f"{golden_dir}/g67_memory_evaluate.npz")
+    for name in ("unb", "bnd", "trim", "ade"):
+        C, D, H, ps = g[f"cfg_{name}"][:4].tolist()
+        lh = g[f"label_hat_{name}"]
+        got = ops.upsample_argmax(torch.from_numpy(lh).cuda(), H // ps, H, H).cpu().numpy()
+        assert (got == g[f"cluster_map_{name}"]).mean() > 0.9995
+
+
+def test_k7_predsmiou_golden(cuda_device, golden_dir):
+    g = np.load(f"{golden_dir}/g8_predsmiou.npz")
+    for name in ("c5", "c21", "ade"):
+        C, n, ign = g[f"cfg_{name}"].tolist()
+        gt, pred = g[f"gt_{name}"], g[f"pred_{name}"]
+        for mode, kw in {"hung": {}, "m2o": {"many_to_one": True},
+                         "m2o_prec": {"many_to_one": True, "precision_based": True}, "lin": {"linear_probe": True}}.items():
+            m = PredsmIoU(C, C, ignore_index=ign)
+            m.update(torch.from_numpy(gt.reshape(2, -1)), torch.from_numpy(pred.reshape(2, -1)))   # CPU in, GPU kernel
+            assert np.array_equal(m._conf_mat.cpu().numpy(), g[f"conf_{name}"])
+            miou, tp, fp, fn, reordered, bg = m.compute(is_global_zero=True, **kw)
+            assert abs(miou - float(g[f"miou_{name}_{mode}"])) < 1e-12
+            assert tp == g[f"tp_{name}_{mode}"].tolist() and fp == g[f"fp_{name}_{mode}"].tolist()
+            assert fn == g[f"fn_{name}_{mode}"].tolist()
+            assert abs(bg - float(g[f"bg_{name}_{mode}"])) < 1e-12
+            assert len(reordered) == int(g[f"nreordered_{name}_{mode}"])
+            assert reordered[:64] == g[f"reordered_head_{name}_{mode}"].tolist()
+        with pytest.raises(ValueError):
+            m.update(torch.zeros(3), torch.zeros(4))
+        assert m.compute(is_global_zero=False) == (0.0, [], [], [], [], 0.0)
+
+
+def test_k7_large_class_count_global_path(cuda_device):
+    rng = np.random.default_rng(0)
+    C = 200                                        # 200*200*4 B > LDS budget -> global-atomic path
+    gt = rng.integers(0, C, 200_000); pred = rng.integers(0, C, 200_000)
+    conf = torch.zeros((C, C), dtype=torch.int64, device="cuda")
+    ops.confusion_update(conf, torch.from_numpy(gt).cuda(), torch.from_numpy(pred).cuda(), None)
+    assert np.array_equal(conf.cpu().numpy(), oracle.confusion_matrix(gt, pred, C, C, None))
