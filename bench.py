@@ -109,6 +109,7 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         torch.distributed.init_process_group("nccl", device_id=device)
+    from hbird_mi import dist as hdist
     from hbird_mi.nn.search_hip import HipFlatIndex, merge_topk
 
     M, D, C, nq, k = a.rows, a.dim, a.classes, a.nq, a.k
@@ -121,6 +122,15 @@ def main():
         index.set_tuning(a.workgroups, a.panel)
     t_build = time.time()
     build_bank(index, lo, hi, D, C, device)
+    if world > 1:
+        # label rows and bank-row norms are small (6 GB / 40 MB at cfg-3): replicate them once so that any
+        # rank can aggregate the labels of any merged neighbour list
+        lab_all, counts = hdist.allgather_rows(index.gather_labels(torch.arange(hi - lo, device=device)))
+        nrm_all, _ = hdist.allgather_rows(index.copy_norms())
+        index.set_label_table(torch.cat([lab_all[r, :counts[r]] for r in range(world)]),
+                              torch.cat([nrm_all[r, :counts[r]] for r in range(world)]), 0)
+        del lab_all, nrm_all
+    torch.cuda.synchronize(device)
     t_build = time.time() - t_build
 
     g = torch.Generator(device=device)
@@ -132,18 +142,11 @@ def main():
 
     def step():
         if world == 1:
-            out = index.search_aggregate(q, k, beta=0.02)
-        else:
-            idx, dist = index.search(q, k, id_base=lo)
-            pi = torch.empty((world, nq, k), dtype=torch.int64, device=device)
-            pd = torch.empty((world, nq, k), dtype=torch.float32, device=device)
-            torch.distributed.all_gather_into_tensor(pi, idx)
-            torch.distributed.all_gather_into_tensor(pd, dist)
-            midx, mdist = merge_topk(pd[:, qs_lo:qs_hi].contiguous(), pi[:, qs_lo:qs_hi].contiguous(), 0)
-            # labels are co-sharded with the bank: every rank adds the contribution of ITS rows to the
-            # un-normalised softmax sums of all queries... (labels replicated variant: see DESIGN.md)
-            out = (midx, mdist)
-        return out
+            return index.search_aggregate(q, k, beta=0.02)
+        # every rank searches all queries on its shard; one all-gather of the per-rank top-k + local merge;
+        # each rank then aggregates the labels for its own slice of the queries
+        idx, dist = hdist.sharded_search(index.search, merge_topk, q, k, lo, 0)
+        return index.aggregate(q[qs_lo:qs_hi], idx[qs_lo:qs_hi], dist[qs_lo:qs_hi], beta=0.02)
 
     def sync():
         torch.cuda.synchronize(device)

@@ -22,6 +22,7 @@ from typing import Any, Dict, List, Optional, Tuple
 
 import torch
 
+from hbird_mi import dist as hdist
 from hbird_mi import ops
 from hbird_mi.models import FeatureExtractor, FeatureExtractorSimple
 from hbird_mi.nn.search_hip import HipFlatIndex, MAX_K, merge_topk, _METRICS
@@ -42,12 +43,6 @@ if not logger.handlers:
     logger.setLevel(getattr(logging, os.environ.get("HBIRD_LOG_LEVEL", "WARNING").upper(), logging.WARNING))
 
 _NN_METHODS = ("hip", "faiss", "scann")
-
-
-def _dist_info() -> Tuple[int, int]:
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
-        return torch.distributed.get_rank(), torch.distributed.get_world_size()
-    return 0, 1
 
 
 class HbirdEvaluation:
@@ -88,7 +83,7 @@ class HbirdEvaluation:
         self.f_mem_p = f_mem_p
         self.l_mem_p = l_mem_p
         self.num_sampled_features: Optional[int] = None
-        self.rank, self.world = _dist_info()
+        self.rank, self.world = hdist.rank_world()
 
         distance = str(nn_params.get("distance_measure", "dot_product")).lower()
         if distance not in _METRICS:
@@ -138,8 +133,7 @@ class HbirdEvaluation:
         if self.sharded:
             if total_flat is None:
                 raise ValueError("a sharded bank build needs a train_loader with a length")
-            per = (total_flat + self.world - 1) // self.world
-            own_lo, own_hi = min(total_flat, self.rank * per), min(total_flat, (self.rank + 1) * per)
+            own_lo, own_hi = hdist.shard_range(total_flat, self.rank, self.world)
         else:
             own_lo, own_hi = 0, float("inf")
         if self.memory_size is not None:
@@ -208,28 +202,15 @@ class HbirdEvaluation:
         counts = counts.cpu().tolist()
         self.id_base = sum(counts[:self.rank])
         self.total_rows = sum(counts)
-        C = self.num_classes
-        mx = max(counts)
-        lab_local = torch.zeros((mx, C), dtype=torch.float32, device=self.gpu_device)
-        nrm_local = torch.zeros((mx,), dtype=torch.float32, device=self.gpu_device)
-        if n_local:
-            ids = torch.arange(n_local, device=self.gpu_device)
-            lab_local[:n_local] = self.index.gather_labels(ids)
-            from hbird_mi import _lib
-            import ctypes
-            self.index.use_current_stream()
-            _lib.check(_lib.lib().hb_index_copy_norms(self.index._h, ctypes.c_void_p(nrm_local.data_ptr()), 1))
-        lab_all = torch.empty((self.world, mx, C), dtype=torch.float32, device=self.gpu_device)
-        nrm_all = torch.empty((self.world, mx), dtype=torch.float32, device=self.gpu_device)
-        torch.distributed.all_gather_into_tensor(lab_all, lab_local)
-        torch.distributed.all_gather_into_tensor(nrm_all, nrm_local)
+        self.index.use_current_stream()
+        lab_local = (self.index.gather_labels(torch.arange(n_local, device=self.gpu_device)) if n_local
+                     else torch.zeros((0, self.num_classes), device=self.gpu_device))
+        lab_all, _ = hdist.allgather_rows(lab_local)
+        nrm_all, _ = hdist.allgather_rows(self.index.copy_norms())
         labels = torch.cat([lab_all[r, :counts[r]] for r in range(self.world)]).contiguous()
         norms = torch.cat([nrm_all[r, :counts[r]] for r in range(self.world)]).contiguous()
-        self._label_table = (labels, norms)   # keep alive: the index borrows the pointers
-        from hbird_mi import _lib
-        import ctypes
-        _lib.check(_lib.lib().hb_index_set_label_table(self.index._h, ctypes.c_void_p(labels.data_ptr()),
-                                                       ctypes.c_void_p(norms.data_ptr()), labels.shape[0], C, 0))
+        self._label_table = (labels, norms)
+        self.index.set_label_table(labels, norms, 0)
 
     # ------------------------------------------------------------------------------------------------
     # bank persistence (reference 371-400): same two-tensor torch.save format
@@ -282,14 +263,9 @@ class HbirdEvaluation:
         """q_flat [nq, D] on the GPU -> (idx int64 [nq,k] global ids, dist [nq,k]); un-normalised queries (625)."""
         k = self.n_neighbours if k is None else k
         self.index.use_current_stream()
-        idx, dist = self.index.search(q_flat, k, id_base=self.id_base)
-        if self.sharded:
-            pi = torch.empty((self.world,) + tuple(idx.shape), dtype=idx.dtype, device=idx.device)
-            pd = torch.empty((self.world,) + tuple(dist.shape), dtype=dist.dtype, device=dist.device)
-            torch.distributed.all_gather_into_tensor(pi, idx)
-            torch.distributed.all_gather_into_tensor(pd, dist)
-            idx, dist = merge_topk(pd, pi, self.metric)
-        return idx, dist
+        if not self.sharded:
+            return self.index.search(q_flat, k, id_base=self.id_base)
+        return hdist.sharded_search(self.index.search, merge_topk, q_flat, k, self.id_base, self.metric)
 
     def _label_hat(self, feats: torch.Tensor, want_details: bool):
         """feats [B,N,D] -> label_hat [B,N,C] (+ neighbours when details are requested)."""
@@ -375,18 +351,10 @@ class HbirdEvaluation:
                 q = feats.reshape(B * N, D)
             else:
                 q = torch.zeros((0, D), dtype=torch.float32, device=self.gpu_device)
-            # all-gather of ragged query batches: sizes first, then zero-padded payload
-            nq = torch.zeros(self.world, dtype=torch.int64, device=self.gpu_device)
-            nq[self.rank] = q.shape[0]
-            torch.distributed.all_reduce(nq)
-            nq = nq.cpu().tolist()
-            mx = max(nq)
+            qall, nq = hdist.allgather_rows(q)      # ragged query batches, zero-padded to the largest
+            mx = qall.shape[1]
             if mx == 0:
                 continue
-            qpad = torch.zeros((mx, D), dtype=torch.float32, device=self.gpu_device)
-            qpad[:q.shape[0]] = q
-            qall = torch.empty((self.world, mx, D), dtype=torch.float32, device=self.gpu_device)
-            torch.distributed.all_gather_into_tensor(qall, qpad)
             idx, dist = self.find_neighbours(qall.view(self.world * mx, D), k)   # collective inside
             kf_all = None
             if want_details:

@@ -166,6 +166,26 @@ class HipFlatIndex:
         _lib.check(_lib.lib().hb_index_gather_labels(self._h, _ptr(ids), n, 0, _ptr(out), int(on_dev)))
         return out
 
+    def copy_norms(self) -> torch.Tensor:
+        """L2 norms of this shard's stored rows (CUDA tensor [ntotal])."""
+        out = torch.empty((self.ntotal,), dtype=torch.float32, device=torch.device("cuda", self.device))
+        if self.ntotal:
+            _lib.check(_lib.lib().hb_index_copy_norms(self._h, _ptr(out), 1))
+        return out
+
+    def set_label_table(self, labels: Optional[torch.Tensor], norms: Optional[torch.Tensor], id_base: int = 0):
+        """Borrow all-gathered label / norm tables that cover global ids [id_base, id_base + n)."""
+        if labels is None:
+            self._tables = None
+            _lib.check(_lib.lib().hb_index_set_label_table(self._h, None, None, 0, 0, 0))
+            return
+        labels = labels.contiguous().float(); norms = norms.contiguous().float()
+        assert labels.is_cuda and norms.is_cuda and labels.shape[0] == norms.shape[0]
+        self._tables = (labels, norms)     # keep alive: the index only borrows the pointers
+        self._c = int(labels.shape[1])
+        _lib.check(_lib.lib().hb_index_set_label_table(self._h, _ptr(labels), _ptr(norms), labels.shape[0],
+                                                       labels.shape[1], int(id_base)))
+
     def set_timing(self, on: bool):
         _lib.check(_lib.lib().hb_index_set_timing(self._h, int(on)))
 
@@ -268,11 +288,8 @@ class NearestNeighborSearchHIP(NearestNeighborSearchBase):
 
     def _search_device(self, q: torch.Tensor, k: int):
         self.index.use_current_stream()
-        idx, dist = self.index.search(q, k, self.id_base)
         if self.idx_shard and self.world > 1:
-            parts_i = torch.empty((self.world,) + tuple(idx.shape), dtype=idx.dtype, device=idx.device)
-            parts_d = torch.empty((self.world,) + tuple(dist.shape), dtype=dist.dtype, device=dist.device)
-            torch.distributed.all_gather_into_tensor(parts_i, idx)
-            torch.distributed.all_gather_into_tensor(parts_d, dist)
-            idx, dist = merge_topk(parts_d, parts_i, _METRICS[self.distance_measure])
-        return idx, dist
+            from hbird_mi import dist as hdist
+            return hdist.sharded_search(self.index.search, merge_topk, q, k, self.id_base,
+                                        _METRICS[self.distance_measure])
+        return self.index.search(q, k, self.id_base)

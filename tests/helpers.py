@@ -27,3 +27,28 @@ def golden_case(g, name):
     va_tok = [g[f"val_tok_{name}_{i}"] for i in range(2)]
     return dict(C=C, D=D, H=H, ps=ps, nb=nb, B=B, k=k, mem=None if mem < 0 else mem, aug=aug, ign=ign,
                 train=train, val=val, tr_tok=tr_tok, va_tok=va_tok, S=H // ps)
+
+
+class IndexedReplayExtractor(torch.nn.Module):
+    """Like ReplayExtractor, but the batch identifies itself through x[0,0,0,0] (so that ranks which skip
+    batches in a sharded build still get the right tokens)."""
+
+    def __init__(self, tokens_by_key, eval_spatial_resolution, d_model):
+        super().__init__()
+        self.tokens = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in tokens_by_key.items()}
+        self.eval_spatial_resolution = eval_spatial_resolution
+        self.d_model = d_model
+
+    def forward_features(self, x):
+        return self.tokens[int(x[0, 0, 0, 0].item())].clone().to(x.device), None
+
+
+def golden_case_indexed(g, name):
+    c = golden_case(g, name)
+    tok = {}
+    for i, (x, _) in enumerate(c["train"]):
+        x[0, 0, 0, 0] = float(i); tok[i] = c["tr_tok"][i]
+    for i, (x, _) in enumerate(c["val"]):
+        x[0, 0, 0, 0] = float(1000 + i); tok[1000 + i] = c["va_tok"][i]
+    c["tokens_by_key"] = tok
+    return c

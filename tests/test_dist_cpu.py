@@ -1,0 +1,84 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU composition in hbird_mi/dist.py.
+
+The HIP kernels cannot run here, so the per-rank searcher is the CPU oracle and the merge is a numpy
+restatement of hb_merge_topk's ordering -- both are test doubles; what is under test is the sharding
+arithmetic, the id bases, the ragged all-gather and the fact that an all-gather of per-shard top-k lists
+followed by a k-way merge reproduces the unsharded search exactly (ties included)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as td
+import torch.multiprocessing as mp
+
+import golden_inputs as gi
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _np_merge(dist_parts, idx_parts, metric):
+    d = dist_parts.numpy(); i = idx_parts.numpy()
+    parts, nq, k = d.shape
+    out_i = np.empty((nq, k), dtype=np.int64); out_d = np.empty((nq, k), dtype=np.float32)
+    for q in range(nq):
+        dd = d[:, q].reshape(-1); ii = i[:, q].reshape(-1)
+        key = -dd if metric == 0 else dd
+        missing = ii < 0
+        order = np.lexsort((ii, key, missing))[:k]
+        out_i[q] = ii[order]; out_d[q] = dd[order]
+    return torch.from_numpy(out_i), torch.from_numpy(out_d)
+
+
+def _worker(rank, world, port, metric_name, M, D, nq, k, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "open-hummingbird-eval_amd"), os.path.join(root, "tests")]
+    import oracle
+    from hbird_mi import dist as hdist
+    bank = gi.unit_bank(M, D, seed=1)
+    bank[M - 3] = bank[5]                      # a tie that straddles the shard boundary
+    q = gi.vit_like_queries(nq, D, seed=2)
+    lo, hi = hdist.shard_range(M, rank, world)
+    assert (lo, hi) == ((0, (M + 1) // 2) if rank == 0 else ((M + 1) // 2, M))
+
+    def local_search(qq, kk, id_base):
+        i, d = oracle.knn_chain_f32(qq.numpy(), bank[lo:hi], kk, metric_name, id_base)
+        return torch.from_numpy(i), torch.from_numpy(d)
+
+    metric = 0 if metric_name == "dot_product" else 1
+    idx, dist = hdist.sharded_search(local_search, _np_merge, torch.from_numpy(q), k, lo, metric)
+    ridx, rdist = oracle.knn_chain_f32(q, bank, k, metric_name)
+    ok = np.array_equal(idx.numpy(), ridx) and np.array_equal(dist.numpy(), rdist)
+    # ragged all-gather
+    rows = torch.full((3 + 2 * rank, 4), float(rank))
+    allr, counts = hdist.allgather_rows(rows)
+    ok = ok and counts == [3, 5] and allr.shape == (2, 5, 4) and float(allr[1, 4, 0]) == 1.0 and float(allr[0, 4, 0]) == 0.0
+    ok = ok and hdist.deal_round_robin(5, rank, world) == ([0, 2, 4] if rank == 0 else [1, 3])
+    ret[rank] = bool(ok)
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("metric", ["dot_product", "l2"])
+def test_sharded_search_equals_unsharded_world2(metric):
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, metric, 2001, 32, 37, 30, ret), nprocs=world, join=True)
+    assert ret[0] and ret[1]
+
+
+def test_shard_range_properties():
+    from hbird_mi import dist as hdist
+    for n in (0, 1, 7, 100, 10_000_000):
+        for world in (1, 2, 3, 8):
+            ranges = [hdist.shard_range(n, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:]))
+            assert sorted(sum((hdist.deal_round_robin(n % 50, r, world) for r in range(world)), [])) == list(range(n % 50))
