@@ -306,7 +306,9 @@ class HbirdEvaluation:
             if self.sharded:
                 self._evaluate_sharded(val_loader, S, metric, return_knn_details, knns, knns_labels, knns_ca_labels)
             else:
-                for x, y in tqdm(val_loader, desc="Evaluation loop"):
+                for bi, (x, y) in enumerate(tqdm(val_loader, desc="Evaluation loop")):
+                    if self.world > 1 and bi % self.world != self.rank:
+                        continue      # replica mode (idx_shard=False): validation batches are data-parallel
                     _, _, h, w = x.shape
                     feats = self._tokens(x)                                       # 217 (stays on the GPU)
                     y = (y.to(self.gpu_device) * 255).long()                       # 219 (255 is NOT remapped here)
@@ -316,7 +318,7 @@ class HbirdEvaluation:
                         knns.append(kf.cpu()); knns_labels.append(kl.cpu()); knns_ca_labels.append(label_hat.cpu())
                     cluster_map = ops.upsample_argmax(label_hat, S, h, w)           # 235-243
                     metric.update(y, cluster_map)                                   # 252 (streamed per batch)
-        jac, tp, fp, fn, _, _ = metric.compute(is_global_zero=True, sync_distributed=self.sharded,
+        jac, tp, fp, fn, _, _ = metric.compute(is_global_zero=True, sync_distributed=self.world > 1,
                                                return_reordered=False)            # 253
         if return_knn_details:
             details = {"knns": torch.cat(knns), "knns_labels": torch.cat(knns_labels),

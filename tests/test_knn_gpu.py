@@ -162,3 +162,51 @@ def test_mid_size_vs_float64_definition(cuda_device):
     i64, d64 = oracle.knn_f64(q, bank, k)
     rep = oracle.near_tie_report(idx, i64, d64)
     assert rep["excused_rate"] == 1.0 and rep["set_rate"] > 0.98, rep
+
+
+@pytest.mark.parametrize("M,D,nq", [(2_074_072, 384, 12_544), (1_000_000, 768, 21_904)])
+def test_full_batch_properties_at_scale(cuda_device, M, D, nq):
+    """cfg-2 bank (full size) and a cfg-3-shaped batch: size-independent properties + an oracle spot check."""
+    k = 30
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(M)
+    ix = HipFlatIndex(D, 0, 0)
+    ix.reserve(M)
+    for r in range(0, M, 500_000):
+        n = min(500_000, M - r)
+        ix.add(torch.randn((n, D), generator=g, device=dev), normalize=True)
+    assert ix.ntotal == M
+    q = 3.0 * torch.randn((nq, D), generator=g, device=dev)
+    # plant: query j (j < 256) is a scaled copy of bank row 7919*j -> that row must be its best neighbour
+    planted = torch.arange(256, device=dev) * 7919 % M
+    q[:256] = 4.0 * ix.reconstruct(planted)
+    idx, dist = ix.search(q, k)
+    assert (idx[:256, 0] == planted).all()
+    assert torch.allclose(dist[:256, 0], torch.full((256,), 4.0, device=dev), atol=1e-4)
+    assert (dist[:, :-1] >= dist[:, 1:]).all()                                  # sortedness
+    assert (idx >= 0).all() and (idx < M).all()
+    srt = idx.sort(dim=1).values
+    assert (srt[:, 1:] != srt[:, :-1]).all()                                    # no duplicates in a row
+    # idempotence / determinism: same call, same bits
+    idx2, dist2 = ix.search(q, k)
+    assert torch.equal(idx, idx2) and torch.equal(dist, dist2)
+    # sharding invariance: two half banks + merge == one bank
+    half = M // 2
+    ids = torch.arange(M, device=dev)
+    a, b = HipFlatIndex(D, 0, 0), HipFlatIndex(D, 0, 0)
+    for lo in range(0, M, 500_000):
+        hi = min(M, lo + 500_000)
+        rows = ix.reconstruct(ids[lo:hi])
+        if lo < half:
+            a.add(rows[: max(0, min(hi, half) - lo)])
+        if hi > half:
+            b.add(rows[max(0, half - lo):])
+    ia, da = a.search(q, k, id_base=0)
+    ib, db = b.search(q, k, id_base=half)
+    from hbird_mi.nn.search_hip import merge_topk
+    im, dm = merge_topk(torch.stack([da, db]), torch.stack([ia, ib]), 0)
+    assert torch.equal(im, idx) and torch.equal(dm, dist)
+    # oracle spot check on 48 random queries against the whole bank
+    sel = torch.randperm(nq, generator=torch.Generator().manual_seed(1))[:48]
+    bank = ix.reconstruct(ids).cpu().numpy()
+    _check_exact(idx[sel.to(dev)], dist[sel.to(dev)], q[sel.to(dev)].cpu().numpy(), bank, k, "dot_product")
