@@ -58,6 +58,8 @@ extern "C" int64_t hb_index_nlabels(const hb_index_t* ix) { return ix->nlabels; 
 extern "C" int hb_index_set_timing(hb_index_t* ix, int enable) { ix->time_kernels = enable; return 0; }
 extern "C" int hb_index_last_knn_ms(const hb_index_t* ix, double* ms) { *ms = ix->last_knn_ms; return 0; }
 extern "C" int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_tiles) {
+    // workgroups < 0 selects a timing-only ablation variant (HB_ABLATION builds): bits = -workgroups
+    if (workgroups < 0) { ix->ablate = -workgroups; workgroups = 0; } else ix->ablate = 0;
     ix->force_G = workgroups; ix->force_panel = panel_tiles; ix->sched = hb_schedule(); return 0;
 }
 extern "C" int hb_index_schedule_info(const hb_index_t* ix, int64_t out[8]) {

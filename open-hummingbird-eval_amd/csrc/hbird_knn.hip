@@ -61,24 +61,86 @@ __device__ __forceinline__ void list_insert(float* lst_s, unsigned* lst_i, int q
         _Pragma("unroll") for (int r = 0; r < 8; ++r) sc[r * 64 + lane] = acc[T][8 * (H) + r]; \
         break;
 
+// Epilogue of one (query tile, bank tile) pair for one wave: filter the wave's 256 x 32 scores against the
+// per-query thresholds (phase 1, always) and insert the rare survivors into the LDS lists (phase 2).
+template <bool SLOW = true>
+__device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, float* lst_s, unsigned* lst_i, float* sc,
+                                              int w, int lane, int k, unsigned bt) {
+    unsigned hmask = 0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        bool any0 = false, any1 = false;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { any0 |= acc[t][r] > thr; any1 |= acc[t][8 + r] > thr; }
+        if (__ballot(any0) != 0ull) hmask |= 1u << (2 * t);
+        if (__ballot(any1) != 0ull) hmask |= 1u << (2 * t + 1);
+    }
+    if (!SLOW) { asm volatile("" :: "s"(hmask)); return; }
+    while (hmask) {   // wave-uniform slow path: some score beat its query's k-th best
+        const int th = __builtin_ctz(hmask);
+        hmask &= hmask - 1;
+        switch (th) {
+            HB_DUMP_CASE(0, 0) HB_DUMP_CASE(0, 1) HB_DUMP_CASE(1, 0) HB_DUMP_CASE(1, 1)
+            HB_DUMP_CASE(2, 0) HB_DUMP_CASE(2, 1) HB_DUMP_CASE(3, 0) HB_DUMP_CASE(3, 1)
+            HB_DUMP_CASE(4, 0) HB_DUMP_CASE(4, 1) HB_DUMP_CASE(5, 0) HB_DUMP_CASE(5, 1)
+            HB_DUMP_CASE(6, 0) HB_DUMP_CASE(6, 1) HB_DUMP_CASE(7, 0) HB_DUMP_CASE(7, 1)
+        }
+        const unsigned row_base = bt * HB_BT + (th >> 1) * 32 + (th & 1) * 16;
+        // ascending bank-row order: (g, h, j) -> row = 8g + 4h + j within the half tile
+        for (int gg = 0; gg < 2; ++gg)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int j = 0; j < 4; ++j) {
+                    const float v = sc[(gg * 4 + j) * 64 + lane];
+                    unsigned long long m = __ballot(v > thr);
+                    m &= hh ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
+                    while (m) {
+                        const int l = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+                        const int n = l & 31;
+                        list_insert(lst_s, lst_i, w * 32 + n, k, s, row_base + gg * 8 + hh * 4 + j, lane);
+                        const float kth = lst_s[(w * 32 + n) * HB_KL + (k - 1)];
+                        if ((lane & 31) == n) thr = kth;
+                    }
+                }
+    }
+}
+
+// LDS map of the kernel (bytes): a 4-slot ring of k8 stages, two row-init buffers, the lists, the scratch
+#define KN_SLOT_BYTES 16384                 // 8 KiB bank fragments + 8 KiB query fragments (32 rows x 8 k blocks)
+#define KN_RING 4
+#define KN_BINIT (KN_RING * KN_SLOT_BYTES)  // 2 x 1 KiB
+#define KN_LISTS (KN_BINIT + 2048)
+#define KN_SCRATCH (KN_LISTS + 2 * HB_QT * HB_KL * 4)
+#define KN_LDS_TOTAL (KN_SCRATCH + HB_WAVES * 8 * 64 * 4)
+
+// One stage = one k8 fragment group of the pair tile: 32 MFMAs per wave, in two halves of 16 (bank row tiles
+// 0-3 = "X", 4-7 = "Y").  Fragments of the next half are fetched from LDS while the current half is in the
+// matrix pipe; HBM->LDS copies run three stages ahead (4-slot ring, hand-counted vmcnt).  Every non-MFMA
+// instruction of the stage (9 ds_read_b128, 2 LDS-DMA copies, scalar bookkeeping) is pinned into its own gap
+// between two MFMAs so that the 64-cycle matrix op ahead of it hides its issue.
+#define KN_MFMA(T, FR, B, S) acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(FR[(T) & 3][S], B[S], acc[T], 0, 0, 0);
+#define KN_FENCE __builtin_amdgcn_sched_barrier(0);
+
+// ABL: timing-only ablation bits (results are garbage when != 0): 1 = no LDS-DMA in the steady state,
+// 2 = no fragment reads, 4 = no barrier / vmcnt wait, 8 = no epilogue.
+template <int ABL>
 __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
-    float* lst_s = reinterpret_cast<float*>(smem + HB_LDS_LISTS);
-    unsigned* lst_i = reinterpret_cast<unsigned*>(smem + HB_LDS_LISTS + HB_QT * HB_KL * 4);
-    float* sc = reinterpret_cast<float*>(smem + HB_LDS_SCRATCH) + w * 512;
-    const int g8 = a.g8, k = a.k;
-    const int NS = g8 >> 1;   // stages per bank tile
+    float* lst_s = reinterpret_cast<float*>(smem + KN_LISTS);
+    unsigned* lst_i = reinterpret_cast<unsigned*>(smem + KN_LISTS + HB_QT * HB_KL * 4);
+    float* sc = reinterpret_cast<float*>(smem + KN_SCRATCH) + w * 512;
+    const int g8 = a.g8, k = a.k;   // g8 = stages per bank tile
     const int myq = w * 32 + (lane & 31);
 
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
     for (int si = seg_begin; si < seg_end; ++si) {
         const hb_seg seg = a.segs[si];
-        // ---- load (or start) this query tile's partial lists; each wave owns its 32 queries ----
-        {
+        {   // load (or start) this query tile's partial lists; each wave owns its 32 queries
             float* gs = a.state_s + (size_t)seg.slot * (HB_QT * HB_KL) + w * 1024;
             unsigned* gi = a.state_i + (size_t)seg.slot * (HB_QT * HB_KL) + w * 1024;
             for (int e = lane; e < 1024; e += 64) {
@@ -87,36 +149,55 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
             }
         }
         float thr = lst_s[myq * HB_KL + (k - 1)];
-
         const float* qsrc = a.q_tiles + ((size_t)(seg.q_tile * 8 + w) * g8) * HB_BLK + lane * 4;
-        const int total = seg.n_tiles * NS;
+        const int total = seg.n_tiles * g8;
         f32x16 acc[8];
+        f32x4 fa[4], fy[4], fb, fbk;   // X-half / Y-half bank fragments, query fragment (current, kept for Y)
 
-        // stage issue: wave w stages bank row-tile w and query row-tile w (2 KiB each), wave 0 also
-        // the 256 row-init values at the first stage of a bank tile
-        auto issue = [&](int bt, int ks, int buf) {
-            char* sb = smem + buf * HB_STAGE_BYTES;
-            const float* bsrc = a.bank_tiles + ((size_t)(bt * 8 + w) * g8 + ks * 2) * HB_BLK + lane * 4;
-            glds16(bsrc, sb + (w * 2) * 1024);
-            glds16(bsrc + HB_BLK, sb + (w * 2 + 1) * 1024);
-            const float* qs = qsrc + (size_t)(ks * 2) * HB_BLK;
-            glds16(qs, sb + 16384 + (w * 2) * 1024);
-            glds16(qs + HB_BLK, sb + 16384 + (w * 2 + 1) * 1024);
-            if (ks == 0 && w == 0) glds16(a.binit + (size_t)bt * HB_BT + lane * 4, sb + 32768);
+        // wave w stages bank row-tile w and query row-tile w of one k8 group (1 KiB each)
+        auto issue_a = [&](int bt, int ks, int slot) {
+            glds16(a.bank_tiles + ((size_t)(bt * 8 + w) * g8 + ks) * HB_BLK + lane * 4, smem + slot * KN_SLOT_BYTES + w * 1024);
+        };
+        auto issue_b = [&](int bt, int ks, int slot) {
+            glds16(qsrc + (size_t)ks * HB_BLK, smem + slot * KN_SLOT_BYTES + 8192 + w * 1024);
+            if (ks == 0 && w == 0) glds16(a.binit + (size_t)bt * HB_BT + lane * 4, smem + KN_BINIT + (bt & 1) * 1024);
         };
 
-        int bt = seg.b_tile0, ks = 0;         // stage being computed
-        int nbt_ = seg.b_tile0, nks = 0;      // stage being fetched
-        issue(nbt_, nks, 0);
+        int bt = seg.b_tile0, ks = 0;          // stage being computed
+        int fbt = seg.b_tile0, fks = 0;        // next stage to fetch
+        int slot_c = 0, slot_f = 0;            // ring slots of the computed / fetched stage
+        int left = total;                      // stages not yet fetched
+        // After the last real stage the fetch position stays put and the (free) slot is re-filled with the same
+        // stage: the steady-state loop has no data-dependent branches around its LDS traffic, so the compiler
+        // counts its lgkmcnt waits instead of draining.
+        auto advance_fetch = [&]() {
+            if (--left > 0) { if (++fks == g8) { fks = 0; ++fbt; } }
+            if (++slot_f == KN_RING) slot_f = 0;
+        };
+        // vmcnt is counted by hand (the compiler does not wait for LDS-DMA at a barrier): every wave issues
+        // exactly two copies per stage (wave 0 a third, the row-init values, at the first stage of a tile), so
+        // "all but the newest 2" covers everything up to and including the stage about to be published.
+        issue_a(fbt, fks, slot_f); issue_b(fbt, fks, slot_f); advance_fetch();
+        issue_a(fbt, fks, slot_f); issue_b(fbt, fks, slot_f); advance_fetch();
+        issue_a(fbt, fks, slot_f); issue_b(fbt, fks, slot_f); advance_fetch();
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __syncthreads();
+        {
+            const f32x4* A = reinterpret_cast<const f32x4*>(smem);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fa[t] = A[t * 64 + lane];
+            fb = reinterpret_cast<const f32x4*>(smem + 8192)[w * 64 + lane];
+        }
         for (int st = 0; st < total; ++st) {
-            __syncthreads();   // stage st landed everywhere; everyone is done with the other buffer
-            if (st + 1 < total) {
-                if (++nks == NS) { nks = 0; ++nbt_; }
-                issue(nbt_, nks, (st + 1) & 1);
+            if constexpr (!(ABL & 4)) {
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // my copies of stage st+1 have landed
+                __syncthreads();   // ... everyone's have; the slot of stage st-1 is free for stage st+3
             }
-            const char* sb = smem + (st & 1) * HB_STAGE_BYTES;
+            int slot_n = slot_c + 1; if (slot_n == KN_RING) slot_n = 0;
+            const f32x4* Ac = reinterpret_cast<const f32x4*>(smem + slot_c * KN_SLOT_BYTES) + lane;
+            const f32x4* An = reinterpret_cast<const f32x4*>(smem + slot_n * KN_SLOT_BYTES) + lane;
             if (ks == 0) {
-                const f32x4* bi = reinterpret_cast<const f32x4*>(sb + 32768);
+                const f32x4* bi = reinterpret_cast<const f32x4*>(smem + KN_BINIT + (bt & 1) * 1024);
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -126,70 +207,49 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
                         acc[t][4 * g + 2] = v[2]; acc[t][4 * g + 3] = v[3];
                     }
             }
-            const f32x4* A = reinterpret_cast<const f32x4*>(sb);
-            const f32x4* B = reinterpret_cast<const f32x4*>(sb + 16384);
+            // ---- X half: tiles 0-3, k-steps 0-3; fillers: the four Y fragments, the two LDS-DMA copies ----
+            KN_FENCE KN_MFMA(0, fa, fb, 0) KN_FENCE if constexpr (!(ABL & 2)) fy[0] = Ac[4 * 64];
+            KN_FENCE KN_MFMA(1, fa, fb, 0) KN_FENCE if constexpr (!(ABL & 2)) fy[1] = Ac[5 * 64];
+            KN_FENCE KN_MFMA(2, fa, fb, 0) KN_FENCE if constexpr (!(ABL & 2)) fy[2] = Ac[6 * 64];
+            KN_FENCE KN_MFMA(3, fa, fb, 0) KN_FENCE if constexpr (!(ABL & 2)) fy[3] = Ac[7 * 64];
+            KN_FENCE KN_MFMA(0, fa, fb, 1) KN_MFMA(1, fa, fb, 1) KN_FENCE
+            if constexpr (!(ABL & 1)) issue_a(fbt, fks, slot_f);
+            KN_FENCE KN_MFMA(2, fa, fb, 1) KN_MFMA(3, fa, fb, 1) KN_MFMA(0, fa, fb, 2) KN_MFMA(1, fa, fb, 2) KN_FENCE
+            if constexpr (!(ABL & 1)) issue_b(fbt, fks, slot_f);
+            KN_FENCE KN_MFMA(2, fa, fb, 2) KN_MFMA(3, fa, fb, 2) KN_FENCE
+            advance_fetch();
+            KN_FENCE KN_MFMA(0, fa, fb, 3) KN_MFMA(1, fa, fb, 3) KN_MFMA(2, fa, fb, 3) KN_MFMA(3, fa, fb, 3) KN_FENCE
+            fbk = fb;   // the Y half still needs this stage's query fragment
+            // ---- Y half: tiles 4-7; fillers: the X fragments and the query fragment of stage st+1 ----
+            KN_FENCE KN_MFMA(4, fy, fbk, 0) KN_FENCE if constexpr (!(ABL & 2)) fa[0] = An[0 * 64];
+            KN_FENCE KN_MFMA(5, fy, fbk, 0) KN_FENCE if constexpr (!(ABL & 2)) fa[1] = An[1 * 64];
+            KN_FENCE KN_MFMA(6, fy, fbk, 0) KN_FENCE if constexpr (!(ABL & 2)) fa[2] = An[2 * 64];
+            KN_FENCE KN_MFMA(7, fy, fbk, 0) KN_FENCE if constexpr (!(ABL & 2)) fa[3] = An[3 * 64];
+            KN_FENCE KN_MFMA(4, fy, fbk, 1) KN_FENCE
+            if constexpr (!(ABL & 2)) fb = reinterpret_cast<const f32x4*>(smem + slot_n * KN_SLOT_BYTES + 8192)[w * 64 + lane];
+            KN_FENCE
+            KN_MFMA(5, fy, fbk, 1) KN_MFMA(6, fy, fbk, 1) KN_MFMA(7, fy, fbk, 1)
+            KN_MFMA(4, fy, fbk, 2) KN_MFMA(5, fy, fbk, 2) KN_MFMA(6, fy, fbk, 2) KN_MFMA(7, fy, fbk, 2)
+            KN_MFMA(4, fy, fbk, 3) KN_MFMA(5, fy, fbk, 3) KN_MFMA(6, fy, fbk, 3) KN_MFMA(7, fy, fbk, 3)
+            KN_FENCE
+            slot_c = slot_n;
+            if (++ks == g8) {
+                if constexpr (!(ABL & 8)) tile_epilogue<!(ABL & 16)>(acc, thr, lst_s, lst_i, sc, w, lane, k, (unsigned)bt);
+                else {
 #pragma unroll
-            for (int gl = 0; gl < 2; ++gl) {
-                const f32x4 b = B[(w * 2 + gl) * 64 + lane];
-                f32x4 af[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) af[t] = A[(t * 2 + gl) * 64 + lane];
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int t = 0; t < 8; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t][s], b[s], acc[t], 0, 0, 0);
-            }
-            if (++ks == NS) {
-                // ---- epilogue: filter the 256x32 score tile of this wave against the thresholds ----
-                unsigned hmask = 0;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    bool any0 = false, any1 = false;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) { any0 |= acc[t][r] > thr; any1 |= acc[t][8 + r] > thr; }
-                    if (__ballot(any0) != 0ull) hmask |= 1u << (2 * t);
-                    if (__ballot(any1) != 0ull) hmask |= 1u << (2 * t + 1);
-                }
-                while (hmask) {   // wave-uniform slow path: some score beat its query's k-th best
-                    const int th = __builtin_ctz(hmask);
-                    hmask &= hmask - 1;
-                    switch (th) {
-                        HB_DUMP_CASE(0, 0) HB_DUMP_CASE(0, 1) HB_DUMP_CASE(1, 0) HB_DUMP_CASE(1, 1)
-                        HB_DUMP_CASE(2, 0) HB_DUMP_CASE(2, 1) HB_DUMP_CASE(3, 0) HB_DUMP_CASE(3, 1)
-                        HB_DUMP_CASE(4, 0) HB_DUMP_CASE(4, 1) HB_DUMP_CASE(5, 0) HB_DUMP_CASE(5, 1)
-                        HB_DUMP_CASE(6, 0) HB_DUMP_CASE(6, 1) HB_DUMP_CASE(7, 0) HB_DUMP_CASE(7, 1)
-                    }
-                    const unsigned row_base = (unsigned)bt * HB_BT + (th >> 1) * 32 + (th & 1) * 16;
-                    // ascending bank-row order: (g, h, j) -> row = 8g + 4h + j within the half tile
-                    for (int gg = 0; gg < 2; ++gg)
-                        for (int hh = 0; hh < 2; ++hh)
-                            for (int j = 0; j < 4; ++j) {
-                                const float v = sc[(gg * 4 + j) * 64 + lane];
-                                unsigned long long m = __ballot(v > thr);
-                                m &= hh ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
-                                while (m) {
-                                    const int l = __builtin_ctzll(m);
-                                    m &= m - 1;
-                                    const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-                                    const int n = l & 31;
-                                    list_insert(lst_s, lst_i, w * 32 + n, k, s, row_base + gg * 8 + hh * 4 + j, lane);
-                                    const float kth = lst_s[(w * 32 + n) * HB_KL + (k - 1)];
-                                    if ((lane & 31) == n) thr = kth;
-                                }
-                            }
+                    for (int t = 0; t < 8; ++t) asm volatile("" :: "v"(acc[t]));
                 }
                 ks = 0;
                 ++bt;
             }
         }
-        // ---- store the partial lists of this segment ----
-        {
+        {   // store the partial lists of this segment
             float* gs = a.state_s + (size_t)seg.slot * (HB_QT * HB_KL) + w * 1024;
             unsigned* gi = a.state_i + (size_t)seg.slot * (HB_QT * HB_KL) + w * 1024;
             for (int e = lane; e < 1024; e += 64) { gs[e] = lst_s[w * 1024 + e]; gi[e] = lst_i[w * 1024 + e]; }
         }
-        __syncthreads();   // staging buffers are reused by the next segment's first issue
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (unused) run-ahead copies
+        __syncthreads();   // the ring is reused by the next segment's prologue
     }
 }
 
@@ -340,9 +400,21 @@ void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out) {
             }
         }
     }
+    // XCD-aware placement (speed only, never correctness): hardware deals workgroups round-robin over the 8 XCDs
+    // (blocks b and b+8 share an L2), so logical ranges v = 0..G-1 -- neighbours share a query tile -- are laid
+    // out so that each XCD gets a contiguous run of them: block b runs logical range (b % 8) * (G / 8) + b / 8.
+    std::vector<int> logical_of_block(G);
+    for (int b = 0; b < G; ++b) {
+        if (G % 8 == 0) logical_of_block[b] = (b % 8) * (G / 8) + b / 8;
+        else {
+            const int q = G / 8, r = G % 8, x = b % 8;   // bijective variant for G not a multiple of 8
+            logical_of_block[b] = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
+        }
+    }
     out.wg_off.assign(G + 1, 0);
-    for (int w = 0; w < G; ++w) {
-        out.wg_off[w + 1] = out.wg_off[w] + (int)per_wg[w].size();
+    for (int b = 0; b < G; ++b) {
+        const int w = logical_of_block[b];
+        out.wg_off[b + 1] = out.wg_off[b] + (int)per_wg[w].size();
         out.segs.insert(out.segs.end(), per_wg[w].begin(), per_wg[w].end());
     }
     out.qt_off.assign(nqt + 1, 0);
@@ -409,13 +481,23 @@ int hb_launch_knn(hb_index* ix, int64_t nq, int k, int64_t id_base, int64_t* out
     a.state_s = reinterpret_cast<float*>(ix->state);
     a.state_i = reinterpret_cast<unsigned*>(ix->state + state_half);
     a.g8 = ix->g8; a.k = k;
+    typedef void (*knn_fn)(knn_args);
+    static const knn_fn variants[] = {knn_fused_kernel<0>,
+#ifdef HB_ABLATION
+                                      knn_fused_kernel<1>, knn_fused_kernel<2>, knn_fused_kernel<4>, knn_fused_kernel<8>, knn_fused_kernel<15>, knn_fused_kernel<16>,
+                                      knn_fused_kernel<13>, knn_fused_kernel<14>, knn_fused_kernel<11>, knn_fused_kernel<7>
+#endif
+    };
+    static const int variant_bits[] = {0, 1, 2, 4, 8, 15, 16, 13, 14, 11, 7};
     static bool attr_set = false;
     if (!attr_set) {
-        HB_HIP(hipFuncSetAttribute((const void*)knn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, HB_LDS_TOTAL));
+        for (knn_fn f : variants) HB_HIP(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, KN_LDS_TOTAL));
         attr_set = true;
     }
+    knn_fn fn = variants[0];
+    for (size_t i = 0; i < sizeof(variants) / sizeof(variants[0]); ++i) if (variant_bits[i] == ix->ablate) fn = variants[i];
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev0, s));
-    knn_fused_kernel<<<dim3((unsigned)sc.G), dim3(HB_THREADS), HB_LDS_TOTAL, s>>>(a);
+    fn<<<dim3((unsigned)sc.G), dim3(HB_THREADS), KN_LDS_TOTAL, s>>>(a);
     HB_HIP(hipGetLastError());
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
     const size_t msh = (size_t)sc.max_slots_per_qt * k * 8;
