@@ -26,7 +26,7 @@ typedef struct hb_index hb_index_t;
 
 #define HB_METRIC_IP 0 /* faiss.GpuIndexFlatIP, search_faiss.py:43-44 ("dot_product")        */
 #define HB_METRIC_L2 1 /* faiss.GpuIndexFlatL2, search_faiss.py:45-46 ("l2" / "euclidean")   */
-#define HB_MAX_K 32    /* neighbours per query on the fused path (reference default k = 30)  */
+#define HB_MAX_K 256   /* neighbours per query (reference default 30; k <= 32 keeps the lists in LDS) */
 
 const char* hb_last_error(void);
 /* faiss.get_num_gpus(), search_faiss.py:14 */

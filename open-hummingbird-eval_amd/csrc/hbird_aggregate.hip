@@ -9,6 +9,8 @@
 // the reference gathers on the CPU are never touched.  HBM-bound gather: one wave per query.
 #include "hbird_internal.h"
 
+#define AGG_MAX_K 256
+
 __global__ __launch_bounds__(256) void aggregate_kernel(const float* __restrict__ labels, int64_t nlabels, int C,
                                                         const float* __restrict__ bnorm,
                                                         const float* __restrict__ qnorm,
@@ -16,42 +18,50 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const float* __restrict_
                                                         const float* __restrict__ dist, int64_t nq, int k,
                                                         int64_t id_base, int metric, const float* __restrict__ qn2,
                                                         float beta, float* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= nq) return;   // whole wave exits together
-    // lanes j < k: logit of neighbour j  (k <= 64)
-    float logit = -INFINITY;
-    int64_t row = -1;
-    if (lane < k) {
-        const int64_t gid = idx[q * (int64_t)k + lane];
-        row = gid - id_base;
-        if (gid >= 0 && row >= 0 && row < nlabels) {
-            const float bn = fmaxf(bnorm[row], 1e-12f);
+    __shared__ float s_w[4][AGG_MAX_K];
+    __shared__ int64_t s_row[4][AGG_MAX_K];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wv;
+    if (q >= nq) return;   // whole wave exits together (no block-level barrier below)
+    float* wgt = s_w[wv];
+    int64_t* rows = s_row[wv];
+    // logits of the k neighbours (lane-strided), running maximum
+    float mx = -INFINITY;
+    for (int j = lane; j < k; j += 64) {
+        float logit = -INFINITY;
+        int64_t row = -1;
+        const int64_t gid = idx[q * (int64_t)k + j];
+        const int64_t r = gid - id_base;
+        if (gid >= 0 && r >= 0 && r < nlabels) {
+            row = r;
+            const float bn = fmaxf(bnorm[r], 1e-12f);
             const float qn = fmaxf(qnorm[q], 1e-12f);
-            float ip = dist[q * (int64_t)k + lane];
-            if (metric == 1) {
-                // squared L2 -> inner product: ip = (||q||^2 + ||b||^2 - d2) / 2
-                ip = 0.5f * (qn2[q] + bnorm[row] * bnorm[row] - ip);
-            }
+            float ip = dist[q * (int64_t)k + j];
+            if (metric == 1) ip = 0.5f * (qn2[q] + bnorm[r] * bnorm[r] - ip);   // squared L2 -> inner product
             logit = (ip / (qn * bn)) / beta;
-        } else {
-            row = -1;
         }
+        wgt[j] = logit;
+        rows[j] = row;
+        mx = fmaxf(mx, logit);
     }
-    float mx = logit;
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    float wgt = (row >= 0) ? expf(logit - mx) : 0.0f;
-    float den = wgt;
+    float den = 0.0f;
+    for (int j = lane; j < k; j += 64) {
+        const float e = rows[j] >= 0 ? expf(wgt[j] - mx) : 0.0f;
+        wgt[j] = e;
+        den += e;
+    }
     for (int o = 32; o > 0; o >>= 1) den += __shfl_xor(den, o);
-    wgt = den > 0.0f ? wgt / den : 0.0f;
+    const float inv = den > 0.0f ? 1.0f / den : 0.0f;
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are visible to all its lanes
     for (int c0 = 0; c0 < C; c0 += 64) {
         const int c = c0 + lane;
         float accv = 0.0f;
-        for (int j = 0; j < k; ++j) {
-            const float wj = __shfl(wgt, j);
-            const int64_t rj = __shfl(row, j);
-            if (rj >= 0 && c < C) accv = fmaf(wj, labels[rj * (int64_t)C + c], accv);
-        }
+        if (c < C)
+            for (int j = 0; j < k; ++j) {
+                const int64_t rj = rows[j];
+                if (rj >= 0) accv = fmaf(wgt[j] * inv, labels[rj * (int64_t)C + c], accv);
+            }
         if (c < C) out[q * (int64_t)C + c] = accv;
     }
 }
@@ -59,7 +69,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const float* __restrict_
 int hb_launch_aggregate(const hb_index* ix, const float* qnorm, const int64_t* idx, const float* dist, int64_t nq,
                         int k, int64_t id_base, float beta, float* out, hipStream_t s) {
     if (nq == 0) return 0;
-    if (k > 64) return hb_fail("hb_index_search_aggregate: k must be <= 64");
+    if (k > AGG_MAX_K) return hb_fail("hb_index_search_aggregate: k must be <= 256");
     const float* labels = ix->labels; const float* bnorm = ix->bnorm; int64_t nlab = ix->nlabels;
     if (ix->ext_labels) { labels = ix->ext_labels; bnorm = ix->ext_bnorm; nlab = ix->ext_n; id_base = ix->ext_base; }
     else if (!ix->labels || ix->nlabels < ix->ntotal) return hb_fail("hb_index_search_aggregate: label rows missing (hb_index_add_labels)");

@@ -34,6 +34,7 @@ struct knn_args {
     unsigned* state_i;
     int g8;   // Dp / 8
     int k;
+    int klw;  // list row stride in the state buffer: HB_KL, or k rounded up to 64 when k > HB_KL
 };
 
 __device__ __forceinline__ void glds16(const float* gsrc, char* lds_base) {
@@ -56,6 +57,36 @@ __device__ __forceinline__ void list_insert(float* lst_s, unsigned* lst_i, int q
     if (lane == p) { lst_s[ql * HB_KL + p] = s; lst_i[ql * HB_KL + p] = id; }
 }
 
+// Same insertion for lists that live in global memory (k > HB_KL): row stride KLW = k rounded up to 64,
+// each lane holds KLW/64 entries.  Only the owning wave ever touches a query's list; loads bypass the L1 and
+// the stores are drained before the next insertion reads the list again.
+__device__ __forceinline__ void list_insert_wide(float* gs, unsigned* gi, int k, int klw, float s, unsigned id, int lane) {
+    float es[4];
+    unsigned ei[4];
+    const int E = klw >> 6;
+    int p = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (e < E) {
+            const int j = e * 64 + lane;
+            es[e] = __hip_atomic_load(gs + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ei[e] = __hip_atomic_load(gi + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool better = j < k && ((es[e] > s) || (es[e] == s && ei[e] < id));
+            p += __popcll(__ballot(better));
+        }
+    }
+    if (p >= k) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (e < E) {
+            const int j = e * 64 + lane;
+            if (j >= p && j < k - 1) { gs[j + 1] = es[e]; gi[j + 1] = ei[e]; }
+        }
+    }
+    if (lane == 0) { gs[p] = s; gi[p] = id; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 #define HB_DUMP_CASE(T, H)                                                                     \
     case (2 * (T) + (H)):                                                                      \
         _Pragma("unroll") for (int r = 0; r < 8; ++r) sc[r * 64 + lane] = acc[T][8 * (H) + r]; \
@@ -63,9 +94,9 @@ __device__ __forceinline__ void list_insert(float* lst_s, unsigned* lst_i, int q
 
 // Epilogue of one (query tile, bank tile) pair for one wave: filter the wave's 256 x 32 scores against the
 // per-query thresholds (phase 1, always) and insert the rare survivors into the LDS lists (phase 2).
-template <bool SLOW = true>
+template <bool SLOW = true, bool WIDE = false>
 __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, float* lst_s, unsigned* lst_i, float* sc,
-                                              int w, int lane, int k, unsigned bt) {
+                                              int w, int lane, int k, unsigned bt, int klw = HB_KL) {
     unsigned hmask = 0;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -98,8 +129,15 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, floa
                         m &= m - 1;
                         const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
                         const int n = l & 31;
-                        list_insert(lst_s, lst_i, w * 32 + n, k, s, row_base + gg * 8 + hh * 4 + j, lane);
-                        const float kth = lst_s[(w * 32 + n) * HB_KL + (k - 1)];
+                        float kth;
+                        if constexpr (WIDE) {
+                            float* gs = lst_s + (size_t)(w * 32 + n) * klw;
+                            list_insert_wide(gs, lst_i + (size_t)(w * 32 + n) * klw, k, klw, s, row_base + gg * 8 + hh * 4 + j, lane);
+                            kth = __hip_atomic_load(gs + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else {
+                            list_insert(lst_s, lst_i, w * 32 + n, k, s, row_base + gg * 8 + hh * 4 + j, lane);
+                            kth = lst_s[(w * 32 + n) * HB_KL + (k - 1)];
+                        }
                         if ((lane & 31) == n) thr = kth;
                     }
                 }
@@ -124,7 +162,7 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, floa
 
 // ABL: timing-only ablation bits (results are garbage when != 0): 1 = no LDS-DMA in the steady state,
 // 2 = no fragment reads, 4 = no barrier / vmcnt wait, 8 = no epilogue.
-template <int ABL>
+template <int ABL, bool WIDE>
 __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -140,15 +178,24 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
     for (int si = seg_begin; si < seg_end; ++si) {
         const hb_seg seg = a.segs[si];
-        {   // load (or start) this query tile's partial lists; each wave owns its 32 queries
-            float* gs = a.state_s + (size_t)seg.slot * (HB_QT * HB_KL) + w * 1024;
-            unsigned* gi = a.state_i + (size_t)seg.slot * (HB_QT * HB_KL) + w * 1024;
+        const int klw = a.klw;   // list row stride (HB_KL on the LDS path)
+        float* wl_s = a.state_s + (size_t)seg.slot * HB_QT * klw;      // this slot's lists in global memory
+        unsigned* wl_i = a.state_i + (size_t)seg.slot * HB_QT * klw;
+        float thr;
+        if constexpr (WIDE) {
+            // k > HB_KL: the lists stay in global memory; only start them when the slot is new
+            if (seg.first)
+                for (int e = lane; e < 32 * klw; e += 64) { wl_s[(size_t)w * 32 * klw + e] = -INFINITY; wl_i[(size_t)w * 32 * klw + e] = HB_ID_NONE; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            thr = __hip_atomic_load(wl_s + (size_t)myq * klw + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            // load (or start) this query tile's partial lists; each wave owns its 32 queries
             for (int e = lane; e < 1024; e += 64) {
-                lst_s[w * 1024 + e] = seg.first ? -INFINITY : gs[e];
-                lst_i[w * 1024 + e] = seg.first ? HB_ID_NONE : gi[e];
+                lst_s[w * 1024 + e] = seg.first ? -INFINITY : wl_s[w * 1024 + e];
+                lst_i[w * 1024 + e] = seg.first ? HB_ID_NONE : wl_i[w * 1024 + e];
             }
+            thr = lst_s[myq * HB_KL + (k - 1)];
         }
-        float thr = lst_s[myq * HB_KL + (k - 1)];
         const float* qsrc = a.q_tiles + ((size_t)(seg.q_tile * 8 + w) * g8) * HB_BLK + lane * 4;
         const int total = seg.n_tiles * g8;
         f32x16 acc[8];
@@ -234,7 +281,10 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
             KN_FENCE
             slot_c = slot_n;
             if (++ks == g8) {
-                if constexpr (!(ABL & 8)) tile_epilogue<!(ABL & 16)>(acc, thr, lst_s, lst_i, sc, w, lane, k, (unsigned)bt);
+                if constexpr (!(ABL & 8)) {
+                    if constexpr (WIDE) tile_epilogue<true, true>(acc, thr, wl_s, wl_i, sc, w, lane, k, (unsigned)bt, klw);
+                    else tile_epilogue<!(ABL & 16), false>(acc, thr, lst_s, lst_i, sc, w, lane, k, (unsigned)bt);
+                }
                 else {
 #pragma unroll
                     for (int t = 0; t < 8; ++t) asm volatile("" :: "v"(acc[t]));
@@ -243,10 +293,8 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
                 ++bt;
             }
         }
-        {   // store the partial lists of this segment
-            float* gs = a.state_s + (size_t)seg.slot * (HB_QT * HB_KL) + w * 1024;
-            unsigned* gi = a.state_i + (size_t)seg.slot * (HB_QT * HB_KL) + w * 1024;
-            for (int e = lane; e < 1024; e += 64) { gs[e] = lst_s[w * 1024 + e]; gi[e] = lst_i[w * 1024 + e]; }
+        if constexpr (!WIDE) {   // store the partial lists of this segment
+            for (int e = lane; e < 1024; e += 64) { wl_s[w * 1024 + e] = lst_s[w * 1024 + e]; wl_i[w * 1024 + e] = lst_i[w * 1024 + e]; }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (unused) run-ahead copies
         __syncthreads();   // the ring is reused by the next segment's prologue
@@ -257,7 +305,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
 __global__ __launch_bounds__(64) void knn_merge_kernel(const float* __restrict__ state_s,
                                                        const unsigned* __restrict__ state_i,
                                                        const int* __restrict__ qt_off, const int* __restrict__ qt_slots,
-                                                       int64_t nq, int k, int64_t id_base, int metric,
+                                                       int64_t nq, int k, int klw, int64_t id_base, int metric,
                                                        const float* __restrict__ qn2, int64_t* __restrict__ out_idx,
                                                        float* __restrict__ out_dist) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -270,7 +318,7 @@ __global__ __launch_bounds__(64) void knn_merge_kernel(const float* __restrict__
     const int lane = threadIdx.x;
     for (int c = lane; c < n; c += 64) {
         const int sl = qt_slots[s0 + c / k], e = c % k;
-        const size_t off = (size_t)sl * (HB_QT * HB_KL) + (size_t)ql * HB_KL + e;
+        const size_t off = ((size_t)sl * HB_QT + ql) * klw + e;
         cs[c] = state_s[off];
         ci[c] = state_i[off];
     }
@@ -437,7 +485,9 @@ static int ensure_bytes(char** p, size_t* have, size_t need) {
 
 // q_tiles / q_aux must already be prepared by the caller (hb_index_search).
 int hb_launch_knn(hb_index* ix, int64_t nq, int k, int64_t id_base, int64_t* out_idx, float* out_dist) {
-    if (k < 1 || k > HB_KL) return hb_fail("hb_index_search: k must be in [1, 32] on the fused path");
+    if (k < 1 || k > 256) return hb_fail("hb_index_search: k must be in [1, 256]");
+    const bool wide = k > HB_KL;
+    const int klw = wide ? (k + 63) / 64 * 64 : HB_KL;
     if (nq == 0) return 0;
     const int nqt = (int)((nq + HB_QT - 1) / HB_QT);
     const int nbt = (int)((ix->ntotal + HB_BT - 1) / HB_BT);
@@ -471,7 +521,7 @@ int hb_launch_knn(hb_index* ix, int64_t nq, int k, int64_t id_base, int64_t* out
         HB_HIP(hipMemcpyAsync(ix->sched_dev + o_qs, sc.qt_slots.data(), b_qs, hipMemcpyHostToDevice, s));
         HB_HIP(hipStreamSynchronize(s));   // host vectors may be rebuilt by the next call
     }
-    const size_t state_half = (size_t)sc.n_slots * HB_QT * HB_KL * 4;
+    const size_t state_half = (size_t)sc.n_slots * HB_QT * klw * 4;
     if (ensure_bytes(&ix->state, &ix->state_bytes, 2 * state_half)) return -1;
 
     knn_args a;
@@ -480,32 +530,35 @@ int hb_launch_knn(hb_index* ix, int64_t nq, int k, int64_t id_base, int64_t* out
     a.wg_off = reinterpret_cast<const int*>(ix->sched_dev + o_wg);
     a.state_s = reinterpret_cast<float*>(ix->state);
     a.state_i = reinterpret_cast<unsigned*>(ix->state + state_half);
-    a.g8 = ix->g8; a.k = k;
+    a.g8 = ix->g8; a.k = k; a.klw = klw;
     typedef void (*knn_fn)(knn_args);
-    static const knn_fn variants[] = {knn_fused_kernel<0>,
+    static const knn_fn variants[] = {knn_fused_kernel<0, false>, knn_fused_kernel<0, true>,
 #ifdef HB_ABLATION
-                                      knn_fused_kernel<1>, knn_fused_kernel<2>, knn_fused_kernel<4>, knn_fused_kernel<8>, knn_fused_kernel<15>, knn_fused_kernel<16>,
-                                      knn_fused_kernel<13>, knn_fused_kernel<14>, knn_fused_kernel<11>, knn_fused_kernel<7>
+                                      knn_fused_kernel<1, false>, knn_fused_kernel<2, false>, knn_fused_kernel<4, false>,
+                                      knn_fused_kernel<8, false>, knn_fused_kernel<15, false>, knn_fused_kernel<16, false>,
+                                      knn_fused_kernel<13, false>, knn_fused_kernel<14, false>, knn_fused_kernel<11, false>,
+                                      knn_fused_kernel<7, false>
 #endif
     };
-    static const int variant_bits[] = {0, 1, 2, 4, 8, 15, 16, 13, 14, 11, 7};
+    static const int variant_bits[] = {0, -1, 1, 2, 4, 8, 15, 16, 13, 14, 11, 7};
     static bool attr_set = false;
     if (!attr_set) {
         for (knn_fn f : variants) HB_HIP(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, KN_LDS_TOTAL));
         attr_set = true;
     }
-    knn_fn fn = variants[0];
-    for (size_t i = 0; i < sizeof(variants) / sizeof(variants[0]); ++i) if (variant_bits[i] == ix->ablate) fn = variants[i];
+    knn_fn fn = variants[wide ? 1 : 0];
+    if (!wide && ix->ablate)
+        for (size_t i = 0; i < sizeof(variants) / sizeof(variants[0]); ++i) if (variant_bits[i] == ix->ablate) fn = variants[i];
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev0, s));
     fn<<<dim3((unsigned)sc.G), dim3(HB_THREADS), KN_LDS_TOTAL, s>>>(a);
     HB_HIP(hipGetLastError());
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
     const size_t msh = (size_t)sc.max_slots_per_qt * k * 8;
-    if (msh > 60000) return hb_fail("hb_index_search: too many partial lists per query tile for the merge kernel");
+    if (msh > 64000) return hb_fail("hb_index_search: too many partial lists per query tile for the merge kernel");
     const float* qn2 = ix->q_aux;   // [nq] chain ||q||^2 (valid for L2)
     knn_merge_kernel<<<dim3((unsigned)nq), dim3(64), msh, s>>>(a.state_s, a.state_i,
                                                                reinterpret_cast<const int*>(ix->sched_dev + o_qo),
-                                                               reinterpret_cast<const int*>(ix->sched_dev + o_qs), nq, k,
+                                                               reinterpret_cast<const int*>(ix->sched_dev + o_qs), nq, k, klw,
                                                                id_base, ix->metric, qn2, out_idx, out_dist);
     HB_HIP(hipGetLastError());
     if (ix->time_kernels) {

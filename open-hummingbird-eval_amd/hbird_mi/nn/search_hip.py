@@ -19,7 +19,7 @@ from hbird_mi import _lib
 from hbird_mi.nn.search_base import NearestNeighborSearchBase
 
 _METRICS = {"dot_product": 0, "l2": 1, "euclidean": 1}
-MAX_K = 32
+MAX_K = 256
 
 
 def _ptr(t):

@@ -146,7 +146,7 @@ def test_plugin_errors(cuda_device):
         NearestNeighborSearchHIP(fm, gpu_ids=[99])                       # search_faiss.py:25
     nn = NearestNeighborSearchHIP(fm, n_neighbors=5, some_unknown_kwarg=1)   # **kwargs swallowed
     with pytest.raises(ValueError):
-        nn.find_nearest_neighbors(fm[:2], k=64)
+        nn.find_nearest_neighbors(fm[:2], k=257)
 
 
 def test_mid_size_vs_float64_definition(cuda_device):
@@ -210,3 +210,37 @@ def test_full_batch_properties_at_scale(cuda_device, M, D, nq):
     sel = torch.randperm(nq, generator=torch.Generator().manual_seed(1))[:48]
     bank = ix.reconstruct(ids).cpu().numpy()
     _check_exact(idx[sel.to(dev)], dist[sel.to(dev)], q[sel.to(dev)].cpu().numpy(), bank, k, "dot_product")
+
+
+@pytest.mark.parametrize("M,D,nq,k,metric", [
+    (3000, 32, 70, 33, "dot_product"),
+    (5000, 64, 300, 64, "dot_product"),
+    (20000, 128, 260, 90, "dot_product"),     # cfg-5's k
+    (20000, 128, 260, 90, "l2"),
+    (4000, 48, 100, 200, "dot_product"),
+    (300, 16, 20, 256, "dot_product"),        # k = HB_MAX_K, fewer rows than... no: 300 rows > 256
+    (100, 16, 20, 128, "dot_product"),        # fewer rows than k
+])
+def test_wide_k_bit_exact(cuda_device, M, D, nq, k, metric):
+    """k > 32: the per-query lists live in global memory instead of LDS; same results."""
+    bank = gi.unit_bank(M, D, seed=M + k)
+    bank[M // 2] = bank[3]                    # a tie
+    q = gi.vit_like_queries(nq, D, seed=nq + k)
+    ix = HipFlatIndex(D, 0 if metric == "dot_product" else 1, 0)
+    ix.add(bank)
+    idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
+    _check_exact(idx, dist, q, bank, k, metric)
+    ix.set_tuning(5, 2)                       # several segments / slots per query tile
+    idx, dist = ix.search(q, k)
+    _check_exact(idx, dist, q, bank, k, metric)
+
+
+def test_wide_k_aggregate(cuda_device):
+    M, D, C, nq, k = 20000, 128, 19, 300, 90
+    bank = gi.unit_bank(M, D, seed=1); lab = gi.labels_from_masks(M, C, 196, seed=2)
+    q = gi.vit_like_queries(nq, D, seed=3)
+    ix = HipFlatIndex(D, 0, 0); ix.add(bank); ix.add_labels(lab); ix.set_num_classes(C)
+    out = ix.search_aggregate(torch.from_numpy(q).cuda(), k).cpu().numpy()
+    ridx, _ = oracle.knn_chain_f32(q, bank, k)
+    kf, kl = oracle.gather_neighbours(ridx, bank, lab, 1, nq)
+    assert np.abs(out - oracle.cross_attention(q[None], kf, kl)[0]).max() < 2e-5
