@@ -1,0 +1,194 @@
+"""Folder datasets for VOC / ADE20K / Cityscapes with paired (image, mask) transforms, PIL + numpy + torch only
+(counterparts of hbird/data/{voc,ade20k,cityscapes}/*_data.py and hbird/utils/{transforms,
+image_transformations}.py; host-side I/O, "next" row f3 of SURVEY.md section 8).
+
+Directory conventions follow the reference (DATASET.md):
+  voc         <root>/images/*.jpg, <root>/SegmentationClassAug/*.png (train), <root>/SegmentationClass/*.png (val),
+              <root>/sets/{trainaug,val}.txt                                   (voc_data.py:137-160)
+  ade20k      <root>/images/{training,validation}/*.jpg, <root>/annotations/{training,validation}/*.png
+                                                                               (ade20k_data.py:72-88)
+  cityscapes  <root>/leftImg8bit/{train,val}/<city>/*_leftImg8bit.png,
+              <root>/gtFine/{train,val}/<city>/*_gtFine_labelIds.png, labelId -> trainId (cityscapes_data.py:28-48)
+Samples are `(x float [3,S,S] normalised, y float [1,S,S] = mask / 255)` exactly as the reference's
+CombTransforms + ToTensor deliver them (hence `y * 255` in the evaluator, hbird_eval.py:219, 309).
+"""
+from __future__ import annotations
+
+import math
+import os
+import random
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+from PIL import Image, ImageEnhance
+from torch.utils.data import DataLoader, Dataset
+
+IMAGENET_MEAN = [0.485, 0.456, 0.406]
+IMAGENET_STD = [0.229, 0.224, 0.255]      # sic: the reference's value (hbird/utils/transforms.py:29)
+
+
+def read_file_set(path: str) -> List[str]:
+    with open(path) as f:
+        return [ln.strip() for ln in f if ln.strip()]
+
+
+def _to_tensor_img(img: Image.Image) -> torch.Tensor:
+    a = np.asarray(img, dtype=np.float32) / 255.0
+    t = torch.from_numpy(a).permute(2, 0, 1)
+    mean = torch.tensor(IMAGENET_MEAN).view(3, 1, 1)
+    std = torch.tensor(IMAGENET_STD).view(3, 1, 1)
+    return (t - mean) / std
+
+
+def _to_tensor_mask(mask: Image.Image) -> torch.Tensor:
+    a = np.asarray(mask, dtype=np.uint8)
+    return torch.from_numpy(a.astype(np.float32) / np.float32(255.0)).unsqueeze(0)
+
+
+class ValTransform:
+    """Resize both to (S,S): bilinear for the image, nearest for the mask (transforms.py:215-236)."""
+
+    def __init__(self, size: int):
+        self.size = size
+
+    def __call__(self, img, mask):
+        img = img.resize((self.size, self.size), Image.BILINEAR)
+        mask = mask.resize((self.size, self.size), Image.NEAREST)
+        return _to_tensor_img(img), _to_tensor_mask(mask)
+
+
+class TrainTransform:
+    """Colour jitter on the image (each of brightness/contrast/saturation/hue with p = 0.5, range 0.1) then a
+    shared RandomResizedCrop(size, scale=(0.5, 2.0), ratio=(3/4, 4/3)) (transforms.py:166-212)."""
+
+    def __init__(self, size: int, jitter: float = 0.1, p: float = 0.5, scale=(0.5, 2.0), ratio=(3 / 4, 4 / 3)):
+        self.size, self.jitter, self.p, self.scale, self.ratio = size, jitter, p, scale, ratio
+
+    def _jitter(self, img):
+        j = self.jitter
+        if random.random() < self.p:
+            img = ImageEnhance.Brightness(img).enhance(random.uniform(1 - j, 1 + j))
+        if random.random() < self.p:
+            img = ImageEnhance.Contrast(img).enhance(random.uniform(1 - j, 1 + j))
+        if random.random() < self.p:
+            img = ImageEnhance.Color(img).enhance(random.uniform(1 - j, 1 + j))
+        if random.random() < self.p:
+            h, s, v = img.convert("HSV").split()
+            shift = int(round(random.uniform(-j, j) * 255))
+            h = h.point(lambda x: (x + shift) % 256)
+            img = Image.merge("HSV", (h, s, v)).convert("RGB")
+        return img
+
+    def _crop_box(self, w, h):
+        area = w * h
+        log_r = (math.log(self.ratio[0]), math.log(self.ratio[1]))
+        for _ in range(10):
+            target = area * random.uniform(*self.scale)
+            ar = math.exp(random.uniform(*log_r))
+            cw, ch = int(round(math.sqrt(target * ar))), int(round(math.sqrt(target / ar)))
+            if 0 < cw <= w and 0 < ch <= h:
+                x0, y0 = random.randint(0, w - cw), random.randint(0, h - ch)
+                return x0, y0, x0 + cw, y0 + ch
+        # torchvision's fallback: central crop clamped to the ratio bounds
+        in_ratio = w / h
+        if in_ratio < self.ratio[0]:
+            cw, ch = w, int(round(w / self.ratio[0]))
+        elif in_ratio > self.ratio[1]:
+            ch, cw = h, int(round(h * self.ratio[1]))
+        else:
+            cw, ch = w, h
+        x0, y0 = (w - cw) // 2, (h - ch) // 2
+        return x0, y0, x0 + cw, y0 + ch
+
+    def __call__(self, img, mask):
+        img = self._jitter(img)
+        box = self._crop_box(*img.size)
+        img = img.crop(box).resize((self.size, self.size), Image.BILINEAR)
+        mask = mask.crop(box).resize((self.size, self.size), Image.NEAREST)
+        return _to_tensor_img(img), _to_tensor_mask(mask)
+
+
+# labelId -> trainId of cityscapes_data.py:28-48 (255 = void)
+_CITY_KEY = np.array([255, 255, 255, 255, 255, 255, 255, 255, 0, 1, 255, 255, 2, 3, 4, 255, 255, 255, 5, 255, 6, 7, 8,
+                      9, 10, 11, 12, 13, 14, 15, 255, 255, 16, 17, 18], dtype=np.uint8)
+
+
+class SegFolder(Dataset):
+    def __init__(self, name: str, root: str, split: str, transform, file_set: Optional[List[str]] = None):
+        self.name, self.root, self.split, self.transform = name, root, split, transform
+        self.pairs = self._collect(file_set)
+        if not self.pairs:
+            raise RuntimeError(f"Dataset not found or corrupted: no {name}/{split} samples under {root}")
+
+    def _collect(self, fs) -> List[Tuple[str, str]]:
+        r = self.root
+        if self.name == "voc":
+            seg = "SegmentationClassAug" if self.split == "train" else "SegmentationClass"
+            img_dir, seg_dir = os.path.join(r, "images"), os.path.join(r, seg)
+            if not (os.path.isdir(img_dir) and os.path.isdir(seg_dir)):
+                raise RuntimeError("Dataset not found or corrupted.")                 # voc_data.py:146-147
+            if fs is None:
+                fs = read_file_set(os.path.join(r, "sets", "trainaug.txt" if self.split == "train" else "val.txt"))
+            return [(os.path.join(img_dir, f"{f}.jpg"), os.path.join(seg_dir, f"{f}.png")) for f in sorted(fs)]
+        if self.name == "ade20k":
+            sub = "training" if self.split == "train" else "validation"
+            img_dir, ann_dir = os.path.join(r, "images", sub), os.path.join(r, "annotations", sub)
+            if fs is None:
+                fs = [f[:-4] for f in sorted(os.listdir(img_dir)) if f.endswith(".jpg")]
+            return [(os.path.join(img_dir, f"{f}.jpg"), os.path.join(ann_dir, f"{f}.png")) for f in sorted(fs)]
+        if self.name == "cityscapes":
+            img_root, gt_root = os.path.join(r, "leftImg8bit", self.split), os.path.join(r, "gtFine", self.split)
+            out = []
+            for city in sorted(os.listdir(img_root)):
+                for f in sorted(os.listdir(os.path.join(img_root, city))):
+                    if not f.endswith("_leftImg8bit.png"):
+                        continue
+                    stem = f[: -len("_leftImg8bit.png")]
+                    if fs is not None and stem not in fs:
+                        continue
+                    out.append((os.path.join(img_root, city, f), os.path.join(gt_root, city, stem + "_gtFine_labelIds.png")))
+            return out
+        raise NotImplementedError(f"folder dataset '{self.name}' is not implemented (COCO needs the reference's "
+                                  f"stuff/thing mapping files)")
+
+    def __len__(self):
+        return len(self.pairs)
+
+    def __getitem__(self, i):
+        ip, mp = self.pairs[i]
+        img = Image.open(ip).convert("RGB")
+        mask = Image.open(mp)
+        if self.name == "cityscapes":
+            ids = np.asarray(mask, dtype=np.int32)
+            mask = Image.fromarray(_CITY_KEY[np.clip(ids + 1, 0, len(_CITY_KEY) - 1)])   # cityscapes_data.py:50-58
+        return self.transform(img, mask)
+
+
+class FolderSegDataModule:
+    def __init__(self, name, data_dir, batch_size, num_workers, input_size, num_classes, train_fraction=1.0,
+                 train_fs_path=None, val_fs_path=None):
+        self.name, self.num_classes, self.batch_size, self.num_workers = name, num_classes, batch_size, num_workers
+        tfs = read_file_set(train_fs_path) if train_fs_path else None
+        vfs = read_file_set(val_fs_path) if val_fs_path else None
+        self.train = SegFolder(name, data_dir, "train", TrainTransform(input_size), tfs)
+        if train_fraction < 1.0:                                     # hbird/data/__init__.py:64-66
+            random.shuffle(self.train.pairs)
+            self.train.pairs = self.train.pairs[: int(len(self.train.pairs) * train_fraction)]
+        self.val = SegFolder(name, data_dir, "val", ValTransform(input_size), vfs)
+
+    def get_train_dataset_size(self):
+        return len(self.train)
+
+    def get_num_classes(self):
+        return self.num_classes
+
+    def _loader(self, ds):
+        return DataLoader(ds, batch_size=self.batch_size, shuffle=False, num_workers=self.num_workers,
+                          drop_last=False, pin_memory=True)
+
+    def train_dataloader(self):
+        return self._loader(self.train)
+
+    def val_dataloader(self):
+        return self._loader(self.val)

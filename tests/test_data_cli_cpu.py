@@ -1,0 +1,99 @@
+"""Host-side pieces that need no GPU: folder datasets (on a generated miniature VOC tree), transforms, CLI parsing,
+and the C-ABI surface (the library must load and export every symbol declared in include/hbird_hip.h)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _make_voc(root, n=6):
+    rng = np.random.default_rng(0)
+    for d in ("images", "SegmentationClassAug", "SegmentationClass", "sets"):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    names = [f"img{i:03d}" for i in range(n)]
+    for nm in names:
+        h, w = int(rng.integers(40, 80)), int(rng.integers(40, 80))
+        Image.fromarray(rng.integers(0, 255, (h, w, 3), dtype=np.uint8)).save(os.path.join(root, "images", nm + ".jpg"))
+        m = rng.integers(0, 21, (h, w), dtype=np.uint8); m[:2] = 255
+        for d in ("SegmentationClassAug", "SegmentationClass"):
+            Image.fromarray(m).save(os.path.join(root, d, nm + ".png"))
+    open(os.path.join(root, "sets", "trainaug.txt"), "w").write("\n".join(names[:4]))
+    open(os.path.join(root, "sets", "val.txt"), "w").write("\n".join(names[4:]))
+
+
+def test_voc_folder_datamodule(tmp_path):
+    from hbird_mi.data import get_dataset
+    _make_voc(str(tmp_path))
+    dm, ignore = get_dataset("voc", str(tmp_path), batch_size=2, num_workers=0, input_size=32)
+    assert ignore == 255 and dm.get_num_classes() == 21 and dm.get_train_dataset_size() == 4
+    for loader, n in ((dm.train_dataloader(), 4), (dm.val_dataloader(), 2)):
+        seen = 0
+        for x, y in loader:
+            assert x.shape[1:] == (3, 32, 32) and y.shape[1:] == (1, 32, 32) and x.dtype == torch.float32
+            cls = (y * 255).long()                      # hbird_eval.py:219 round trip
+            assert ((cls >= 0) & ((cls <= 20) | (cls == 255))).all()
+            seen += x.shape[0]
+        assert seen == n
+    dm2, _ = get_dataset("voc*0.5", str(tmp_path), 2, 0, 32)
+    assert dm2.get_train_dataset_size() == 2
+    with pytest.raises(ValueError):
+        get_dataset("imagenet", str(tmp_path), 2, 0, 32)
+    with pytest.raises(RuntimeError):
+        get_dataset("voc", str(tmp_path / "nope"), 2, 0, 32)
+
+
+def test_dataset_table_matches_reference_constants():
+    from hbird_mi.data import DATASET_INFO
+    assert DATASET_INFO == {"voc": (21, 255), "ade20k": (151, 0), "cityscapes": (19, 255), "coco-thing": (12, 255),
+                            "coco-stuff": (15, 255)}
+
+
+def test_synthetic_datamodule_is_deterministic():
+    from hbird_mi.data import get_dataset
+    a, _ = get_dataset("synthetic", "", 4, 0, 32)
+    b, _ = get_dataset("synthetic", "", 4, 0, 32)
+    xa, ya = next(iter(a.train_dataloader())); xb, yb = next(iter(b.train_dataloader()))
+    assert torch.equal(xa, xb) and torch.equal(ya, yb) and xa.shape == (4, 3, 32, 32)
+    assert torch.equal((ya * 255).long().unique(), (ya * 255).round().long().unique())
+
+
+def test_cli_parsing():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hb_cli", os.path.join(ROOT, "eval.py"))
+    cli = importlib.util.module_from_spec(spec); spec.loader.exec_module(cli)
+    assert cli.parse_nn_params(["idx_shard=true", "gpu_ids=3", "beta=0.5", "distance_measure=l2"]) == \
+        {"idx_shard": True, "gpu_ids": 3, "beta": 0.5, "distance_measure": "l2"}
+    a = cli.build_parser().parse_args(["--dataset-name", "voc*0.2", "--data-dir", "/x", "--d-model", "384",
+                                       "--patch-size", "16", "--nn-method", "faiss", "--nn-param", "use_fp16=false"])
+    assert a.n_neighbours == 30 and a.batch_size == 64 and a.input_size == 224 and a.seed == 123
+    with pytest.raises(SystemExit):
+        cli.build_parser().parse_args(["--dataset-name", "voc", "--data-dir", "/x", "--d-model", "0", "--patch-size", "16"])
+
+
+def test_c_abi_library_loads_and_exports_every_declared_symbol():
+    """No compute calls (no GPU here): the .so must load and export exactly what include/hbird_hip.h declares."""
+    from hbird_mi import _lib
+    L = _lib.lib()
+    header = open(os.path.join(ROOT, "include", "hbird_hip.h")).read()
+    declared = set(re.findall(r"\b(hb_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in hbird_hip.h but not exported by libhbird_hip.so"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.device_count() == 0 or _lib.device_count() > 0
+
+
+def test_product_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from hbird_mi.nn.search_hip import NearestNeighborSearchHIP
+    from hbird_mi.utils.eval_metrics import PredsmIoU
+    with pytest.raises(RuntimeError):
+        NearestNeighborSearchHIP(torch.zeros(4, 8))
+    with pytest.raises(RuntimeError):
+        PredsmIoU(3, 3)

@@ -97,3 +97,16 @@ def test_hbird_evaluation_entry_point_synthetic(cuda_device):
                                    batch_size=8, input_size=64, device="cuda", nn_method="faiss", ftr_extr_fn=fn,
                                    memory_size=640, return_knn_details=True)
     assert det["knns_ca_labels"].shape == (16, 64, 6) and 0.0 < miou_b <= 1.0
+
+
+def test_cli_synthetic_self_check(cuda_device, tmp_path, capsys):
+    import importlib.util, json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("hb_cli", os.path.join(root, "eval.py"))
+    cli = importlib.util.module_from_spec(spec); spec.loader.exec_module(cli)
+    out = str(tmp_path / "res.json")
+    cli.main(["--dataset-name", "synthetic", "--data-dir", "", "--d-model", "3", "--patch-size", "8", "--input-size", "64",
+              "--batch-size", "8", "--device", "cuda", "--nn-method", "hip", "--nn-param", "distance_measure=dot_product",
+              "--out", out, "--log-level", "WARNING"])
+    res = json.load(open(out))
+    assert 0.5 < res["miou"] <= 1.0 and res["nn_method"] == "hip"
