@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workgroups", type=int, default=0)
     ap.add_argument("--panel", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=0, help="kNN kernel variant (0: 8 waves, 1: 4 waves)")
     return ap.parse_args()
 
 
@@ -120,6 +121,8 @@ def main():
     index.use_current_stream()
     if a.workgroups or a.panel:
         index.set_tuning(a.workgroups, a.panel)
+    if a.variant:
+        index.set_variant(a.variant)
     t_build = time.time()
     build_bank(index, lo, hi, D, C, device)
     if world > 1:

@@ -116,6 +116,9 @@ int hb_index_set_timing(hb_index_t* ix, int enable);
 int hb_index_last_knn_ms(const hb_index_t* ix, double* ms);
 /* Overrides for tests: number of workgroups (0 = one per CU) and bank tiles per panel (0 = auto). */
 int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_tiles);
+/* kNN kernel variant: 0 = 8 waves per workgroup (two per SIMD, default), 1 = 4 waves (one per SIMD, 256
+ * accumulator registers per lane).  Same results; for tuning. */
+int hb_index_set_variant(hb_index_t* ix, int variant);
 /* Work-list statistics of the last search: out[0]=workgroups, [1]=segments, [2]=slots, [3]=panel tiles,
  * [4]=max slots per query tile, [5]=query tiles, [6]=bank tiles. */
 int hb_index_schedule_info(const hb_index_t* ix, int64_t out[8]);

@@ -62,6 +62,11 @@ extern "C" int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_til
     if (workgroups < 0) { ix->ablate = -workgroups; workgroups = 0; } else ix->ablate = 0;
     ix->force_G = workgroups; ix->force_panel = panel_tiles; ix->sched = hb_schedule(); return 0;
 }
+extern "C" int hb_index_set_variant(hb_index_t* ix, int variant) {
+    if (variant < 0 || variant > 1) return hb_fail("hb_index_set_variant: unknown kernel variant");
+    ix->variant = variant;
+    return 0;
+}
 extern "C" int hb_index_schedule_info(const hb_index_t* ix, int64_t out[8]) {
     const hb_schedule& s = ix->sched;
     out[0] = s.G; out[1] = (int64_t)s.segs.size(); out[2] = s.n_slots; out[3] = s.panel; out[4] = s.max_slots_per_qt;

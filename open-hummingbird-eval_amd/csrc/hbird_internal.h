@@ -64,6 +64,7 @@ struct hb_index {
     char* tmp = nullptr; size_t tmp_bytes = 0;           // staging for host<->device convenience paths
     hb_schedule sched;                                   // cached for (nqt, nbt)
     int force_G = 0, force_panel = 0;                    // test/tuning overrides
+    int variant = 0;                                     // 0: 8-wave kernel, 1: 4-wave (one wave per SIMD) kernel
     int ablate = 0;                                      // timing-only kernel ablation (HB_ABLATION builds)
     double last_knn_ms = 0.0;                            // HIP-event time of the last knn kernel launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

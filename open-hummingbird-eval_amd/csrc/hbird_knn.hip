@@ -19,73 +19,7 @@
 #include <algorithm>
 #include <map>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) const void gbl_cvoid;
-
-struct knn_args {
-    const float* bank_tiles;
-    const float* binit;
-    const float* q_tiles;
-    const hb_seg* segs;
-    const int* wg_off;
-    float* state_s;
-    unsigned* state_i;
-    int g8;   // Dp / 8
-    int k;
-    int klw;  // list row stride in the state buffer: HB_KL, or k rounded up to 64 when k > HB_KL
-};
-
-__device__ __forceinline__ void glds16(const float* gsrc, char* lds_base) {
-    // 64 lanes x 16 B: per-lane global source, LDS destination = wave-uniform base + 16*lane
-    __builtin_amdgcn_global_load_lds((gbl_cvoid*)gsrc, (lds_void*)lds_base, 16, 0, 0);
-}
-
-// Wave-cooperative insertion of candidate (s, id) into the sorted list of local query ql
-// (lanes 0..k-1 each hold one entry; the list stays sorted by (score desc, id asc)).
-__device__ __forceinline__ void list_insert(float* lst_s, unsigned* lst_i, int ql, int k, float s, unsigned id,
-                                            int lane) {
-    const int e = lane & 31;
-    const float es = lst_s[ql * HB_KL + e];
-    const unsigned ei = lst_i[ql * HB_KL + e];
-    const bool better = (es > s) || (es == s && ei < id);
-    const unsigned long long kmask = (k >= 32) ? 0xFFFFFFFFull : ((1ull << k) - 1ull);
-    const int p = __popcll(__ballot(better) & kmask);   // entries 0..p-1 beat the candidate
-    if (p >= k) return;                                  // wave-uniform: not among the k best
-    if (lane >= p && lane < k - 1) { lst_s[ql * HB_KL + lane + 1] = es; lst_i[ql * HB_KL + lane + 1] = ei; }
-    if (lane == p) { lst_s[ql * HB_KL + p] = s; lst_i[ql * HB_KL + p] = id; }
-}
-
-// Same insertion for lists that live in global memory (k > HB_KL): row stride KLW = k rounded up to 64,
-// each lane holds KLW/64 entries.  Only the owning wave ever touches a query's list; loads bypass the L1 and
-// the stores are drained before the next insertion reads the list again.
-__device__ __forceinline__ void list_insert_wide(float* gs, unsigned* gi, int k, int klw, float s, unsigned id, int lane) {
-    float es[4];
-    unsigned ei[4];
-    const int E = klw >> 6;
-    int p = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (e < E) {
-            const int j = e * 64 + lane;
-            es[e] = __hip_atomic_load(gs + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ei[e] = __hip_atomic_load(gi + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool better = j < k && ((es[e] > s) || (es[e] == s && ei[e] < id));
-            p += __popcll(__ballot(better));
-        }
-    }
-    if (p >= k) return;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (e < E) {
-            const int j = e * 64 + lane;
-            if (j >= p && j < k - 1) { gs[j + 1] = es[e]; gi[j + 1] = ei[e]; }
-        }
-    }
-    if (lane == 0) { gs[p] = s; gi[p] = id; }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
+#include "hbird_knn_dev.h"
 
 #define HB_DUMP_CASE(T, H)                                                                     \
     case (2 * (T) + (H)):                                                                      \
@@ -144,21 +78,12 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, floa
     }
 }
 
-// LDS map of the kernel (bytes): a 4-slot ring of k8 stages, two row-init buffers, the lists, the scratch
-#define KN_SLOT_BYTES 16384                 // 8 KiB bank fragments + 8 KiB query fragments (32 rows x 8 k blocks)
-#define KN_RING 4
-#define KN_BINIT (KN_RING * KN_SLOT_BYTES)  // 2 x 1 KiB
-#define KN_LISTS (KN_BINIT + 2048)
-#define KN_SCRATCH (KN_LISTS + 2 * HB_QT * HB_KL * 4)
-#define KN_LDS_TOTAL (KN_SCRATCH + HB_WAVES * 8 * 64 * 4)
-
 // One stage = one k8 fragment group of the pair tile: 32 MFMAs per wave, in two halves of 16 (bank row tiles
 // 0-3 = "X", 4-7 = "Y").  Fragments of the next half are fetched from LDS while the current half is in the
 // matrix pipe; HBM->LDS copies run three stages ahead (4-slot ring, hand-counted vmcnt).  Every non-MFMA
 // instruction of the stage (9 ds_read_b128, 2 LDS-DMA copies, scalar bookkeeping) is pinned into its own gap
 // between two MFMAs so that the 64-cycle matrix op ahead of it hides its issue.
 #define KN_MFMA(T, FR, B, S) acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(FR[(T) & 3][S], B[S], acc[T], 0, 0, 0);
-#define KN_FENCE __builtin_amdgcn_sched_barrier(0);
 
 // ABL: timing-only ablation bits (results are garbage when != 0): 1 = no LDS-DMA in the steady state,
 // 2 = no fragment reads, 4 = no barrier / vmcnt wait, 8 = no epilogue.
@@ -203,10 +128,11 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
 
         // wave w stages bank row-tile w and query row-tile w of one k8 group (1 KiB each)
         auto issue_a = [&](int bt, int ks, int slot) {
+            if constexpr (ABL & 32) bt = bt & 7;   // timing only: 8 bank tiles, L2-resident
             glds16(a.bank_tiles + ((size_t)(bt * 8 + w) * g8 + ks) * HB_BLK + lane * 4, smem + slot * KN_SLOT_BYTES + w * 1024);
         };
         auto issue_b = [&](int bt, int ks, int slot) {
-            glds16(qsrc + (size_t)ks * HB_BLK, smem + slot * KN_SLOT_BYTES + 8192 + w * 1024);
+            glds16(((ABL & 64) ? a.q_tiles + (size_t)w * g8 * HB_BLK + lane * 4 : qsrc) + (size_t)ks * HB_BLK, smem + slot * KN_SLOT_BYTES + 8192 + w * 1024);
             if (ks == 0 && w == 0) glds16(a.binit + (size_t)bt * HB_BT + lane * 4, smem + KN_BINIT + (bt & 1) * 1024);
         };
 
@@ -537,10 +463,13 @@ int hb_launch_knn(hb_index* ix, int64_t nq, int k, int64_t id_base, int64_t* out
                                       knn_fused_kernel<1, false>, knn_fused_kernel<2, false>, knn_fused_kernel<4, false>,
                                       knn_fused_kernel<8, false>, knn_fused_kernel<15, false>, knn_fused_kernel<16, false>,
                                       knn_fused_kernel<13, false>, knn_fused_kernel<14, false>, knn_fused_kernel<11, false>,
-                                      knn_fused_kernel<7, false>
+                                      knn_fused_kernel<7, false>, knn_fused_kernel<3, false>, knn_fused_kernel<5, false>,
+                                      knn_fused_kernel<6, false>, knn_fused_kernel<9, false>, knn_fused_kernel<10, false>,
+                                      knn_fused_kernel<12, false>, knn_fused_kernel<32, false>, knn_fused_kernel<64, false>,
+                                      knn_fused_kernel<96, false>
 #endif
     };
-    static const int variant_bits[] = {0, -1, 1, 2, 4, 8, 15, 16, 13, 14, 11, 7};
+    static const int variant_bits[] = {0, -1, 1, 2, 4, 8, 15, 16, 13, 14, 11, 7, 3, 5, 6, 9, 10, 12, 32, 64, 96};
     static bool attr_set = false;
     if (!attr_set) {
         for (knn_fn f : variants) HB_HIP(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, KN_LDS_TOTAL));
@@ -549,8 +478,18 @@ int hb_launch_knn(hb_index* ix, int64_t nq, int k, int64_t id_base, int64_t* out
     knn_fn fn = variants[wide ? 1 : 0];
     if (!wide && ix->ablate)
         for (size_t i = 0; i < sizeof(variants) / sizeof(variants[0]); ++i) if (variant_bits[i] == ix->ablate) fn = variants[i];
+    int threads = HB_THREADS;
+    if (ix->variant == 1) {
+        fn = hb_knn_w4_kernel(wide);
+        threads = 256;
+        static bool w4_attr[2] = {false, false};
+        if (!w4_attr[wide]) {
+            HB_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, KN_LDS_TOTAL));
+            w4_attr[wide] = true;
+        }
+    }
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev0, s));
-    fn<<<dim3((unsigned)sc.G), dim3(HB_THREADS), KN_LDS_TOTAL, s>>>(a);
+    fn<<<dim3((unsigned)sc.G), dim3(threads), KN_LDS_TOTAL, s>>>(a);
     HB_HIP(hipGetLastError());
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
     const size_t msh = (size_t)sc.max_slots_per_qt * k * 8;

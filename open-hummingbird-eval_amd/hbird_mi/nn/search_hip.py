@@ -197,6 +197,9 @@ class HipFlatIndex:
     def set_tuning(self, workgroups: int = 0, panel_tiles: int = 0):
         _lib.check(_lib.lib().hb_index_set_tuning(self._h, int(workgroups), int(panel_tiles)))
 
+    def set_variant(self, variant: int):
+        _lib.check(_lib.lib().hb_index_set_variant(self._h, int(variant)))
+
     def schedule_info(self) -> dict:
         out = (ctypes.c_int64 * 8)()
         _lib.check(_lib.lib().hb_index_schedule_info(self._h, out))

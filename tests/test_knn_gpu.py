@@ -244,3 +244,18 @@ def test_wide_k_aggregate(cuda_device):
     ridx, _ = oracle.knn_chain_f32(q, bank, k)
     kf, kl = oracle.gather_neighbours(ridx, bank, lab, 1, nq)
     assert np.abs(out - oracle.cross_attention(q[None], kf, kl)[0]).max() < 2e-5
+
+
+@pytest.mark.parametrize("M,D,nq,k", [(5000, 64, 300, 30), (20000, 384, 520, 30), (3000, 32, 100, 90)])
+def test_four_wave_kernel_variant_bit_exact(cuda_device, M, D, nq, k):
+    """hb_index_set_variant(1): one wave per SIMD with 256 accumulator registers -- same results."""
+    bank = gi.unit_bank(M, D, seed=1)
+    q = gi.vit_like_queries(nq, D, seed=2)
+    ix = HipFlatIndex(D, 0, 0)
+    ix.add(bank)
+    ix.set_variant(1)
+    idx, dist = ix.search(q, k)
+    _check_exact(idx, dist, q, bank, k, "dot_product")
+    ix.set_tuning(5, 2)
+    idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
+    _check_exact(idx, dist, q, bank, k, "dot_product")
