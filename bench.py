@@ -173,6 +173,14 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "latest_knn_traffic.json")
+    if world == 1 and os.path.exists(tpath):
+        # PMC counters cannot be read from inside the bench; the committed rocprofv3 --pmc passes of this very
+        # command (tools/gpu_profile.sh) provide them when the workload matches
+        t = json.load(open(tpath))
+        if t.get("workload") == {"bank_rows": M, "dim": D, "k": k, "queries_per_step": nq}:
+            traffic = t["traffic_bytes_per_launch"]
     if rank == 0:
         kms = float(np.mean(knn_ms))
         flops = 2.0 * nq * (hi - lo) * D
@@ -188,7 +196,8 @@ def main():
                        "parallelism": f"bank-shard{world}" if world > 1 else "single-gpu",
                        "bank_build_s": round(t_build, 2), "schedule": index.schedule_info()},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "bytes/launch (L2-miss side, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
                          "kernel": "knn_fused_kernel", "avg_kernel_ms": kms,
                          "algorithmic_flops_per_launch": flops},
         }

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Time the secondary hot-path kernels (K1, K2, K3, K5, K6, K7) at cfg-2 / cfg-3 shapes and report achieved GB/s
+against their algorithmic bytes.  GPU only."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "open-hummingbird-eval_amd")]
+import torch
+from hbird_mi import ops
+from hbird_mi.nn.search_hip import HipFlatIndex
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+res = []
+for name, (B, S, ps, D, C, k) in {"cfg2": (64, 14, 16, 384, 21, 30), "cfg3": (16, 37, 14, 768, 151, 30)}.items():
+    N, H = S * S, S * ps
+    g = torch.Generator(device=dev).manual_seed(0)
+    feats = torch.randn((B * N, D), generator=g, device=dev)
+    y = torch.randint(0, C, (B, 1, H, H), generator=g, device=dev)
+    # K1: fused normalise + append (8*D bytes per row: read once + write once)
+    ix = HipFlatIndex(D, 0, 0); ix.reserve(B * N * 8); ix.use_current_stream()
+    def k1():
+        ix.reset() if ix.ntotal + B * N > B * N * 8 else None
+        ix.add(feats, normalize=True)
+    ms = timeit(k1); res.append((name, "K1 normalize+append", ms, 8 * D * B * N))
+    # K2
+    ms = timeit(lambda: ops.patch_label_hist(y, ps, C, map255=True)); res.append((name, "K2 patch_label_hist", ms, (8 * ps * ps + 4 * C) * B * N))
+    lab = ops.patch_label_hist(y, ps, C).view(B, N, C)
+    # K3
+    sc, ne, nz = ops.patch_scores(lab)
+    r = torch.rand(B * N, device=dev); roff = (torch.arange(B, device=dev) * N)
+    ms = timeit(lambda: ops.patch_scores(lab)); res.append((name, "K3a patch_scores", ms, 4 * C * B * N))
+    ms = timeit(lambda: ops.patch_select(sc, ne, r, roff, min(N, 100))); res.append((name, "K3b patch_select", ms, 8 * B * N))
+    # K5 on a 1M-row bank
+    M = 1_000_000
+    bank = HipFlatIndex(D, 0, 0); bank.reserve(M); bank.use_current_stream()
+    for r0 in range(0, M, 250_000):
+        bank.add(torch.randn((250_000, D), generator=g, device=dev), normalize=True)
+        bank.add_labels(torch.rand((250_000, C), generator=g, device=dev))
+    bank.set_num_classes(C)
+    q = 3 * torch.randn((B * N, D), generator=g, device=dev)
+    idx, dist = bank.search(q, k)
+    ms = timeit(lambda: bank.aggregate(q, idx, dist)); res.append((name, "K5 aggregate (+query norms)", ms, (4 * k * C + 12 * k + 4 * C + 4 * D) * B * N))
+    lh = bank.aggregate(q, idx, dist).view(B, N, C)
+    # K6
+    ms = timeit(lambda: ops.upsample_argmax(lh, S, H, H)); res.append((name, "K6 upsample_argmax", ms, 4 * C * N * B + 8 * H * H * B))
+    pred = ops.upsample_argmax(lh, S, H, H)
+    conf = torch.zeros((C, C), dtype=torch.int64, device=dev)
+    ms = timeit(lambda: ops.confusion_update(conf, y, pred, 255)); res.append((name, "K7 confusion", ms, 16 * H * H * B))
+    del bank, ix
+for name, op, ms, nbytes in res:
+    print(f"{name}  {op:30s} {ms:8.3f} ms  {nbytes / 1e6:9.1f} MB algorithmic  {nbytes / ms / 1e6:8.1f} GB/s")
