@@ -106,17 +106,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # HBIRD_BENCH_ONE_GPU=1 (testing only): all ranks share cuda:0 and talk over gloo, since RCCL refuses two
+    # ranks on one device; the normal path is one rank per GPU over RCCL.
+    one_gpu = os.environ.get("HBIRD_BENCH_ONE_GPU") == "1"
+    dev_index = 0 if one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=device)
+        if one_gpu:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=device)
     from hbird_mi import dist as hdist
     from hbird_mi.nn.search_hip import HipFlatIndex, merge_topk
 
     M, D, C, nq, k = a.rows, a.dim, a.classes, a.nq, a.k
     per = (M + world - 1) // world
     lo, hi = min(M, rank * per), min(M, (rank + 1) * per)
-    index = HipFlatIndex(D, 0, local_rank)
+    index = HipFlatIndex(D, 0, dev_index)
     index.set_num_classes(C)
     index.use_current_stream()
     if a.workgroups or a.panel:

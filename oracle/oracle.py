@@ -4,7 +4,7 @@ ctypes front-end of oracle/hbird_oracle.c plus numpy restatements of the small i
 stages of the reference's hot path.  Every function cites the reference lines it follows
 (paths relative to /root/reference).  The reference ships no tests or golden vectors for this
 path, so the oracle is pinned against fixtures produced by importing the
-reference's own Python in the build container: tools/gen_golden.py -> tests/golden/*.npz,
+reference's own Python in the build container: tests/golden/gen_golden.py -> tests/golden/*.npz,
 checked by tests/test_oracle_golden.py.  The third-party Faiss-GPU arithmetic (exact flat
 search) is restated from its definition; see hbird_oracle.c.
 """

@@ -10,7 +10,7 @@ class derives from the reference's own NearestNeighborSearchBase and answers wit
 definition of an exact flat search (the oracle's orc_knn_f64), so that the reference's
 HbirdEvaluation(nn_method="faiss") + evaluate() run unmodified end to end.
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
 """
 from __future__ import annotations
 
@@ -19,7 +19,7 @@ import sys
 import types
 
 sys.dont_write_bytecode = True
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = "/root/reference"
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

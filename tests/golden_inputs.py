@@ -1,4 +1,4 @@
-"""Deterministic synthetic inputs shared by tools/gen_golden.py (which feeds them to the
+"""Deterministic synthetic inputs shared by tests/golden/gen_golden.py (which feeds them to the
 reference's own Python) and by the tests (which feed the same inputs to the oracle / HIP path).
 
 Pure numpy; nothing here reads /root/reference.

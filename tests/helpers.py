@@ -4,7 +4,7 @@ import torch
 
 
 class ReplayExtractor(torch.nn.Module):
-    """Fake extractor returning pre-computed tokens in call order (same as tools/gen_golden.py)."""
+    """Fake extractor returning pre-computed tokens in call order (same as tests/golden/gen_golden.py)."""
 
     def __init__(self, tokens, eval_spatial_resolution, d_model):
         super().__init__()

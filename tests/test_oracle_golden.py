@@ -1,4 +1,4 @@
-"""Pins the CPU oracle against fixtures produced by the reference's own Python (tools/gen_golden.py).
+"""Pins the CPU oracle against fixtures produced by the reference's own Python (tests/golden/gen_golden.py).
 
 CPU only.  These tests are what makes the oracle trustworthy as the checker of the HIP path.
 """
