@@ -259,3 +259,20 @@ def test_four_wave_kernel_variant_bit_exact(cuda_device, M, D, nq, k):
     ix.set_tuning(5, 2)
     idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
     _check_exact(idx, dist, q, bank, k, "dot_product")
+
+
+def test_reference_named_backends(cuda_device):
+    """hbird_mi.nn.search_faiss / search_scann carry the reference's class names and keyword surfaces."""
+    from hbird_mi.nn.search_faiss import NearestNeighborSearchFaiss
+    from hbird_mi.nn.search_scann import NearestNeighborSearchScaNN
+    bank = gi.unit_bank(3000, 32, seed=1); q = gi.vit_like_queries(50, 32, seed=2)
+    fm = torch.from_numpy(bank)
+    nn = NearestNeighborSearchFaiss(fm, n_neighbors=10, distance_measure="l2", idx_shard=False, use_fp16=True, gpu_ids=[0])
+    idx, dist = nn.find_nearest_neighbors(torch.from_numpy(q))
+    _check_exact(idx, dist, q, bank, 10, "l2")
+    sc = NearestNeighborSearchScaNN(fm, n_neighbors=10, num_leaves=100, num_leaves_to_search=10)
+    idx, dist = sc.find_nearest_neighbors(torch.from_numpy(q), k=3)      # k is ignored, like the reference
+    assert idx.shape == (50, 10)
+    _check_exact(idx, dist, q, bank, 10, "dot_product")
+    with pytest.raises(ValueError):
+        NearestNeighborSearchScaNN(fm, distance_measure="l2")            # search_scann.py:19-20
