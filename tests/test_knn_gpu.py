@@ -276,3 +276,54 @@ def test_reference_named_backends(cuda_device):
     _check_exact(idx, dist, q, bank, 10, "dot_product")
     with pytest.raises(ValueError):
         NearestNeighborSearchScaNN(fm, distance_measure="l2")            # search_scann.py:19-20
+
+
+def test_headline_size_10m_x_768(cuda_device):
+    """BASELINE.json's headline shape (10 M x 768 bank, 21,904-query batch, k = 30): planted neighbours,
+    sortedness, determinism, sharding invariance and an independent float64 check of 16 queries against ALL rows."""
+    M, D, nq, k = 10_000_000, 768, 21_904, 30
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(3)
+    ix = HipFlatIndex(D, 0, 0)
+    ix.reserve(M)
+    half = M // 2
+    a, b = HipFlatIndex(D, 0, 0), HipFlatIndex(D, 0, 0)
+    a.reserve(half); b.reserve(M - half)
+    for r in range(0, M, 500_000):
+        rows = torch.randn((500_000, D), generator=g, device=dev)
+        rows = rows / rows.norm(dim=1, keepdim=True)
+        ix.add(rows)
+        (a if r < half else b).add(rows)
+    q = 3.0 * torch.randn((nq, D), generator=g, device=dev)
+    planted = torch.arange(128, device=dev) * 78_125 + 11
+    q[:128] = 2.5 * ix.reconstruct(planted)
+    idx, dist = ix.search(q, k)
+    assert (idx[:128, 0] == planted).all()
+    assert (dist[:, :-1] >= dist[:, 1:]).all() and (idx >= 0).all() and (idx < M).all()
+    srt = idx.sort(dim=1).values
+    assert (srt[:, 1:] != srt[:, :-1]).all()
+    idx2, dist2 = ix.search(q, k)
+    assert torch.equal(idx, idx2) and torch.equal(dist, dist2)
+    from hbird_mi.nn.search_hip import merge_topk
+    ia, da = a.search(q, k, id_base=0)
+    ib, db = b.search(q, k, id_base=half)
+    im, dm = merge_topk(torch.stack([da, db]), torch.stack([ia, ib]), 0)
+    assert torch.equal(im, idx) and torch.equal(dm, dist)
+    del a, b
+    # float64 scores of 16 queries against every bank row (chunked reconstruct), exact top-k by (score, id)
+    sel = torch.tensor([0, 5, 127, 128, 1000, 5000, 9999, 12345, 15000, 17000, 19000, 20000, 21000, 21500, 21900, 21903],
+                       device=dev)
+    qs = q[sel].double()
+    best_s = torch.full((16, k), -float("inf"), dtype=torch.float64, device=dev)
+    best_i = torch.full((16, k), -1, dtype=torch.int64, device=dev)
+    for r in range(0, M, 1_000_000):
+        ids = torch.arange(r, min(M, r + 1_000_000), device=dev)
+        sc = qs @ ix.reconstruct(ids).double().T                      # [16, chunk]
+        cs = torch.cat([best_s, sc], dim=1); ci = torch.cat([best_i, ids[None].expand(16, -1)], dim=1)
+        top = cs.topk(k, dim=1)
+        best_s, best_i = top.values, ci.gather(1, top.indices)
+    got = idx[sel].cpu().numpy(); ref = best_i.cpu().numpy()
+    rep = oracle.near_tie_report(got, ref, best_s.cpu().numpy())
+    assert rep["excused_rate"] == 1.0 and rep["set_rate"] >= 0.9, rep
+    # fp32 chain rounding: ~1e-7 * sum|q_k b_k| (a few 1e-5 at |q| ~ 83, D = 768)
+    assert np.abs(dist[sel].cpu().numpy() - best_s.cpu().numpy()).max() < 1e-4
