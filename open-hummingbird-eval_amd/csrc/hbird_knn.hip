@@ -21,60 +21,58 @@
 
 #include "hbird_knn_dev.h"
 
-#define HB_DUMP_CASE(T, H)                                                                     \
-    case (2 * (T) + (H)):                                                                      \
-        _Pragma("unroll") for (int r = 0; r < 8; ++r) sc[r * 64 + lane] = acc[T][8 * (H) + r]; \
+// dump the 4 registers of quarter Q (rows 8Q .. 8Q+7 of the 32-row tile) of accumulator tile T
+#define HB_DUMP_CASE(T, Q)                                                                  \
+    case (4 * (T) + (Q)):                                                                   \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) sc[r * 64 + lane] = acc[T][4 * (Q) + r]; \
         break;
+#define HB_DUMP_TILE(T) HB_DUMP_CASE(T, 0) HB_DUMP_CASE(T, 1) HB_DUMP_CASE(T, 2) HB_DUMP_CASE(T, 3)
 
 // Epilogue of one (query tile, bank tile) pair for one wave: filter the wave's 256 x 32 scores against the
-// per-query thresholds (phase 1, always) and insert the rare survivors into the LDS lists (phase 2).
+// per-query thresholds (phase 1, always) and insert the rare survivors into the lists (phase 2).
 template <bool SLOW = true, bool WIDE = false>
 __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, float* lst_s, unsigned* lst_i, float* sc,
                                               int w, int lane, int k, unsigned bt, int klw = HB_KL) {
-    unsigned hmask = 0;
+    unsigned qmask = 0;   // bit 4t+q: quarter q (8 bank rows) of row tile t holds a score above its query's threshold
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        bool any0 = false, any1 = false;
+    for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { any0 |= acc[t][r] > thr; any1 |= acc[t][8 + r] > thr; }
-        if (__ballot(any0) != 0ull) hmask |= 1u << (2 * t);
-        if (__ballot(any1) != 0ull) hmask |= 1u << (2 * t + 1);
-    }
-    if (!SLOW) { asm volatile("" :: "s"(hmask)); return; }
-    while (hmask) {   // wave-uniform slow path: some score beat its query's k-th best
-        const int th = __builtin_ctz(hmask);
-        hmask &= hmask - 1;
-        switch (th) {
-            HB_DUMP_CASE(0, 0) HB_DUMP_CASE(0, 1) HB_DUMP_CASE(1, 0) HB_DUMP_CASE(1, 1)
-            HB_DUMP_CASE(2, 0) HB_DUMP_CASE(2, 1) HB_DUMP_CASE(3, 0) HB_DUMP_CASE(3, 1)
-            HB_DUMP_CASE(4, 0) HB_DUMP_CASE(4, 1) HB_DUMP_CASE(5, 0) HB_DUMP_CASE(5, 1)
-            HB_DUMP_CASE(6, 0) HB_DUMP_CASE(6, 1) HB_DUMP_CASE(7, 0) HB_DUMP_CASE(7, 1)
+        for (int q = 0; q < 4; ++q) {
+            const bool any = (acc[t][4 * q] > thr) | (acc[t][4 * q + 1] > thr) | (acc[t][4 * q + 2] > thr) | (acc[t][4 * q + 3] > thr);
+            if (__ballot(any) != 0ull) qmask |= 1u << (4 * t + q);
         }
-        const unsigned row_base = bt * HB_BT + (th >> 1) * 32 + (th & 1) * 16;
-        // ascending bank-row order: (g, h, j) -> row = 8g + 4h + j within the half tile
-        for (int gg = 0; gg < 2; ++gg)
-            for (int hh = 0; hh < 2; ++hh)
-                for (int j = 0; j < 4; ++j) {
-                    const float v = sc[(gg * 4 + j) * 64 + lane];
-                    unsigned long long m = __ballot(v > thr);
-                    m &= hh ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
-                    while (m) {
-                        const int l = __builtin_ctzll(m);
-                        m &= m - 1;
-                        const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-                        const int n = l & 31;
-                        float kth;
-                        if constexpr (WIDE) {
-                            float* gs = lst_s + (size_t)(w * 32 + n) * klw;
-                            list_insert_wide(gs, lst_i + (size_t)(w * 32 + n) * klw, k, klw, s, row_base + gg * 8 + hh * 4 + j, lane);
-                            kth = __hip_atomic_load(gs + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        } else {
-                            list_insert(lst_s, lst_i, w * 32 + n, k, s, row_base + gg * 8 + hh * 4 + j, lane);
-                            kth = lst_s[(w * 32 + n) * HB_KL + (k - 1)];
-                        }
-                        if ((lane & 31) == n) thr = kth;
+    if (!SLOW) { asm volatile("" :: "s"(qmask)); return; }
+    while (qmask) {   // wave-uniform slow path; ascending bit order = ascending bank row
+        const int bit = __builtin_ctz(qmask);
+        qmask &= qmask - 1;
+        switch (bit) {
+            HB_DUMP_TILE(0) HB_DUMP_TILE(1) HB_DUMP_TILE(2) HB_DUMP_TILE(3)
+            HB_DUMP_TILE(4) HB_DUMP_TILE(5) HB_DUMP_TILE(6) HB_DUMP_TILE(7)
+        }
+        const unsigned row_base = bt * HB_BT + (bit >> 2) * 32 + (bit & 3) * 8;
+        // rows inside the quarter: lane half hh holds rows 4*hh + j in register j
+        for (int hh = 0; hh < 2; ++hh)
+            for (int j = 0; j < 4; ++j) {
+                const float v = sc[j * 64 + lane];
+                unsigned long long m = __ballot(v > thr);
+                m &= hh ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
+                while (m) {
+                    const int l = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+                    const int n = l & 31;
+                    float kth;
+                    if constexpr (WIDE) {
+                        float* gs = lst_s + (size_t)(w * 32 + n) * klw;
+                        list_insert_wide(gs, lst_i + (size_t)(w * 32 + n) * klw, k, klw, s, row_base + hh * 4 + j, lane);
+                        kth = __hip_atomic_load(gs + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        list_insert(lst_s, lst_i, w * 32 + n, k, s, row_base + hh * 4 + j, lane);
+                        kth = lst_s[(w * 32 + n) * HB_KL + (k - 1)];
                     }
+                    if ((lane & 31) == n) thr = kth;
                 }
+            }
     }
 }
 
@@ -96,7 +94,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
     const int h = lane >> 5;
     float* lst_s = reinterpret_cast<float*>(smem + KN_LISTS);
     unsigned* lst_i = reinterpret_cast<unsigned*>(smem + KN_LISTS + HB_QT * HB_KL * 4);
-    float* sc = reinterpret_cast<float*>(smem + KN_SCRATCH) + w * 512;
+    float* sc = reinterpret_cast<float*>(smem + KN_SCRATCH) + w * 256;
     const int g8 = a.g8, k = a.k;   // g8 = stages per bank tile
     const int myq = w * 32 + (lane & 31);
 
@@ -127,12 +125,23 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
         f32x4 fa[4], fy[4], fb, fbk;   // X-half / Y-half bank fragments, query fragment (current, kept for Y)
 
         // wave w stages bank row-tile w and query row-tile w of one k8 group (1 KiB each)
+        // Only waves 0-3 issue the LDS-DMA copies (4 per stage each: bank row-tiles w, w+4 and query row-tiles
+        // w, w+4).  Waves w and w+4 share a SIMD: when both stalled on a copy's issue at the same point of the
+        // stage the matrix pipe idled; with one issuer per SIMD the partner keeps it fed (+3.1 % measured).
         auto issue_a = [&](int bt, int ks, int slot) {
             if constexpr (ABL & 32) bt = bt & 7;   // timing only: 8 bank tiles, L2-resident
-            glds16(a.bank_tiles + ((size_t)(bt * 8 + w) * g8 + ks) * HB_BLK + lane * 4, smem + slot * KN_SLOT_BYTES + w * 1024);
+            const float* src = a.bank_tiles + ((size_t)(bt * 8 + w) * g8 + ks) * HB_BLK + lane * 4;
+            if (w < 4) {
+                glds16(src, smem + slot * KN_SLOT_BYTES + w * 1024);
+                glds16(src + (size_t)4 * g8 * HB_BLK, smem + slot * KN_SLOT_BYTES + (w + 4) * 1024);
+            }
         };
         auto issue_b = [&](int bt, int ks, int slot) {
-            glds16(((ABL & 64) ? a.q_tiles + (size_t)w * g8 * HB_BLK + lane * 4 : qsrc) + (size_t)ks * HB_BLK, smem + slot * KN_SLOT_BYTES + 8192 + w * 1024);
+            const float* src = ((ABL & 64) ? a.q_tiles + (size_t)w * g8 * HB_BLK + lane * 4 : qsrc) + (size_t)ks * HB_BLK;
+            if (w < 4) {
+                glds16(src, smem + slot * KN_SLOT_BYTES + 8192 + w * 1024);
+                glds16(src + (size_t)4 * g8 * HB_BLK, smem + slot * KN_SLOT_BYTES + 8192 + (w + 4) * 1024);
+            }
             if (ks == 0 && w == 0) glds16(a.binit + (size_t)bt * HB_BT + lane * 4, smem + KN_BINIT + (bt & 1) * 1024);
         };
 
@@ -147,13 +156,11 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
             if (--left > 0) { if (++fks == g8) { fks = 0; ++fbt; } }
             if (++slot_f == KN_RING) slot_f = 0;
         };
-        // vmcnt is counted by hand (the compiler does not wait for LDS-DMA at a barrier): every wave issues
-        // exactly two copies per stage (wave 0 a third, the row-init values, at the first stage of a tile), so
-        // "all but the newest 2" covers everything up to and including the stage about to be published.
-        issue_a(fbt, fks, slot_f); issue_b(fbt, fks, slot_f); advance_fetch();
-        issue_a(fbt, fks, slot_f); issue_b(fbt, fks, slot_f); advance_fetch();
-        issue_a(fbt, fks, slot_f); issue_b(fbt, fks, slot_f); advance_fetch();
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // vmcnt is counted by hand (the compiler does not wait for LDS-DMA at a barrier): an issuing wave has
+        // exactly four copies per stage in flight (wave 0 a fifth, the row-init values, at the first stage of a
+        // tile), so "all but the newest 4" covers everything up to and including the stage about to be published.
+        for (int p = 0; p < KN_RING - 1; ++p) { issue_a(fbt, fks, slot_f); issue_b(fbt, fks, slot_f); advance_fetch(); }
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stage 0 landed; stages 1-2 in flight
         __syncthreads();
         {
             const f32x4* A = reinterpret_cast<const f32x4*>(smem);
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
         }
         for (int st = 0; st < total; ++st) {
             if constexpr (!(ABL & 4)) {
-                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // my copies of stage st+1 have landed
+                if constexpr (!(ABL & 128)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // my copies of stage st+1 have landed (st+2 in flight)
                 __syncthreads();   // ... everyone's have; the slot of stage st-1 is free for stage st+3
             }
             int slot_n = slot_c + 1; if (slot_n == KN_RING) slot_n = 0;
@@ -466,10 +473,10 @@ int hb_launch_knn(hb_index* ix, int64_t nq, int k, int64_t id_base, int64_t* out
                                       knn_fused_kernel<7, false>, knn_fused_kernel<3, false>, knn_fused_kernel<5, false>,
                                       knn_fused_kernel<6, false>, knn_fused_kernel<9, false>, knn_fused_kernel<10, false>,
                                       knn_fused_kernel<12, false>, knn_fused_kernel<32, false>, knn_fused_kernel<64, false>,
-                                      knn_fused_kernel<96, false>
+                                      knn_fused_kernel<96, false>, knn_fused_kernel<128, false>
 #endif
     };
-    static const int variant_bits[] = {0, -1, 1, 2, 4, 8, 15, 16, 13, 14, 11, 7, 3, 5, 6, 9, 10, 12, 32, 64, 96};
+    static const int variant_bits[] = {0, -1, 1, 2, 4, 8, 15, 16, 13, 14, 11, 7, 3, 5, 6, 9, 10, 12, 32, 64, 96, 128};
     static bool attr_set = false;
     if (!attr_set) {
         for (knn_fn f : variants) HB_HIP(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, KN_LDS_TOTAL));

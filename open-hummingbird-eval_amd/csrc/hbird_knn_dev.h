@@ -77,7 +77,7 @@ __device__ __forceinline__ void list_insert_wide(float* gs, unsigned* gi, int k,
 #define KN_BINIT (KN_RING * KN_SLOT_BYTES)  // 2 x 1 KiB
 #define KN_LISTS (KN_BINIT + 2048)
 #define KN_SCRATCH (KN_LISTS + 2 * HB_QT * HB_KL * 4)
-#define KN_LDS_TOTAL (KN_SCRATCH + 8 * 8 * 64 * 4)
+#define KN_LDS_TOTAL (KN_SCRATCH + 8192)      // scratch: 1 KiB per wave (8 waves) / 2 KiB per wave (4 waves)
 #define KN_FENCE __builtin_amdgcn_sched_barrier(0);
 
 typedef void (*hb_knn_fn)(knn_args);

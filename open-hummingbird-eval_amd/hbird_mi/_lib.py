@@ -10,7 +10,7 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libhbird_hip.so")
+LIB_PATH = os.environ.get("HBIRD_HIP_LIB") or os.path.join(_PKG_ROOT, "lib", "libhbird_hip.so")   # override: A/B builds
 CSRC_DIR = os.path.join(_PKG_ROOT, "csrc")
 
 _lib = None
