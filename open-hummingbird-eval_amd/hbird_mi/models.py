@@ -14,21 +14,20 @@ import torch.nn as nn
 
 
 class FeatureExtractorSimple(nn.Module):
-    """Delegates to `ftr_extr_fn(model, imgs)` (hbird/models.py:70-103)."""
+    """User-supplied token extraction: `ftr_extr_fn(model, imgs)` returns `tokens [B,N,D]` or `(tokens, attn)`
+    (counterpart of hbird/models.py:70-103; this is what the CLI always uses, eval.py:324)."""
 
     def __init__(self, vit_model: nn.Module, ftr_extr_fn: Callable, eval_spatial_resolution: int = 14,
                  d_model: int = 768) -> None:
         super().__init__()
-        self.model = vit_model
-        self.eval_spatial_resolution = eval_spatial_resolution
-        self.d_model = d_model
-        self.ftr_extr_fn = ftr_extr_fn
+        self.model, self.ftr_extr_fn = vit_model, ftr_extr_fn
+        self.eval_spatial_resolution, self.d_model = eval_spatial_resolution, d_model
 
     def forward_features(self, imgs: torch.Tensor):
-        return self.ftr_extr_fn(self.model, imgs)
+        out = self.ftr_extr_fn(self.model, imgs)
+        return out if isinstance(out, (tuple, list)) else (out, None)
 
-    def forward(self, imgs: torch.Tensor):
-        return self.forward_features(imgs)
+    forward = forward_features
 
 
 class FeatureExtractor(nn.Module):
