@@ -110,3 +110,55 @@ def test_cli_synthetic_self_check(cuda_device, tmp_path, capsys):
               "--out", out, "--log-level", "WARNING"])
     res = json.load(open(out))
     assert 0.5 < res["miou"] <= 1.0 and res["nn_method"] == "hip"
+
+
+def test_end_to_end_vit_b14_shapes_vs_oracle(cuda_device):
+    """cfg-3 geometry end to end (518 px, patch 14 -> 37 x 37 = 1369 tokens, D = 768, C = 151, k = 30) with a small
+    random-init transformer as the extractor; the oracle replays the whole evaluation from the same tokens."""
+    from hbird_mi.data.synthetic import SyntheticSegDataModule
+    torch.manual_seed(0)
+    D, ps, H, C, k, B = 768, 14, 518, 151, 30, 4
+    S = H // ps
+
+    class TinyViT(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.embed = torch.nn.Conv2d(3, D, ps, ps)
+            self.pos = torch.nn.Parameter(0.02 * torch.randn(1, S * S, D))
+            layer = torch.nn.TransformerEncoderLayer(D, 12, 4 * D, batch_first=True, norm_first=True, dropout=0.0)
+            self.blocks = torch.nn.TransformerEncoder(layer, 2)
+            self.norm = torch.nn.LayerNorm(D)
+
+        def forward_features(self, x):
+            t = self.embed(x).flatten(2).transpose(1, 2) + self.pos
+            return {"x_norm_patchtokens": self.norm(self.blocks(t))}
+
+    dm = SyntheticSegDataModule(batch_size=B, input_size=H, num_classes=C, n_train=12, n_val=8, seed=3)
+    tokens = []
+
+    def fn(model, imgs):
+        with torch.no_grad():
+            t = model.forward_features(imgs)["x_norm_patchtokens"].float()
+        tokens.append(t.cpu().numpy())
+        return t, None
+
+    from hbird_mi.models import FeatureExtractorSimple
+    ext = FeatureExtractorSimple(TinyViT().eval(), fn, eval_spatial_resolution=S, d_model=D)
+    ev = HbirdEvaluation(ext, dm.train_dataloader(), num_classes=C, n_neighbours=k, device="cuda", nn_method="hip")
+    assert ev.index.ntotal == 12 * S * S
+    n_train_batches = len(tokens)
+    jac = ev.evaluate(dm.val_dataloader(), S, ignore_index=255)
+    fm, lm = ev.feature_memory.numpy(), ev.label_memory.numpy()
+    # bank rows = normalised tokens in loader order; labels = patch histograms (255 -> 0)
+    ref_rows = oracle.normalize_rows(np.concatenate(tokens[:n_train_batches]).reshape(-1, D))
+    assert np.abs(fm - ref_rows).max() <= 1.5e-7
+    ys = np.concatenate([np.rint(y.numpy() * 255).astype(np.int64) for _, y in dm.train_dataloader()])
+    ys[ys == 255] = 0
+    assert np.array_equal(lm, oracle.patch_label_hist(ys, ps, C).reshape(-1, C))
+    m = oracle.PredsMIoUOracle(C, C, 255)
+    for (x, y), tok in zip(dm.val_dataloader(), tokens[n_train_batches:]):
+        idx, _ = oracle.knn_chain_f32(tok.reshape(-1, D), fm, k)
+        kf, kl = oracle.gather_neighbours(idx, fm, lm, tok.shape[0], S * S)
+        lh = oracle.cross_attention(tok, kf, kl)
+        m.update(np.rint(y.numpy() * 255).astype(np.int64), oracle.upsample_argmax(lh, S, H, H))
+    assert abs(jac - m.compute()[0]) < 1e-4, (jac, m.compute()[0])
