@@ -97,3 +97,35 @@ def test_product_fails_loudly_without_gpu():
         NearestNeighborSearchHIP(torch.zeros(4, 8))
     with pytest.raises(RuntimeError):
         PredsmIoU(3, 3)
+
+
+def test_feature_extractor_backends_cpu():
+    """FeatureExtractor auto-detection (counterpart of hbird/models.py:164-235): DINO-style
+    get_intermediate_layers (CLS first), DINOv2-style forward_features dict, plain module output with CLS."""
+    from hbird_mi.models import FeatureExtractor, FeatureExtractorSimple
+    B, S, D = 2, 4, 8
+    tok = torch.arange(B * (S * S + 1) * D, dtype=torch.float32).view(B, S * S + 1, D)
+
+    class Dino(torch.nn.Module):
+        def get_intermediate_layers(self, x):
+            return [tok]
+
+    class DinoV2(torch.nn.Module):
+        def forward_features(self, x):
+            return {"x_norm_clstoken": tok[:, 0], "x_norm_patchtokens": tok[:, 1:]}
+
+    class Plain(torch.nn.Module):
+        def forward(self, x):
+            return tok
+
+    x = torch.zeros(B, 3, 8, 8)
+    for m in (Dino(), DinoV2(), Plain()):
+        fe = FeatureExtractor(m, eval_spatial_resolution=S, d_model=D)
+        out, attn = fe.forward_features(x)
+        assert attn is None and out.shape == (B, S * S, D) and torch.equal(out, tok[:, 1:])
+        assert fe.eval_spatial_resolution == S and fe.d_model == D
+    fs = FeatureExtractorSimple(Plain(), lambda model, imgs: model(imgs)[:, 1:], eval_spatial_resolution=S, d_model=D)
+    out, attn = fs.forward_features(x)
+    assert attn is None and torch.equal(out, tok[:, 1:])
+    fs2 = FeatureExtractorSimple(Plain(), lambda model, imgs: (model(imgs)[:, 1:], "a"), S, D)
+    assert fs2(x)[1] == "a"
