@@ -1,4 +1,4 @@
-"""Folder datasets for VOC / ADE20K / Cityscapes with paired (image, mask) transforms, PIL + numpy + torch only
+"""Folder datasets for VOC / ADE20K / Cityscapes / COCO (thing, stuff) with paired (image, mask) transforms, PIL + numpy + torch only
 (counterparts of hbird/data/{voc,ade20k,cityscapes}/*_data.py and hbird/utils/{transforms,
 image_transformations}.py; host-side I/O, "next" row f3 of SURVEY.md section 8).
 
@@ -9,6 +9,7 @@ Directory conventions follow the reference (DATASET.md):
                                                                                (ade20k_data.py:72-88)
   cityscapes  <root>/leftImg8bit/{train,val}/<city>/*_leftImg8bit.png,
               <root>/gtFine/{train,val}/<city>/*_gtFine_labelIds.png, labelId -> trainId (cityscapes_data.py:28-48)
+  coco-*      <root>/images/{train,val}2017/*.jpg, <root>/annotations/... pixel maps + category json (coco_data.py:95-146)
 Samples are `(x float [3,S,S] normalised, y float [1,S,S] = mask / 255)` exactly as the reference's
 CombTransforms + ToTensor deliver them (hence `y * 255` in the evaluator, hbird_eval.py:219, 309).
 """
@@ -149,8 +150,44 @@ class SegFolder(Dataset):
                         continue
                     out.append((os.path.join(img_root, city, f), os.path.join(gt_root, city, stem + "_gtFine_labelIds.png")))
             return out
-        raise NotImplementedError(f"folder dataset '{self.name}' is not implemented (COCO needs the reference's "
-                                  f"stuff/thing mapping files)")
+        if self.name in ("coco-thing", "coco-stuff"):
+            return self._collect_coco(fs)
+        raise NotImplementedError(f"folder dataset '{self.name}' is not implemented")
+
+    def _collect_coco(self, fs):
+        """COCO-Stuff 'stuff' (15 coarse classes) / panoptic 'thing' (12 super-categories) masks; the category ->
+        coarse-id table is derived from the annotation json exactly as coco_data.py:104-124 does, and applied as a
+        256-entry lookup table on the uint8 mask (before the nearest-neighbour resize, which commutes with it)."""
+        import json
+        thing = self.name == "coco-thing"
+        r, sp = self.root, self.split
+        seg_dir = os.path.join(r, f"annotations/{sp}2017/" if thing else f"annotations/stuff_annotations/stuff_{sp}2017_pixelmaps/")
+        js = os.path.join(r, "annotations/panoptic_annotations/panoptic_val2017.json" if thing
+                          else "annotations/stuff_annotations/stuff_val2017.json")
+        img_dir = os.path.join(r, "images", f"{sp}2017")
+        if not os.path.isdir(seg_dir) or not os.path.isdir(img_dir):
+            raise RuntimeError("Dataset not found or corrupted.")                        # coco_data.py:129-132
+        cats = json.load(open(js))["categories"]
+        lut = np.full(256, 255, dtype=np.uint8)
+        if thing:
+            sup = sorted({c["supercategory"] for c in cats if c["isthing"] == 1})
+            for c in cats:
+                if c["isthing"] == 1 and c["id"] <= 200:
+                    lut[c["id"]] = sup.index(c["supercategory"])
+            lut[0] = 255                                                                  # unlabelled -> stuff -> ignored (170-178)
+        else:
+            sup = sorted({c["supercategory"] for c in cats} - {"other"})
+            for c in cats:
+                if c["id"] < 256:
+                    lut[c["id"]] = 255 if c["supercategory"] == "other" else sup.index(c["supercategory"])
+            lut[0] = 255                                                                  # things -> id 183 'other' -> ignored (155-160)
+        self._lut = lut
+        if fs is None:
+            imgs = [os.path.join(img_dir, f) for f in sorted(os.listdir(img_dir))]
+            msks = [os.path.join(seg_dir, f) for f in sorted(os.listdir(seg_dir))]
+            return list(zip(imgs, msks))
+        fs = sorted(f.replace(".jpg", "").replace(".png", "") for f in fs)
+        return [(os.path.join(img_dir, f"{f}.jpg"), os.path.join(seg_dir, f"{f}.png")) for f in fs]
 
     def __len__(self):
         return len(self.pairs)
@@ -162,6 +199,8 @@ class SegFolder(Dataset):
         if self.name == "cityscapes":
             ids = np.asarray(mask, dtype=np.int32)
             mask = Image.fromarray(_CITY_KEY[np.clip(ids + 1, 0, len(_CITY_KEY) - 1)])   # cityscapes_data.py:50-58
+        elif self.name.startswith("coco"):
+            mask = Image.fromarray(self._lut[np.asarray(mask.convert("L"), dtype=np.uint8)])
         return self.transform(img, mask)
 
 

@@ -129,3 +129,35 @@ def test_feature_extractor_backends_cpu():
     assert attn is None and torch.equal(out, tok[:, 1:])
     fs2 = FeatureExtractorSimple(Plain(), lambda model, imgs: (model(imgs)[:, 1:], "a"), S, D)
     assert fs2(x)[1] == "a"
+
+
+def test_coco_stuff_and_cityscapes_folder(tmp_path):
+    """Category -> coarse-class tables (coco_data.py:104-124) and the Cityscapes labelId -> trainId map (28-48)."""
+    import json
+    from hbird_mi.data import get_dataset
+    rng = np.random.default_rng(1)
+    root = tmp_path / "coco"
+    for sp in ("train", "val"):
+        os.makedirs(root / "images" / f"{sp}2017"); os.makedirs(root / "annotations" / "stuff_annotations" / f"stuff_{sp}2017_pixelmaps")
+        for i in range(3):
+            Image.fromarray(rng.integers(0, 255, (40, 50, 3), dtype=np.uint8)).save(root / "images" / f"{sp}2017" / f"{i:04d}.jpg")
+            m = rng.choice(np.array([0, 92, 93, 100, 183], dtype=np.uint8), size=(40, 50))
+            Image.fromarray(m).save(root / "annotations" / "stuff_annotations" / f"stuff_{sp}2017_pixelmaps" / f"{i:04d}.png")
+    cats = [{"id": 92, "supercategory": "textile"}, {"id": 93, "supercategory": "building"},
+            {"id": 100, "supercategory": "textile"}, {"id": 183, "supercategory": "other"}]
+    json.dump({"categories": cats}, open(root / "annotations" / "stuff_annotations" / "stuff_val2017.json", "w"))
+    dm, ign = get_dataset("coco-stuff", str(root), 3, 0, 32)
+    assert ign == 255 and dm.get_num_classes() == 15
+    x, y = next(iter(dm.val_dataloader()))
+    vals = set((y * 255).long().unique().tolist())
+    assert vals <= {0, 1, 255} and {0, 1} <= vals          # building -> 0, textile -> 1, things/other -> 255
+    # cityscapes
+    croot = tmp_path / "city"
+    for sp in ("train", "val"):
+        os.makedirs(croot / "leftImg8bit" / sp / "ulm"); os.makedirs(croot / "gtFine" / sp / "ulm")
+        Image.fromarray(rng.integers(0, 255, (32, 64, 3), dtype=np.uint8)).save(croot / "leftImg8bit" / sp / "ulm" / "ulm_000_leftImg8bit.png")
+        m = rng.choice(np.array([0, 7, 8, 26, 33], dtype=np.uint8), size=(32, 64))
+        Image.fromarray(m).save(croot / "gtFine" / sp / "ulm" / "ulm_000_gtFine_labelIds.png")
+    dm, ign = get_dataset("cityscapes", str(croot), 1, 0, 32)
+    x, y = next(iter(dm.val_dataloader()))
+    assert set((y * 255).long().unique().tolist()) <= {0, 1, 13, 18, 255}    # 7->0 road, 8->1, 26->13 car, 33->18 bicycle
