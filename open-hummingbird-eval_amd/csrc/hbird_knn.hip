@@ -132,15 +132,25 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
             if constexpr (ABL & 32) bt = bt & 7;   // timing only: 8 bank tiles, L2-resident
             const float* src = a.bank_tiles + ((size_t)(bt * 8 + w) * g8 + ks) * HB_BLK + lane * 4;
             if (w < 4) {
-                glds16(src, smem + slot * KN_SLOT_BYTES + w * 1024);
-                glds16(src + (size_t)4 * g8 * HB_BLK, smem + slot * KN_SLOT_BYTES + (w + 4) * 1024);
+                if constexpr (ABL & 256) {   // timing only: same global traffic into registers, no LDS writes
+                    f32x4 d0 = *reinterpret_cast<const f32x4*>(src), d1 = *reinterpret_cast<const f32x4*>(src + (size_t)4 * g8 * HB_BLK);
+                    asm volatile("" :: "v"(d0), "v"(d1));
+                } else {
+                    glds16(src, smem + slot * KN_SLOT_BYTES + w * 1024);
+                    glds16(src + (size_t)4 * g8 * HB_BLK, smem + slot * KN_SLOT_BYTES + (w + 4) * 1024);
+                }
             }
         };
         auto issue_b = [&](int bt, int ks, int slot) {
             const float* src = ((ABL & 64) ? a.q_tiles + (size_t)w * g8 * HB_BLK + lane * 4 : qsrc) + (size_t)ks * HB_BLK;
             if (w < 4) {
-                glds16(src, smem + slot * KN_SLOT_BYTES + 8192 + w * 1024);
-                glds16(src + (size_t)4 * g8 * HB_BLK, smem + slot * KN_SLOT_BYTES + 8192 + (w + 4) * 1024);
+                if constexpr (ABL & 256) {
+                    f32x4 d0 = *reinterpret_cast<const f32x4*>(src), d1 = *reinterpret_cast<const f32x4*>(src + (size_t)4 * g8 * HB_BLK);
+                    asm volatile("" :: "v"(d0), "v"(d1));
+                } else {
+                    glds16(src, smem + slot * KN_SLOT_BYTES + 8192 + w * 1024);
+                    glds16(src + (size_t)4 * g8 * HB_BLK, smem + slot * KN_SLOT_BYTES + 8192 + (w + 4) * 1024);
+                }
             }
             if (ks == 0 && w == 0) glds16(a.binit + (size_t)bt * HB_BT + lane * 4, smem + KN_BINIT + (bt & 1) * 1024);
         };
@@ -473,10 +483,10 @@ int hb_launch_knn(hb_index* ix, int64_t nq, int k, int64_t id_base, int64_t* out
                                       knn_fused_kernel<7, false>, knn_fused_kernel<3, false>, knn_fused_kernel<5, false>,
                                       knn_fused_kernel<6, false>, knn_fused_kernel<9, false>, knn_fused_kernel<10, false>,
                                       knn_fused_kernel<12, false>, knn_fused_kernel<32, false>, knn_fused_kernel<64, false>,
-                                      knn_fused_kernel<96, false>, knn_fused_kernel<128, false>
+                                      knn_fused_kernel<96, false>, knn_fused_kernel<128, false>, knn_fused_kernel<256, false>, knn_fused_kernel<384, false>
 #endif
     };
-    static const int variant_bits[] = {0, -1, 1, 2, 4, 8, 15, 16, 13, 14, 11, 7, 3, 5, 6, 9, 10, 12, 32, 64, 96, 128};
+    static const int variant_bits[] = {0, -1, 1, 2, 4, 8, 15, 16, 13, 14, 11, 7, 3, 5, 6, 9, 10, 12, 32, 64, 96, 128, 256, 384};
     static bool attr_set = false;
     if (!attr_set) {
         for (knn_fn f : variants) HB_HIP(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, KN_LDS_TOTAL));

@@ -1,5 +1,5 @@
 import sys, os, json, subprocess
-for bits in (0, 128, 4, 0):
+for bits in (0, 1, 256, 384, 0):
     out = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--workgroups", str(-bits)], capture_output=True, text=True)
     try:
         r = json.loads(out.stdout.strip().splitlines()[-1])
