@@ -123,6 +123,12 @@ int hb_index_set_variant(hb_index_t* ix, int variant);
  * [4]=max slots per query tile, [5]=query tiles, [6]=bank tiles. */
 int hb_index_schedule_info(const hb_index_t* ix, int64_t out[8]);
 
+/* Host-only (no GPU needed): the work list the kNN kernel would run for nqt query tiles (256 rows) x nbt bank tiles
+ * (256 rows) on `workgroups` workgroups; panel_tiles = 0 selects the automatic panel.  segs_out (may be NULL) receives
+ * up to max_segs rows {block, q_tile, b_tile0, n_tiles, slot, first}; stats as hb_index_schedule_info. */
+int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, int* segs_out, int64_t max_segs,
+                     int64_t stats[8]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,30 @@ extern "C" int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_til
     if (workgroups < 0) { ix->ablate = -workgroups; workgroups = 0; } else ix->ablate = 0;
     ix->force_G = workgroups; ix->force_panel = panel_tiles; ix->sched = hb_schedule(); return 0;
 }
+// Host-only: build the kNN work list for a (query tiles x bank tiles) grid without touching a GPU, for inspection
+// and tests.  segs_out receives up to max_segs rows of {block, q_tile, b_tile0, n_tiles, slot, first}.
+extern "C" int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, int* segs_out, int64_t max_segs,
+                                int64_t stats[8]) {
+    if (nqt <= 0 || nbt <= 0 || workgroups <= 0 || d <= 0) return hb_fail("hb_schedule_plan: bad arguments");
+    const int dp = (d + HB_KC - 1) / HB_KC * HB_KC;
+    const int G = (int)std::min<long long>(workgroups, (long long)nqt * nbt);
+    const int panel = panel_tiles > 0 ? panel_tiles : hb_default_panel(nqt, G, (size_t)HB_BT * dp * 4);
+    hb_schedule sc;
+    hb_build_schedule(nqt, nbt, workgroups, panel, sc);
+    stats[0] = sc.G; stats[1] = (int64_t)sc.segs.size(); stats[2] = sc.n_slots; stats[3] = sc.panel;
+    stats[4] = sc.max_slots_per_qt; stats[5] = sc.nqt; stats[6] = sc.nbt; stats[7] = 0;
+    if (segs_out) {
+        int64_t n = 0;
+        for (int b = 0; b < sc.G; ++b)
+            for (int i = sc.wg_off[b]; i < sc.wg_off[b + 1] && n < max_segs; ++i, ++n) {
+                const hb_seg& g = sc.segs[i];
+                int* o = segs_out + n * 6;
+                o[0] = b; o[1] = g.q_tile; o[2] = g.b_tile0; o[3] = g.n_tiles; o[4] = g.slot; o[5] = g.first;
+            }
+    }
+    return 0;
+}
+
 extern "C" int hb_index_set_variant(hb_index_t* ix, int variant) {
     if (variant < 0 || variant > 1) return hb_fail("hb_index_set_variant: unknown kernel variant");
     ix->variant = variant;
