@@ -116,6 +116,14 @@ int hb_index_set_timing(hb_index_t* ix, int enable);
 int hb_index_last_knn_ms(const hb_index_t* ix, double* ms);
 /* Overrides for tests: number of workgroups (0 = one per CU) and bank tiles per panel (0 = auto). */
 int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_tiles);
+/* GpuIndexFlatConfig.useFloat16 (search_faiss.py:40): 1 = searches run an fp16 candidate pass (fp16 copies of the
+ * fragment tiles, fp16 MFMA, k' >= 2k candidates) followed by an exact fp32 re-rank of the candidates, so the
+ * returned indices / distances are those of the fp32 search.  Every query carries a certificate (exact k-th score >
+ * k'-th fp16 score + rounding bound); queries that fail it are searched again with the fp32 kernel, so the result is
+ * ALWAYS the fp32 result.  Applies to k <= 128; larger k use the fp32 kernel. */
+int hb_index_set_fp16(hb_index_t* ix, int enable);
+/* Number of queries of the last fp16-mode search that needed the exact fp32 re-search. */
+int hb_index_last_fp16_fallbacks(const hb_index_t* ix, int64_t* n);
 /* kNN kernel variant: 0 = 8 waves per workgroup (two per SIMD, default), 1 = 4 waves (one per SIMD, 256
  * accumulator registers per lane).  Same results; for tuning. */
 int hb_index_set_variant(hb_index_t* ix, int variant);

@@ -30,10 +30,12 @@ extern "C" int hb_index_create(int d, int metric, int device, hb_index_t** out) 
         return hb_fail("hb_index_create: invalid GPU id " + std::to_string(device) + ", available 0-" + std::to_string(ndev - 1));
     HB_HIP(hipSetDevice(device));
     hb_index* ix = new hb_index();
-    ix->d = d; ix->dp = (d + HB_KC - 1) / HB_KC * HB_KC; ix->g8 = ix->dp / 8; ix->metric = metric; ix->device = device;
+    ix->d = d; ix->dp = (d + HB_KC - 1) / HB_KC * HB_KC; ix->g8 = ix->dp / 8; ix->dp16 = (d + 63) / 64 * 64; ix->metric = metric; ix->device = device;
     hipDeviceProp_t prop;
     HB_HIP(hipGetDeviceProperties(&prop, device));
     ix->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HB_HIP(hipMalloc((void**)&ix->bmax, 4));
+    HB_HIP(hipMemset(ix->bmax, 0, 4));
     HB_HIP(hipEventCreate(&ix->ev0));
     HB_HIP(hipEventCreate(&ix->ev1));
     *out = ix;
@@ -44,7 +46,8 @@ extern "C" int hb_index_free(hb_index_t* ix) {
     if (!ix) return 0;
     (void)hipSetDevice(ix->device);
     (void)hipStreamSynchronize(ix->stream);
-    void* ptrs[] = {ix->tiles, ix->binit, ix->bnorm, ix->labels, ix->q_tiles, ix->q_aux, ix->state, ix->sched_dev, ix->tmp};
+    void* ptrs[] = {ix->tiles, ix->binit, ix->bnorm, ix->labels, ix->q_tiles, ix->q_aux, ix->state, ix->sched_dev, ix->tmp,
+                    ix->tiles16, ix->q16, ix->cand, ix->bmax, ix->fb};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ix->ev0) (void)hipEventDestroy(ix->ev0);
     if (ix->ev1) (void)hipEventDestroy(ix->ev1);
@@ -64,6 +67,13 @@ extern "C" int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_til
 }
 // Host-only: build the kNN work list for a (query tiles x bank tiles) grid without touching a GPU, for inspection
 // and tests.  segs_out receives up to max_segs rows of {block, q_tile, b_tile0, n_tiles, slot, first}.
+extern "C" int hb_index_set_fp16(hb_index_t* ix, int enable) {
+    ix->fp16 = enable ? 1 : 0;
+    return 0;
+}
+
+extern "C" int hb_index_last_fp16_fallbacks(const hb_index_t* ix, int64_t* n) { *n = ix->last_fp16_fallbacks; return 0; }
+
 extern "C" int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, int* segs_out, int64_t max_segs,
                                 int64_t stats[8]) {
     if (nqt <= 0 || nbt <= 0 || workgroups <= 0 || d <= 0) return hb_fail("hb_schedule_plan: bad arguments");
@@ -143,7 +153,8 @@ extern "C" int hb_index_reset(hb_index_t* ix) {
         HB_HIP(hipMemsetAsync(ix->bnorm, 0, (size_t)ix->cap_rows * 4, s));
         HB_HIP(hipStreamSynchronize(s));
     }
-    ix->ntotal = 0; ix->nlabels = 0;
+    HB_HIP(hipMemsetAsync(ix->bmax, 0, 4, s));
+    ix->ntotal = 0; ix->nlabels = 0; ix->f16_rows = 0;
     return 0;
 }
 
@@ -178,6 +189,7 @@ extern "C" int hb_index_add(hb_index_t* ix, const float* x, int64_t n, int x_on_
         if (hb_launch_rows_to_tiles(src, n, ix->d, ix->dp, ix->ntotal, ix->tiles, ix->binit, ix->bnorm, ix->metric,
                                     normalize, 1, ix->stream)) return -1;
     }
+    if (hb_launch_bnorm_max(ix->bnorm + ix->ntotal, n, ix->bmax, ix->stream)) return -1;
     ix->ntotal += n;
     return 0;
 }
@@ -238,7 +250,7 @@ static int search_impl(hb_index* ix, const float* q, int64_t nq, int k, int64_t 
     if (b_lab) { d_lab = (float*)cur; cur += b_lab; }
     if (hb_launch_rows_to_tiles(qd, nq, ix->d, ix->dp, 0, ix->q_tiles, nullptr, nullptr, ix->metric, 0, 0, ix->stream)) return -1;
     if (hb_launch_query_aux(qd, nq, ix->d, ix->q_aux, ix->q_aux + nq, ix->stream)) return -1;
-    if (hb_launch_knn(ix, nq, k, id_base, d_idx, d_dist)) return -1;
+    if (hb_launch_knn(ix, qd, nq, k, id_base, d_idx, d_dist)) return -1;
     if (aggregate) {
         if (hb_launch_aggregate(ix, ix->q_aux + nq, d_idx, d_dist, nq, k, id_base, beta, d_lab, ix->stream)) return -1;
     }

@@ -64,6 +64,14 @@ struct hb_index {
     char* tmp = nullptr; size_t tmp_bytes = 0;           // staging for host<->device convenience paths
     hb_schedule sched;                                   // cached for (nqt, nbt)
     int force_G = 0, force_panel = 0;                    // test/tuning overrides
+    // fp16 candidate mode (use_fp16): fp16 copies of the bank / query fragment tiles, candidate buffers
+    int fp16 = 0, dp16 = 0;
+    void* tiles16 = nullptr; int64_t f16_cap_rows = 0, f16_rows = 0;
+    void* q16 = nullptr; size_t q16_bytes = 0;
+    char* cand = nullptr; size_t cand_bytes = 0;
+    float* bmax = nullptr;                               // device scalar: max bank-row norm
+    char* fb = nullptr; size_t fb_bytes = 0;             // fallback workspace (uncertified queries)
+    int64_t last_fp16_fallbacks = 0;
     int variant = 0;                                     // 0: 8-wave kernel, 1: 4-wave (one wave per SIMD) kernel
     int ablate = 0;                                      // timing-only kernel ablation (HB_ABLATION builds)
     double last_knn_ms = 0.0;                            // HIP-event time of the last knn kernel launch
@@ -86,7 +94,16 @@ int hb_launch_rows_to_tiles(const float* src, int64_t n_rows, int d, int dp, int
 int hb_launch_query_aux(const float* q, int64_t nq, int d, float* qn2, float* qnorm, hipStream_t s);
 int hb_launch_tiles_to_rows(const float* tiles, int g8, int d, const int64_t* ids, int64_t n, int64_t id_base,
                             float* out, hipStream_t s);
-int hb_launch_knn(hb_index* ix, int64_t nq, int k, int64_t id_base, int64_t* out_idx, float* out_dist);
+int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t id_base, int64_t* out_idx, float* out_dist);
+int hb_launch_tiles_to_f16(const float* t32, int g8, _Float16* t16, int g16, int64_t n_row_tiles, int64_t rt0, hipStream_t s);
+int hb_launch_rerank(const float* tiles, const float* binit, int g8, int d, const float* q, const float* qn2,
+                     const int64_t* cand, const float* cand_score, const float* qnorm, const float* bmax,
+                     unsigned char* certified, int kc, int64_t nq, int k, int64_t id_base, int metric, int64_t* out_idx,
+                     float* out_dist, hipStream_t s);
+int hb_launch_bnorm_max(const float* bnorm, int64_t n, float* bmax, hipStream_t s);
+int hb_launch_scatter_rows(const int64_t* rows, int64_t n, int k, const int64_t* src_idx, const float* src_dist,
+                           int64_t* out_idx, float* out_dist, hipStream_t s);
+void hb_knn_f16_launch(const void* args, int grid, hipStream_t s);
 int hb_launch_aggregate(const hb_index* ix, const float* qnorm, const int64_t* idx, const float* dist, int64_t nq,
                         int k, int64_t id_base, float beta, float* out, hipStream_t s);
 int hb_launch_merge_parts(const float* dist_parts, const int64_t* idx_parts, int parts, int64_t nq, int k, int metric,

@@ -21,61 +21,6 @@
 
 #include "hbird_knn_dev.h"
 
-// dump the 4 registers of quarter Q (rows 8Q .. 8Q+7 of the 32-row tile) of accumulator tile T
-#define HB_DUMP_CASE(T, Q)                                                                  \
-    case (4 * (T) + (Q)):                                                                   \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r) sc[r * 64 + lane] = acc[T][4 * (Q) + r]; \
-        break;
-#define HB_DUMP_TILE(T) HB_DUMP_CASE(T, 0) HB_DUMP_CASE(T, 1) HB_DUMP_CASE(T, 2) HB_DUMP_CASE(T, 3)
-
-// Epilogue of one (query tile, bank tile) pair for one wave: filter the wave's 256 x 32 scores against the
-// per-query thresholds (phase 1, always) and insert the rare survivors into the lists (phase 2).
-template <bool SLOW = true, bool WIDE = false>
-__device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, float* lst_s, unsigned* lst_i, float* sc,
-                                              int w, int lane, int k, unsigned bt, int klw = HB_KL) {
-    unsigned qmask = 0;   // bit 4t+q: quarter q (8 bank rows) of row tile t holds a score above its query's threshold
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bool any = (acc[t][4 * q] > thr) | (acc[t][4 * q + 1] > thr) | (acc[t][4 * q + 2] > thr) | (acc[t][4 * q + 3] > thr);
-            if (__ballot(any) != 0ull) qmask |= 1u << (4 * t + q);
-        }
-    if (!SLOW) { asm volatile("" :: "s"(qmask)); return; }
-    while (qmask) {   // wave-uniform slow path; ascending bit order = ascending bank row
-        const int bit = __builtin_ctz(qmask);
-        qmask &= qmask - 1;
-        switch (bit) {
-            HB_DUMP_TILE(0) HB_DUMP_TILE(1) HB_DUMP_TILE(2) HB_DUMP_TILE(3)
-            HB_DUMP_TILE(4) HB_DUMP_TILE(5) HB_DUMP_TILE(6) HB_DUMP_TILE(7)
-        }
-        const unsigned row_base = bt * HB_BT + (bit >> 2) * 32 + (bit & 3) * 8;
-        // rows inside the quarter: lane half hh holds rows 4*hh + j in register j
-        for (int hh = 0; hh < 2; ++hh)
-            for (int j = 0; j < 4; ++j) {
-                const float v = sc[j * 64 + lane];
-                unsigned long long m = __ballot(v > thr);
-                m &= hh ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
-                while (m) {
-                    const int l = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-                    const int n = l & 31;
-                    float kth;
-                    if constexpr (WIDE) {
-                        float* gs = lst_s + (size_t)(w * 32 + n) * klw;
-                        list_insert_wide(gs, lst_i + (size_t)(w * 32 + n) * klw, k, klw, s, row_base + hh * 4 + j, lane);
-                        kth = __hip_atomic_load(gs + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else {
-                        list_insert(lst_s, lst_i, w * 32 + n, k, s, row_base + hh * 4 + j, lane);
-                        kth = lst_s[(w * 32 + n) * HB_KL + (k - 1)];
-                    }
-                    if ((lane & 31) == n) thr = kth;
-                }
-            }
-    }
-}
-
 // One stage = one k8 fragment group of the pair tile: 32 MFMAs per wave, in two halves of 16 (bank row tiles
 // 0-3 = "X", 4-7 = "Y").  Fragments of the next half are fetched from LDS while the current half is in the
 // matrix pipe; HBM->LDS copies run three stages ahead (4-slot ring, hand-counted vmcnt).  Every non-MFMA
@@ -427,10 +372,18 @@ static int ensure_bytes(char** p, size_t* have, size_t need) {
 }
 
 // q_tiles / q_aux must already be prepared by the caller (hb_index_search).
-int hb_launch_knn(hb_index* ix, int64_t nq, int k, int64_t id_base, int64_t* out_idx, float* out_dist) {
+struct knn16_args_host {   // must match knn16_args in hbird_knn_f16.hip
+    const void* bank16; const float* binit; const void* q16; const hb_seg* segs; const int* wg_off;
+    float* state_s; unsigned* state_i; int g16, k, klw;
+};
+
+int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t id_base, int64_t* out_idx, float* out_dist) {
     if (k < 1 || k > 256) return hb_fail("hb_index_search: k must be in [1, 256]");
-    const bool wide = k > HB_KL;
-    const int klw = wide ? (k + 63) / 64 * 64 : HB_KL;
+    const bool f16 = ix->fp16 != 0 && k <= 128;
+    // fp16 mode: the fused kernel collects kc >= 2k candidates, the fp32 chain arithmetic re-ranks them
+    const int kc = f16 ? std::min(256, std::max(64, (2 * k + 63) / 64 * 64)) : k;
+    const bool wide = f16 || k > HB_KL;
+    const int klw = wide ? (kc + 63) / 64 * 64 : HB_KL;
     if (nq == 0) return 0;
     const int nqt = (int)((nq + HB_QT - 1) / HB_QT);
     const int nbt = (int)((ix->ntotal + HB_BT - 1) / HB_BT);
@@ -474,6 +427,90 @@ int hb_launch_knn(hb_index* ix, int64_t nq, int k, int64_t id_base, int64_t* out
     a.state_s = reinterpret_cast<float*>(ix->state);
     a.state_i = reinterpret_cast<unsigned*>(ix->state + state_half);
     a.g8 = ix->g8; a.k = k; a.klw = klw;
+    const size_t msh = (size_t)sc.max_slots_per_qt * kc * 8;
+    if (msh > 64000) return hb_fail("hb_index_search: too many partial lists per query tile for the merge kernel");
+    if (f16) {
+        // bring the fp16 copies of the bank / query fragment tiles up to date
+        const int64_t need_rt = (ix->ntotal + 31) / 32;
+        if (ix->f16_cap_rows != ix->cap_rows) {
+            if (ix->tiles16) HB_HIP(hipFree(ix->tiles16));
+            ix->tiles16 = nullptr; ix->f16_rows = 0;
+            HB_HIP(hipMalloc(&ix->tiles16, (size_t)ix->cap_rows * ix->dp16 * 2));
+            HB_HIP(hipMemsetAsync(ix->tiles16, 0, (size_t)ix->cap_rows * ix->dp16 * 2, s));
+            ix->f16_cap_rows = ix->cap_rows;
+        }
+        if (ix->f16_rows < ix->ntotal) {
+            const int64_t rt0 = ix->f16_rows / 32;
+            if (hb_launch_tiles_to_f16(ix->tiles, ix->g8, (_Float16*)ix->tiles16, ix->dp16 / 16, need_rt - rt0, rt0, s)) return -1;
+            ix->f16_rows = ix->ntotal;
+        }
+        const int64_t nqp = (int64_t)nqt * HB_QT;
+        if (ensure_bytes((char**)&ix->q16, &ix->q16_bytes, (size_t)nqp * ix->dp16 * 2)) return -1;
+        if (hb_launch_tiles_to_f16(ix->q_tiles, ix->g8, (_Float16*)ix->q16, ix->dp16 / 16, nqp / 32, 0, s)) return -1;
+        if (ensure_bytes(&ix->cand, &ix->cand_bytes, (size_t)nq * kc * 12)) return -1;
+        int64_t* cand_idx = reinterpret_cast<int64_t*>(ix->cand);
+        float* cand_dist = reinterpret_cast<float*>(ix->cand + (size_t)nq * kc * 8);
+        knn16_args_host h;
+        h.bank16 = ix->tiles16; h.binit = ix->binit; h.q16 = ix->q16; h.segs = a.segs; h.wg_off = a.wg_off;
+        h.state_s = a.state_s; h.state_i = a.state_i; h.g16 = ix->dp16 / 16; h.k = kc; h.klw = klw;
+        if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev0, s));
+        hb_knn_f16_launch(&h, sc.G, s);
+        HB_HIP(hipGetLastError());
+        if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
+        knn_merge_kernel<<<dim3((unsigned)nq), dim3(64), msh, s>>>(a.state_s, a.state_i,
+                                                                   reinterpret_cast<const int*>(ix->sched_dev + o_qo),
+                                                                   reinterpret_cast<const int*>(ix->sched_dev + o_qs), nq, kc, klw,
+                                                                   0, 0, nullptr, cand_idx, cand_dist);
+        HB_HIP(hipGetLastError());
+        if (ensure_bytes(&ix->fb, &ix->fb_bytes, (size_t)nq + 64)) return -1;
+        unsigned char* cert = reinterpret_cast<unsigned char*>(ix->fb);
+        if (hb_launch_rerank(ix->tiles, ix->binit, ix->g8, ix->d, q_dev, ix->q_aux, cand_idx, cand_dist, ix->q_aux + nq, ix->bmax,
+                             cert, kc, nq, k, id_base, ix->metric, out_idx, out_dist, s)) return -1;
+        if (ix->time_kernels) {
+            HB_HIP(hipEventSynchronize(ix->ev1));
+            float ms = 0.f;
+            HB_HIP(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
+            ix->last_knn_ms = ms;
+        }
+        // queries whose certificate failed are searched again with the exact fp32 kernel
+        std::vector<unsigned char> hc((size_t)nq);
+        HB_HIP(hipMemcpyAsync(hc.data(), cert, (size_t)nq, hipMemcpyDeviceToHost, s));
+        HB_HIP(hipStreamSynchronize(s));
+        std::vector<int64_t> bad;
+        for (int64_t i = 0; i < nq; ++i) if (!hc[i]) bad.push_back(i);
+        ix->last_fp16_fallbacks = (int64_t)bad.size();
+        if (!bad.empty()) {
+            const int64_t nf = (int64_t)bad.size();
+            auto al2 = [](size_t x) { return (x + 255) / 256 * 256; };
+            const size_t o_rows = al2((size_t)nq + 64), o_q = o_rows + al2((size_t)nf * 8), o_aux = o_q + al2((size_t)nf * ix->d * 4),
+                         o_idx = o_aux + al2((size_t)nf * 8), o_dist = o_idx + al2((size_t)nf * k * 8), tot2 = o_dist + al2((size_t)nf * k * 4);
+            if (ix->fb_bytes < tot2) {
+                char* nb = nullptr;
+                HB_HIP(hipMalloc((void**)&nb, tot2));
+                HB_HIP(hipFree(ix->fb));
+                ix->fb = nb; ix->fb_bytes = tot2;
+            }
+            int64_t* d_rows = reinterpret_cast<int64_t*>(ix->fb + o_rows);
+            float* d_q = reinterpret_cast<float*>(ix->fb + o_q);
+            float* d_aux = reinterpret_cast<float*>(ix->fb + o_aux);
+            int64_t* d_fi = reinterpret_cast<int64_t*>(ix->fb + o_idx);
+            float* d_fd = reinterpret_cast<float*>(ix->fb + o_dist);
+            HB_HIP(hipMemcpyAsync(d_rows, bad.data(), (size_t)nf * 8, hipMemcpyHostToDevice, s));
+            if (hb_launch_gather_rows(q_dev, nq, ix->d, d_rows, nf, d_q, s)) return -1;
+            if (hb_launch_rows_to_tiles(d_q, nf, ix->d, ix->dp, 0, ix->q_tiles, nullptr, nullptr, ix->metric, 0, 0, s)) return -1;
+            float* saved_aux = ix->q_aux;
+            ix->q_aux = d_aux;                       // chain ||q||^2 of the re-searched queries (L2 distances)
+            int rc = hb_launch_query_aux(d_q, nf, ix->d, d_aux, d_aux + nf, s);
+            const int saved = ix->fp16, saved_t = ix->time_kernels;
+            ix->fp16 = 0; ix->time_kernels = 0;
+            if (!rc) rc = hb_launch_knn(ix, d_q, nf, k, id_base, d_fi, d_fd);
+            ix->fp16 = saved; ix->time_kernels = saved_t; ix->q_aux = saved_aux;
+            if (rc) return -1;
+            if (hb_launch_scatter_rows(d_rows, nf, k, d_fi, d_fd, out_idx, out_dist, s)) return -1;
+            HB_HIP(hipStreamSynchronize(s));         // `bad` and the workspace are reused by the next call
+        }
+        return 0;
+    }
     typedef void (*knn_fn)(knn_args);
     static const knn_fn variants[] = {knn_fused_kernel<0, false>, knn_fused_kernel<0, true>,
 #ifdef HB_ABLATION
@@ -509,8 +546,6 @@ int hb_launch_knn(hb_index* ix, int64_t nq, int k, int64_t id_base, int64_t* out
     fn<<<dim3((unsigned)sc.G), dim3(threads), KN_LDS_TOTAL, s>>>(a);
     HB_HIP(hipGetLastError());
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
-    const size_t msh = (size_t)sc.max_slots_per_qt * k * 8;
-    if (msh > 64000) return hb_fail("hb_index_search: too many partial lists per query tile for the merge kernel");
     const float* qn2 = ix->q_aux;   // [nq] chain ||q||^2 (valid for L2)
     knn_merge_kernel<<<dim3((unsigned)nq), dim3(64), msh, s>>>(a.state_s, a.state_i,
                                                                reinterpret_cast<const int*>(ix->sched_dev + o_qo),

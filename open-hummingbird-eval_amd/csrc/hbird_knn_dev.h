@@ -71,6 +71,61 @@ __device__ __forceinline__ void list_insert_wide(float* gs, unsigned* gi, int k,
 }
 
 
+// dump the 4 registers of quarter Q (rows 8Q .. 8Q+7 of the 32-row tile) of accumulator tile T
+#define HB_DUMP_CASE(T, Q)                                                                  \
+    case (4 * (T) + (Q)):                                                                   \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) sc[r * 64 + lane] = acc[T][4 * (Q) + r]; \
+        break;
+#define HB_DUMP_TILE(T) HB_DUMP_CASE(T, 0) HB_DUMP_CASE(T, 1) HB_DUMP_CASE(T, 2) HB_DUMP_CASE(T, 3)
+
+// Epilogue of one (query tile, bank tile) pair for one wave: filter the wave's 256 x 32 scores against the
+// per-query thresholds (phase 1, always) and insert the rare survivors into the lists (phase 2).
+template <bool SLOW = true, bool WIDE = false>
+__device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, float* lst_s, unsigned* lst_i, float* sc,
+                                              int w, int lane, int k, unsigned bt, int klw = HB_KL) {
+    unsigned qmask = 0;   // bit 4t+q: quarter q (8 bank rows) of row tile t holds a score above its query's threshold
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool any = (acc[t][4 * q] > thr) | (acc[t][4 * q + 1] > thr) | (acc[t][4 * q + 2] > thr) | (acc[t][4 * q + 3] > thr);
+            if (__ballot(any) != 0ull) qmask |= 1u << (4 * t + q);
+        }
+    if (!SLOW) { asm volatile("" :: "s"(qmask)); return; }
+    while (qmask) {   // wave-uniform slow path; ascending bit order = ascending bank row
+        const int bit = __builtin_ctz(qmask);
+        qmask &= qmask - 1;
+        switch (bit) {
+            HB_DUMP_TILE(0) HB_DUMP_TILE(1) HB_DUMP_TILE(2) HB_DUMP_TILE(3)
+            HB_DUMP_TILE(4) HB_DUMP_TILE(5) HB_DUMP_TILE(6) HB_DUMP_TILE(7)
+        }
+        const unsigned row_base = bt * HB_BT + (bit >> 2) * 32 + (bit & 3) * 8;
+        // rows inside the quarter: lane half hh holds rows 4*hh + j in register j
+        for (int hh = 0; hh < 2; ++hh)
+            for (int j = 0; j < 4; ++j) {
+                const float v = sc[j * 64 + lane];
+                unsigned long long m = __ballot(v > thr);
+                m &= hh ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
+                while (m) {
+                    const int l = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+                    const int n = l & 31;
+                    float kth;
+                    if constexpr (WIDE) {
+                        float* gs = lst_s + (size_t)(w * 32 + n) * klw;
+                        list_insert_wide(gs, lst_i + (size_t)(w * 32 + n) * klw, k, klw, s, row_base + hh * 4 + j, lane);
+                        kth = __hip_atomic_load(gs + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        list_insert(lst_s, lst_i, w * 32 + n, k, s, row_base + hh * 4 + j, lane);
+                        kth = lst_s[(w * 32 + n) * HB_KL + (k - 1)];
+                    }
+                    if ((lane & 31) == n) thr = kth;
+                }
+            }
+    }
+}
+
 // LDS map shared by the variants (bytes): a 4-slot ring of k8 stages, two row-init buffers, the lists, the scratch
 #define KN_SLOT_BYTES 16384                 // 8 KiB bank fragments + 8 KiB query fragments (32 rows x 8 k blocks)
 #define KN_RING 4

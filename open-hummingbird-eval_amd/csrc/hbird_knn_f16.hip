@@ -1,0 +1,283 @@
+// Row f5 of SURVEY.md 8: `use_fp16` (reference hbird/nn/search_faiss.py:7, 40: GpuIndexFlatConfig.useFloat16 --
+// fp16 storage and fp16 GEMM with fp32 accumulation).
+//
+// Here: a CANDIDATE pass on fp16 copies of the bank and query fragment tiles with v_mfma_f32_32x32x16_f16 (16x the
+// fp32 MFMA rate), fused running top-k' (k' = 64 .. 256 >= 2k) exactly like the fp32 kernel, followed by an EXACT
+// re-rank of the k' candidates in the fp32 chain arithmetic of the fp32 kernel (every score one k-ascending fmaf
+// chain on the fp32 tiles).  Indices and distances are therefore those of the fp32 definition whenever the true
+// top-k lie within the fp16 top-k' -- their fp16 scores would have to be off by more than the gap between rank k
+// and rank k' for that to fail.
+//
+// The candidate kernel is bound by LDS staging (128 FLOP per staged byte, about 6 TB/s of LDS-DMA streaming on this
+// chip, tools/ubench/dma_bw.hip), not by the matrix pipe: a stage is k = 64 (32 KiB of bank + 32 KiB of query
+// fragments), double-buffered (128 KiB of LDS); the per-query lists live in HBM (the WIDE path), only the
+// thresholds stay in registers.
+#include "hbird_knn_dev.h"
+#include <algorithm>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define F16_GROUPS 4                                   // k16 fragment groups per stage (k = 64)
+#define F16_SLOT_BYTES (2 * 8 * F16_GROUPS * 1024)     // 32 KiB bank + 32 KiB query fragments
+#define F16_BINIT (2 * F16_SLOT_BYTES)
+#define F16_SCRATCH (F16_BINIT + 2048)
+#define F16_LDS_TOTAL (F16_SCRATCH + 8192)
+
+// fp32 fragment tiles -> fp16 fragment tiles.  fp16 block(rt, g16) = 32 rows x 16 k = 1 KiB, element (i, kk) at half
+// index ((kk >> 3) * 32 + i) * 8 + (kk & 7): lane l = h*32 + i reads 8 halves = k = 16 g16 + 8h + 0..7, the A/B
+// operand of one 32x32x16 MFMA.  One thread per 8 output halves.
+__global__ __launch_bounds__(256) void tiles_to_f16_kernel(const float* __restrict__ t32, int g8, _Float16* __restrict__ t16,
+                                                           int g16, int64_t n_row_tiles, int64_t rt0) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one per (row tile, g16, h, i)
+    const int64_t total = n_row_tiles * g16 * 64;
+    if (gid >= total) return;
+    const int i = (int)(gid & 31), h = (int)((gid >> 5) & 1);
+    const int64_t blk = gid >> 6;
+    const int g = (int)(blk % g16);
+    const int64_t rt = rt0 + blk / g16;
+    f16x8 out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 16 * g + 8 * h + j;
+        const int gg = k >> 3, kk = k & 7;
+        float v = 0.0f;
+        if (gg < g8) v = t32[((rt * g8) + gg) * HB_BLK + ((kk & 1) * 32 + i) * 4 + (kk >> 1)];
+        out[j] = (_Float16)v;
+    }
+    reinterpret_cast<f16x8*>(t16)[(rt * g16 + g) * 64 + h * 32 + i] = out;
+}
+
+int hb_launch_tiles_to_f16(const float* t32, int g8, _Float16* t16, int g16, int64_t n_row_tiles, int64_t rt0, hipStream_t s) {
+    const int64_t total = n_row_tiles * g16 * 64;
+    if (total == 0) return 0;
+    tiles_to_f16_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(t32, g8, t16, g16, n_row_tiles, rt0);
+    HB_HIP(hipGetLastError());
+    return 0;
+}
+
+struct knn16_args {
+    const _Float16* bank16;
+    const float* binit;
+    const _Float16* q16;
+    const hb_seg* segs;
+    const int* wg_off;
+    float* state_s;
+    unsigned* state_i;
+    int g16;   // Dp16 / 16
+    int k;     // k' (candidates per query)
+    int klw;
+};
+
+__global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    float* sc = reinterpret_cast<float*>(smem + F16_SCRATCH) + w * 256;
+    const int g16 = a.g16, k = a.k, klw = a.klw;
+    const int NS = g16 / F16_GROUPS;   // stages per bank tile
+    const int myq = w * 32 + (lane & 31);
+
+    const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
+    for (int si = seg_begin; si < seg_end; ++si) {
+        const hb_seg seg = a.segs[si];
+        float* wl_s = a.state_s + (size_t)seg.slot * HB_QT * klw;
+        unsigned* wl_i = a.state_i + (size_t)seg.slot * HB_QT * klw;
+        if (seg.first)
+            for (int e = lane; e < 32 * klw; e += 64) { wl_s[(size_t)w * 32 * klw + e] = -INFINITY; wl_i[(size_t)w * 32 * klw + e] = HB_ID_NONE; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float thr = __hip_atomic_load(wl_s + (size_t)myq * klw + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int total = seg.n_tiles * NS;
+        f32x16 acc[8];
+
+        // stage (bt, ks): 32 bank blocks (8 row tiles x 4 groups) + 32 query blocks; waves 0-3 issue 16 copies each:
+        // wave w copies row tiles w and w+4 (4 consecutive KiB each) of the bank and of the query tile
+        auto issue = [&](int bt, int ks, int slot) {
+            if (w < 4) {
+                char* sb = smem + slot * F16_SLOT_BYTES;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int rt = w + 4 * r;
+                    const _Float16* bsrc = a.bank16 + ((size_t)(bt * 8 + rt) * g16 + ks * F16_GROUPS) * 512 + lane * 8;
+                    const _Float16* qsrc = a.q16 + ((size_t)(seg.q_tile * 8 + rt) * g16 + ks * F16_GROUPS) * 512 + lane * 8;
+#pragma unroll
+                    for (int g = 0; g < F16_GROUPS; ++g) {
+                        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(bsrc + g * 512), (lds_void*)(sb + (rt * F16_GROUPS + g) * 1024), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(qsrc + g * 512), (lds_void*)(sb + 32768 + (rt * F16_GROUPS + g) * 1024), 16, 0, 0);
+                    }
+                }
+                if (ks == 0 && w == 0) glds16(a.binit + (size_t)bt * HB_BT + lane * 4, smem + F16_BINIT + (bt & 1) * 1024);
+            }
+        };
+
+        int bt = seg.b_tile0, ks = 0;
+        int fbt = seg.b_tile0, fks = 0;
+        issue(fbt, fks, 0);
+        for (int st = 0; st < total; ++st) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage st has landed (only one stage is ever in flight)
+            __syncthreads();                                     // ... for everyone; the other slot is free again
+            if (st + 1 < total) {
+                if (++fks == NS) { fks = 0; ++fbt; }
+                issue(fbt, fks, (st + 1) & 1);
+            }
+            const char* sb = smem + (st & 1) * F16_SLOT_BYTES;
+            if (ks == 0) {
+                const f32x4* bi = reinterpret_cast<const f32x4*>(smem + F16_BINIT + (bt & 1) * 1024);
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = bi[8 * t + 2 * g + h];
+                        acc[t][4 * g + 0] = v[0]; acc[t][4 * g + 1] = v[1];
+                        acc[t][4 * g + 2] = v[2]; acc[t][4 * g + 3] = v[3];
+                    }
+            }
+            const f16x8* A = reinterpret_cast<const f16x8*>(sb) + lane;
+            const f16x8* B = reinterpret_cast<const f16x8*>(sb + 32768) + lane;
+#pragma unroll
+            for (int g = 0; g < F16_GROUPS; ++g) {
+                const f16x8 b = B[(w * F16_GROUPS + g) * 64];
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(t * F16_GROUPS + g) * 64], b, acc[t], 0, 0, 0);
+            }
+            if (++ks == NS) {
+                tile_epilogue<true, true>(acc, thr, wl_s, wl_i, sc, w, lane, k, (unsigned)bt, klw);
+                ks = 0;
+                ++bt;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+// Exact re-rank: one wave per query; lane j scores candidates j, j+64, ... with the fp32 chain arithmetic of the fp32
+// kernel (acc = row init; acc = fmaf(q_k, b_k, acc) for k ascending over the fp32 fragment tiles), then the wave
+// ranks them by (score desc, id asc) and writes the best k.
+__global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ tiles, const float* __restrict__ binit, int g8,
+                                                     int d, const float* __restrict__ q, const float* __restrict__ qn2,
+                                                     const int64_t* __restrict__ cand, const float* __restrict__ cand_score,
+                                                     const float* __restrict__ qnorm, const float* __restrict__ bmax,
+                                                     unsigned char* __restrict__ certified, int kc, int64_t nq, int k,
+                                                     int64_t id_base, int metric, int64_t* __restrict__ out_idx,
+                                                     float* __restrict__ out_dist) {
+    __shared__ float s_sc[4][256];
+    __shared__ int64_t s_id[4][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + wv;
+    if (qi >= nq) return;   // wave-uniform
+    const float* qr = q + qi * (int64_t)d;
+    for (int c = lane; c < kc; c += 64) {
+        const int64_t row = cand[qi * (int64_t)kc + c];
+        float acc = -INFINITY;
+        if (row >= 0) {
+            acc = binit[row];
+            const float* base = tiles + ((row >> 5) * (int64_t)g8) * HB_BLK + (int)(row & 31) * 4;
+            for (int g = 0; g < g8; ++g) {
+                const f32x4 e = *reinterpret_cast<const f32x4*>(base + (int64_t)g * HB_BLK);         // k = 8g + 0,2,4,6
+                const f32x4 o = *reinterpret_cast<const f32x4*>(base + (int64_t)g * HB_BLK + 128);   // k = 8g + 1,3,5,7
+                const int k0 = 8 * g;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (k0 + 2 * j < d) acc = fmaf(qr[k0 + 2 * j], e[j], acc);
+                    if (k0 + 2 * j + 1 < d) acc = fmaf(qr[k0 + 2 * j + 1], o[j], acc);
+                }
+            }
+        }
+        s_sc[wv][c] = acc;
+        s_id[wv][c] = row;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are visible to its lanes
+    for (int c = lane; c < kc; c += 64) {
+        const float s = s_sc[wv][c];
+        const int64_t id = s_id[wv][c];
+        int rank = 0;
+        for (int j = 0; j < kc; ++j) {
+            const float sj = s_sc[wv][j];
+            const int64_t ij = s_id[wv][j];
+            bool better;
+            if (ij < 0 || id < 0) better = (ij >= 0 && id < 0) || (ij < 0 && id < 0 && j < c);
+            else better = (sj > s) || (sj == s && (ij < id || (ij == id && j < c)));
+            rank += better;
+        }
+        if (rank == k - 1) {
+            // Certificate: every row outside the candidate list has an fp16 score <= the kc-th candidate's, hence an
+            // exact score <= that + E with E >= |fp16 score - exact score| (both inputs rounded to fp16: relative
+            // 2^-10 per product, Cauchy-Schwarz over the row; fp32 accumulation: D * 2^-23).  If the exact k-th best
+            // is strictly above that bound, no outside row can enter the top k: the answer IS the fp32 answer.
+            const int64_t last = cand[qi * (int64_t)kc + kc - 1];
+            bool ok = last < 0;                       // fewer than kc rows exist: every row was a candidate
+            if (!ok && id >= 0) {
+                const float E = qnorm[qi] * bmax[0] * (1.05f / 1024.0f + (float)d * 2.4e-7f)
+                                + (qnorm[qi] + bmax[0]) * sqrtf((float)d) * 6e-8f + 1e-30f;   // fp16 subnormal inputs
+                ok = s > cand_score[qi * (int64_t)kc + kc - 1] + E;
+            }
+            certified[qi] = ok ? 1 : 0;
+        }
+        if (rank < k) {
+            const int64_t o = qi * (int64_t)k + rank;
+            if (id < 0) { out_idx[o] = -1; out_dist[o] = metric == 1 ? INFINITY : -INFINITY; }
+            else {
+                out_idx[o] = id + id_base;
+                if (metric == 1) { const float d2 = fmaf(-2.0f, s, qn2[qi]); out_dist[o] = d2 > 0.0f ? d2 : 0.0f; }
+                else out_dist[o] = s;
+            }
+        }
+    }
+}
+
+int hb_launch_rerank(const float* tiles, const float* binit, int g8, int d, const float* q, const float* qn2,
+                     const int64_t* cand, const float* cand_score, const float* qnorm, const float* bmax,
+                     unsigned char* certified, int kc, int64_t nq, int k, int64_t id_base, int metric, int64_t* out_idx,
+                     float* out_dist, hipStream_t s) {
+    if (nq == 0) return 0;
+    if (kc > 256) return hb_fail("hb_index_search: too many candidates for the re-rank kernel");
+    rerank_kernel<<<dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s>>>(tiles, binit, g8, d, q, qn2, cand, cand_score, qnorm, bmax,
+                                                                     certified, kc, nq, k, id_base, metric, out_idx, out_dist);
+    HB_HIP(hipGetLastError());
+    return 0;
+}
+
+void hb_knn_f16_launch(const void* args, int grid, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)knn_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F16_LDS_TOTAL); attr = true; }
+    knn_f16_kernel<<<dim3((unsigned)grid), dim3(HB_THREADS), F16_LDS_TOTAL, s>>>(*reinterpret_cast<const knn16_args*>(args));
+}
+
+// max over bank-row norms (all positive), kept in a device scalar for the certificate above
+__global__ __launch_bounds__(256) void bnorm_max_kernel(const float* __restrict__ bnorm, int64_t n, float* __restrict__ bmax) {
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, bnorm[i]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(bmax), __float_as_int(m));   // positive floats order like ints
+}
+
+int hb_launch_bnorm_max(const float* bnorm, int64_t n, float* bmax, hipStream_t s) {
+    if (n == 0) return 0;
+    const int64_t blocks = std::min<int64_t>((n + 255) / 256, 1024);
+    bnorm_max_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(bnorm, n, bmax);
+    HB_HIP(hipGetLastError());
+    return 0;
+}
+
+// out_idx[rows[i], :] = src_idx[i, :], out_dist likewise (results of the exact re-search of uncertified queries)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const int64_t* __restrict__ rows, int64_t n, int k,
+                                                           const int64_t* __restrict__ src_idx, const float* __restrict__ src_dist,
+                                                           int64_t* __restrict__ out_idx, float* __restrict__ out_dist) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * k) return;
+    const int64_t i = t / k;
+    const int j = (int)(t % k);
+    out_idx[rows[i] * k + j] = src_idx[t];
+    out_dist[rows[i] * k + j] = src_dist[t];
+}
+
+int hb_launch_scatter_rows(const int64_t* rows, int64_t n, int k, const int64_t* src_idx, const float* src_dist,
+                           int64_t* out_idx, float* out_dist, hipStream_t s) {
+    if (n == 0) return 0;
+    scatter_rows_kernel<<<dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, s>>>(rows, n, k, src_idx, src_dist, out_idx, out_dist);
+    HB_HIP(hipGetLastError());
+    return 0;
+}

@@ -310,6 +310,12 @@ def test_headline_size_10m_x_768(cuda_device):
     im, dm = merge_topk(torch.stack([da, db]), torch.stack([ia, ib]), 0)
     assert torch.equal(im, idx) and torch.equal(dm, dist)
     del a, b
+    # use_fp16 mode (fp16 candidate pass + certified exact re-rank) must return the very same bits
+    ix.set_fp16(True)
+    idx16, dist16 = ix.search(q, k)
+    assert torch.equal(idx16, idx) and torch.equal(dist16, dist)
+    assert ix.last_fp16_fallbacks() < nq // 100
+    ix.set_fp16(False)
     # float64 scores of 16 queries against every bank row (chunked reconstruct), exact top-k by (score, id)
     sel = torch.tensor([0, 5, 127, 128, 1000, 5000, 9999, 12345, 15000, 17000, 19000, 20000, 21000, 21500, 21900, 21903],
                        device=dev)
@@ -327,3 +333,54 @@ def test_headline_size_10m_x_768(cuda_device):
     assert rep["excused_rate"] == 1.0 and rep["set_rate"] >= 0.9, rep
     # fp32 chain rounding: ~1e-7 * sum|q_k b_k| (a few 1e-5 at |q| ~ 83, D = 768)
     assert np.abs(dist[sel].cpu().numpy() - best_s.cpu().numpy()).max() < 1e-4
+
+
+@pytest.mark.parametrize("M,D,nq,k,metric", [
+    (5000, 64, 300, 30, "dot_product"),
+    (20000, 384, 520, 30, "dot_product"),
+    (20000, 384, 520, 30, "l2"),
+    (9000, 768, 300, 10, "dot_product"),
+    (3000, 40, 100, 90, "dot_product"),        # D padded to 64, k' = 192
+    (100, 16, 20, 30, "dot_product"),          # fewer rows than k'
+])
+def test_use_fp16_candidate_pass_with_exact_rerank(cuda_device, M, D, nq, k, metric):
+    """use_fp16 (search_faiss.py:40): fp16 MFMA candidate pass (k' >= 2k) + fp32 chain re-rank -> the fp32 answer."""
+    bank = gi.unit_bank(M, D, seed=M + 1)
+    q = gi.vit_like_queries(nq, D, seed=nq + 1)
+    nn = NearestNeighborSearchHIP(torch.from_numpy(bank), n_neighbors=k, distance_measure=metric, use_fp16=True, gpu_ids=[0])
+    idx, dist = nn.find_nearest_neighbors(torch.from_numpy(q))
+    _check_exact(idx, dist, q, bank, k, metric)
+    ix = nn.index
+    ix.set_tuning(6, 2)
+    idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
+    _check_exact(idx, dist, q, bank, k, metric)
+    ix.add(bank[:100] * 0.5)                    # appending after a search re-converts the touched tiles
+    idx, dist = ix.search(q, k)
+    _check_exact(idx, dist, q, np.concatenate([bank, bank[:100] * 0.5]), k, metric)
+
+
+def test_use_fp16_certificate_and_exact_fallback(cuda_device):
+    """Near-duplicate bank rows cannot be ranked by fp16 scores: the per-query certificate must fail for them and the
+    exact fp32 re-search must deliver the fp32 answer anyway; well-separated queries stay on the fast path."""
+    M, D, k = 6000, 64, 30
+    rng = np.random.default_rng(5)
+    bank = gi.unit_bank(M, D, seed=3)
+    centre = bank[10].copy()
+    for r in range(200, 500):                      # 300 rows within 1e-4 of one direction
+        v = centre + 1e-4 * rng.standard_normal(D).astype(np.float32)
+        bank[r] = v / np.linalg.norm(v)
+    q = gi.vit_like_queries(300, D, seed=4)
+    q[:40] = 4.0 * centre + 1e-3 * rng.standard_normal((40, D)).astype(np.float32)   # queries aimed at the cluster
+    ix = HipFlatIndex(D, 0, 0)
+    ix.add(bank)
+    ix.set_fp16(True)
+    idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
+    _check_exact(idx, dist, q, bank, k, "dot_product")
+    nfb = ix.last_fp16_fallbacks()
+    assert 40 <= nfb < 150, nfb                    # the 40 cluster queries (at least) were re-searched exactly
+    idx, dist = ix.search(q[40:], k)               # host path, only ordinary queries
+    _check_exact(idx, dist, q[40:], bank, k, "dot_product")
+    assert ix.last_fp16_fallbacks() <= nfb - 40
+    ix.set_fp16(False)
+    i32, d32 = ix.search(q, k)
+    _check_exact(i32, d32, q, bank, k, "dot_product")
