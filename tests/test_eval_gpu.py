@@ -162,3 +162,17 @@ def test_end_to_end_vit_b14_shapes_vs_oracle(cuda_device):
         lh = oracle.cross_attention(tok, kf, kl)
         m.update(np.rint(y.numpy() * 255).astype(np.int64), oracle.upsample_argmax(lh, S, H, H))
     assert abs(jac - m.compute()[0]) < 1e-4, (jac, m.compute()[0])
+
+
+def test_evaluate_with_use_fp16_equals_fp32(cuda_device, golden_dir):
+    """nn_params={'use_fp16': True} (search_faiss.py:7, 40) runs the certified fast mode: same mIoU, same label_hat."""
+    g = np.load(f"{golden_dir}/g67_memory_evaluate.npz")
+    c = golden_case(g, "ade")
+    outs = []
+    for fp16 in (False, True):
+        ev = HbirdEvaluation(ReplayExtractor(c["tr_tok"] + c["va_tok"], c["S"], c["D"]), c["train"], num_classes=c["C"],
+                             n_neighbours=c["k"], device="cuda", nn_method="faiss", nn_params={"use_fp16": fp16})
+        outs.append(ev.evaluate(c["val"], c["S"], return_knn_details=True, ignore_index=c["ign"]))
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1]["knns_ca_labels"], outs[1][1]["knns_ca_labels"])
+    assert torch.equal(outs[0][1]["knns_labels"], outs[1][1]["knns_labels"])
