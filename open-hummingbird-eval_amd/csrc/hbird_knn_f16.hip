@@ -211,7 +211,9 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ t
             bool ok = last < 0;                       // fewer than kc rows exist: every row was a candidate
             if (!ok && id >= 0) {
                 const float E = qnorm[qi] * bmax[0] * (1.05f / 1024.0f + (float)d * 2.4e-7f)
-                                + (qnorm[qi] + bmax[0]) * sqrtf((float)d) * 6e-8f + 1e-30f;   // fp16 subnormal inputs
+                                + (qnorm[qi] + bmax[0]) * sqrtf((float)d) * 6e-8f                 // fp16 subnormal inputs
+                                + (metric == 1 ? (float)d * 1.2e-7f * 0.5f * bmax[0] * bmax[0] : 0.0f)  // |row init| in the sums
+                                + 1e-30f;
                 ok = s > cand_score[qi * (int64_t)kc + kc - 1] + E;
             }
             certified[qi] = ok ? 1 : 0;
