@@ -47,7 +47,7 @@ extern "C" int hb_index_free(hb_index_t* ix) {
     (void)hipSetDevice(ix->device);
     (void)hipStreamSynchronize(ix->stream);
     void* ptrs[] = {ix->tiles, ix->binit, ix->bnorm, ix->labels, ix->q_tiles, ix->q_aux, ix->state, ix->sched_dev, ix->tmp,
-                    ix->tiles16, ix->q16, ix->cand, ix->bmax, ix->fb};
+                    ix->tiles16, ix->q16, ix->cand, ix->bmax, ix->fb, ix->mtmp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ix->ev0) (void)hipEventDestroy(ix->ev0);
     if (ix->ev1) (void)hipEventDestroy(ix->ev1);

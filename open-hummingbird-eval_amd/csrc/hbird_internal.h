@@ -70,6 +70,7 @@ struct hb_index {
     void* q16 = nullptr; size_t q16_bytes = 0;
     char* cand = nullptr; size_t cand_bytes = 0;
     float* bmax = nullptr;                               // device scalar: max bank-row norm
+    char* mtmp = nullptr; size_t mtmp_bytes = 0;         // first-level lists of a two-level merge
     char* fb = nullptr; size_t fb_bytes = 0;             // fallback workspace (uncertified queries)
     int64_t last_fp16_fallbacks = 0;
     int variant = 0;                                     // 0: 8-wave kernel, 1: 4-wave (one wave per SIMD) kernel

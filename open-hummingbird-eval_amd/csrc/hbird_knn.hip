@@ -190,26 +190,52 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
 }
 
 // ---- merge of the partial lists of one query: rank by counting over <= slots*k candidates --------
+static int ensure_bytes(char** p, size_t* have, size_t need) {
+    if (*have >= need) return 0;
+    if (*p) HB_HIP(hipFree(*p));
+    *p = nullptr; *have = 0;
+    size_t sz = need + need / 4;
+    HB_HIP(hipMalloc((void**)p, sz));
+    *have = sz;
+    return 0;
+}
+
+// Slot selection of a merge block: either the work list's slots of the query tile (qt_slots) or, in the second
+// level of a two-level merge, the `fixed_ng` group lists written by the first level (slot = qt * fixed_ng + j).
+// grp_size > 0 (first level): block (q, grp) merges only slots [grp*grp_size, (grp+1)*grp_size) of its query tile
+// and writes a list in state format into (tmp_s, tmp_i) slot qt * n_groups + grp.
 __global__ __launch_bounds__(64) void knn_merge_kernel(const float* __restrict__ state_s,
                                                        const unsigned* __restrict__ state_i,
                                                        const int* __restrict__ qt_off, const int* __restrict__ qt_slots,
+                                                       int fixed_ng, int grp_size, int n_groups, float* __restrict__ tmp_s,
+                                                       unsigned* __restrict__ tmp_i,
                                                        int64_t nq, int k, int klw, int64_t id_base, int metric,
                                                        const float* __restrict__ qn2, int64_t* __restrict__ out_idx,
                                                        float* __restrict__ out_dist) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int64_t q = blockIdx.x;
+    const int grp = blockIdx.y;
     const int qt = (int)(q / HB_QT), ql = (int)(q % HB_QT);
-    const int s0 = qt_off[qt], ns = qt_off[qt + 1] - s0;
+    int s0, ns;
+    if (fixed_ng > 0) { s0 = qt * fixed_ng; ns = fixed_ng; }
+    else { s0 = qt_off[qt]; ns = qt_off[qt + 1] - s0; }
+    if (grp_size > 0) {
+        const int lo = min(ns, grp * grp_size), hi = min(ns, lo + grp_size);
+        s0 += lo; ns = hi - lo;
+    }
     const int n = ns * k;
     float* cs = reinterpret_cast<float*>(smem);
     unsigned* ci = reinterpret_cast<unsigned*>(smem) + n;
     const int lane = threadIdx.x;
     for (int c = lane; c < n; c += 64) {
-        const int sl = qt_slots[s0 + c / k], e = c % k;
+        const int sl = fixed_ng > 0 ? s0 + c / k : qt_slots[s0 + c / k], e = c % k;
         const size_t off = ((size_t)sl * HB_QT + ql) * klw + e;
         cs[c] = state_s[off];
         ci[c] = state_i[off];
     }
+    const size_t tmp_off = grp_size > 0 ? ((size_t)(qt * n_groups + grp) * HB_QT + ql) * klw : 0;
+    if (grp_size > 0)   // an empty or short group still yields a full sentinel-padded list
+        for (int e = lane; e < k; e += 64) { tmp_s[tmp_off + e] = -INFINITY; tmp_i[tmp_off + e] = HB_ID_NONE; }
     __syncthreads();
     for (int c = lane; c < n; c += 64) {
         const float s = cs[c];
@@ -221,6 +247,7 @@ __global__ __launch_bounds__(64) void knn_merge_kernel(const float* __restrict__
             rank += (sj > s) || (sj == s && (ij < id || (ij == id && j < c)));
         }
         if (rank < k) {
+            if (grp_size > 0) { tmp_s[tmp_off + rank] = s; tmp_i[tmp_off + rank] = id; continue; }
             const int64_t o = q * (int64_t)k + rank;
             if (id == HB_ID_NONE) {
                 out_idx[o] = -1;
@@ -232,6 +259,36 @@ __global__ __launch_bounds__(64) void knn_merge_kernel(const float* __restrict__
             }
         }
     }
+}
+
+// Merge the partial lists of every query: one level when slots*k fits the merge block's LDS, two levels otherwise
+// (few query tiles against a big bank: up to one slot per workgroup).
+static int launch_merge(hb_index* ix, const float* state_s, const unsigned* state_i, const int* qt_off, const int* qt_slots,
+                        int max_slots, int nqt, int64_t nq, int k, int klw, int64_t id_base, int metric, const float* qn2,
+                        int64_t* out_idx, float* out_dist, hipStream_t s) {
+    const size_t lim = 48 * 1024;
+    if ((size_t)max_slots * k * 8 <= lim) {
+        knn_merge_kernel<<<dim3((unsigned)nq), dim3(64), (size_t)max_slots * k * 8, s>>>(state_s, state_i, qt_off, qt_slots, 0, 0, 0,
+                                                                                          nullptr, nullptr, nq, k, klw, id_base,
+                                                                                          metric, qn2, out_idx, out_dist);
+        HB_HIP(hipGetLastError());
+        return 0;
+    }
+    const int grp = std::max<int>(2, (int)(lim / ((size_t)k * 8)));
+    const int ng = (max_slots + grp - 1) / grp;
+    if ((size_t)ng * k * 8 > lim) return hb_fail("hb_index_search: too many partial lists per query tile for the merge kernel");
+    const size_t half = (size_t)nqt * ng * HB_QT * klw * 4;
+    if (ensure_bytes(&ix->mtmp, &ix->mtmp_bytes, 2 * half)) return -1;
+    float* ts = reinterpret_cast<float*>(ix->mtmp);
+    unsigned* ti = reinterpret_cast<unsigned*>(ix->mtmp + half);
+    knn_merge_kernel<<<dim3((unsigned)nq, (unsigned)ng), dim3(64), (size_t)grp * k * 8, s>>>(state_s, state_i, qt_off, qt_slots, 0, grp, ng,
+                                                                                              ts, ti, nq, k, klw, 0, 0, nullptr,
+                                                                                              nullptr, nullptr);
+    HB_HIP(hipGetLastError());
+    knn_merge_kernel<<<dim3((unsigned)nq), dim3(64), (size_t)ng * k * 8, s>>>(ts, ti, nullptr, nullptr, ng, 0, 0, nullptr, nullptr, nq, k,
+                                                                                klw, id_base, metric, qn2, out_idx, out_dist);
+    HB_HIP(hipGetLastError());
+    return 0;
 }
 
 // ---- merge of per-shard results [parts][nq][k] (multi-GPU: after the all-gather) -------------------
@@ -361,15 +418,6 @@ void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out) {
     }
 }
 
-static int ensure_bytes(char** p, size_t* have, size_t need) {
-    if (*have >= need) return 0;
-    if (*p) HB_HIP(hipFree(*p));
-    *p = nullptr; *have = 0;
-    size_t sz = need + need / 4;
-    HB_HIP(hipMalloc((void**)p, sz));
-    *have = sz;
-    return 0;
-}
 
 // q_tiles / q_aux must already be prepared by the caller (hb_index_search).
 struct knn16_args_host {   // must match knn16_args in hbird_knn_f16.hip
@@ -427,8 +475,6 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     a.state_s = reinterpret_cast<float*>(ix->state);
     a.state_i = reinterpret_cast<unsigned*>(ix->state + state_half);
     a.g8 = ix->g8; a.k = k; a.klw = klw;
-    const size_t msh = (size_t)sc.max_slots_per_qt * kc * 8;
-    if (msh > 64000) return hb_fail("hb_index_search: too many partial lists per query tile for the merge kernel");
     if (f16) {
         // bring the fp16 copies of the bank / query fragment tiles up to date
         const int64_t need_rt = (ix->ntotal + 31) / 32;
@@ -457,11 +503,9 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         hb_knn_f16_launch(&h, sc.G, s);
         HB_HIP(hipGetLastError());
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
-        knn_merge_kernel<<<dim3((unsigned)nq), dim3(64), msh, s>>>(a.state_s, a.state_i,
-                                                                   reinterpret_cast<const int*>(ix->sched_dev + o_qo),
-                                                                   reinterpret_cast<const int*>(ix->sched_dev + o_qs), nq, kc, klw,
-                                                                   0, 0, nullptr, cand_idx, cand_dist);
-        HB_HIP(hipGetLastError());
+        if (launch_merge(ix, a.state_s, a.state_i, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
+                         reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, kc, klw, 0, 0, nullptr,
+                         cand_idx, cand_dist, s)) return -1;
         if (ensure_bytes(&ix->fb, &ix->fb_bytes, (size_t)nq + 64)) return -1;
         unsigned char* cert = reinterpret_cast<unsigned char*>(ix->fb);
         if (hb_launch_rerank(ix->tiles, ix->binit, ix->g8, ix->d, q_dev, ix->q_aux, cand_idx, cand_dist, ix->q_aux + nq, ix->bmax,
@@ -547,11 +591,9 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     HB_HIP(hipGetLastError());
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
     const float* qn2 = ix->q_aux;   // [nq] chain ||q||^2 (valid for L2)
-    knn_merge_kernel<<<dim3((unsigned)nq), dim3(64), msh, s>>>(a.state_s, a.state_i,
-                                                               reinterpret_cast<const int*>(ix->sched_dev + o_qo),
-                                                               reinterpret_cast<const int*>(ix->sched_dev + o_qs), nq, k, klw,
-                                                               id_base, ix->metric, qn2, out_idx, out_dist);
-    HB_HIP(hipGetLastError());
+    if (launch_merge(ix, a.state_s, a.state_i, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
+                     reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, k, klw, id_base, ix->metric,
+                     qn2, out_idx, out_dist, s)) return -1;
     if (ix->time_kernels) {
         HB_HIP(hipEventSynchronize(ix->ev1));
         float ms = 0.f;

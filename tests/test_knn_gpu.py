@@ -384,3 +384,18 @@ def test_use_fp16_certificate_and_exact_fallback(cuda_device):
     ix.set_fp16(False)
     i32, d32 = ix.search(q, k)
     _check_exact(i32, d32, q, bank, k, "dot_product")
+
+
+@pytest.mark.parametrize("k,fp16", [(30, False), (32, False), (90, False), (256, False), (30, True), (100, True)])
+def test_few_queries_against_a_big_bank_two_level_merge(cuda_device, k, fp16):
+    """One query tile against many bank tiles: every workgroup holds a partial list of the same queries (up to 256
+    lists per query), merged in two levels."""
+    M, D, nq = 300_000, 64, 100
+    bank = gi.unit_bank(M, D, seed=8)
+    q = gi.vit_like_queries(nq, D, seed=9)
+    ix = HipFlatIndex(D, 0, 0)
+    ix.add(torch.from_numpy(bank).cuda())
+    ix.set_fp16(fp16)
+    idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
+    assert ix.schedule_info()["max_slots_per_qtile"] == 256
+    _check_exact(idx, dist, q, bank, k, "dot_product")
