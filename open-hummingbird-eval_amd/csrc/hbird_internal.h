@@ -10,6 +10,7 @@
 #define HB_BT 256        // bank rows per tile (8 MFMA row tiles of 32)
 #define HB_RT 32         // rows per fragment tile (MFMA 32x32x2)
 #define HB_KC 16         // k extent of one LDS stage (two 8-wide fragment groups)
+#define HB_POOL_MAX 512  // largest candidate pool per (slot, query) in global memory (k > HB_KL)
 #define HB_KL 32         // per-query list capacity kept in LDS (k <= HB_KL on the fused path)
 #define HB_THREADS 512
 #define HB_WAVES 8

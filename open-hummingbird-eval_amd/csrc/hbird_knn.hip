@@ -40,6 +40,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
     float* lst_s = reinterpret_cast<float*>(smem + KN_LISTS);
     unsigned* lst_i = reinterpret_cast<unsigned*>(smem + KN_LISTS + HB_QT * HB_KL * 4);
     float* sc = reinterpret_cast<float*>(smem + KN_SCRATCH) + w * 256;
+    int* pcnt = reinterpret_cast<int*>(smem + KN_LISTS);
     const int g8 = a.g8, k = a.k;   // g8 = stages per bank tile
     const int myq = w * 32 + (lane & 31);
 
@@ -51,11 +52,8 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
         unsigned* wl_i = a.state_i + (size_t)seg.slot * HB_QT * klw;
         float thr;
         if constexpr (WIDE) {
-            // k > HB_KL: the lists stay in global memory; only start them when the slot is new
-            if (seg.first)
-                for (int e = lane; e < 32 * klw; e += 64) { wl_s[(size_t)w * 32 * klw + e] = -INFINITY; wl_i[(size_t)w * 32 * klw + e] = HB_ID_NONE; }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            thr = __hip_atomic_load(wl_s + (size_t)myq * klw + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // k > HB_KL: candidate pools in global memory, fill counts in the (otherwise unused) LDS list area
+            thr = pool_begin(knn_args_pool_view{a.state_cnt, a.state_thr}, seg.slot, seg.first, pcnt, myq, lane);
         } else {
             // load (or start) this query tile's partial lists; each wave owns its 32 queries
             for (int e = lane; e < 1024; e += 64) {
@@ -170,7 +168,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
             slot_c = slot_n;
             if (++ks == g8) {
                 if constexpr (!(ABL & 8)) {
-                    if constexpr (WIDE) tile_epilogue<true, true>(acc, thr, wl_s, wl_i, sc, w, lane, k, (unsigned)bt, klw);
+                    if constexpr (WIDE) tile_epilogue<true, true>(acc, thr, wl_s, wl_i, sc, w, lane, k, (unsigned)bt, klw, pcnt);
                     else tile_epilogue<!(ABL & 16), false>(acc, thr, lst_s, lst_i, sc, w, lane, k, (unsigned)bt);
                 }
                 else {
@@ -183,6 +181,8 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
         }
         if constexpr (!WIDE) {   // store the partial lists of this segment
             for (int e = lane; e < 1024; e += 64) { wl_s[w * 1024 + e] = lst_s[w * 1024 + e]; wl_i[w * 1024 + e] = lst_i[w * 1024 + e]; }
+        } else {
+            pool_end(knn_args_pool_view{a.state_cnt, a.state_thr}, seg.slot, pcnt, thr, myq, lane);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (unused) run-ahead copies
         __syncthreads();   // the ring is reused by the next segment's prologue
@@ -203,9 +203,12 @@ static int ensure_bytes(char** p, size_t* have, size_t need) {
 // Slot selection of a merge block: either the work list's slots of the query tile (qt_slots) or, in the second
 // level of a two-level merge, the `fixed_ng` group lists written by the first level (slot = qt * fixed_ng + j).
 // grp_size > 0 (first level): block (q, grp) merges only slots [grp*grp_size, (grp+1)*grp_size) of its query tile
-// and writes a list in state format into (tmp_s, tmp_i) slot qt * n_groups + grp.
+// and writes a sorted list of k entries (row stride klw) into (tmp_s, tmp_i) slot qt * n_groups + grp.
+// A slot holds `per` entries per query: a sorted list (per = k, sentinel-padded) or, with cnts != nullptr, an
+// unsorted candidate pool of which the first cnts[slot][query] entries are valid.
 __global__ __launch_bounds__(64) void knn_merge_kernel(const float* __restrict__ state_s,
                                                        const unsigned* __restrict__ state_i,
+                                                       const int* __restrict__ cnts, int per,
                                                        const int* __restrict__ qt_off, const int* __restrict__ qt_slots,
                                                        int fixed_ng, int grp_size, int n_groups, float* __restrict__ tmp_s,
                                                        unsigned* __restrict__ tmp_i,
@@ -223,19 +226,19 @@ __global__ __launch_bounds__(64) void knn_merge_kernel(const float* __restrict__
         const int lo = min(ns, grp * grp_size), hi = min(ns, lo + grp_size);
         s0 += lo; ns = hi - lo;
     }
-    const int n = ns * k;
     float* cs = reinterpret_cast<float*>(smem);
-    unsigned* ci = reinterpret_cast<unsigned*>(smem) + n;
+    unsigned* ci = reinterpret_cast<unsigned*>(smem) + ns * per;
     const int lane = threadIdx.x;
-    for (int c = lane; c < n; c += 64) {
-        const int sl = fixed_ng > 0 ? s0 + c / k : qt_slots[s0 + c / k], e = c % k;
-        const size_t off = ((size_t)sl * HB_QT + ql) * klw + e;
-        cs[c] = state_s[off];
-        ci[c] = state_i[off];
+    // gather the valid candidates of the slots, densely packed
+    int n = 0;
+    for (int j = 0; j < ns; ++j) {
+        const int sl = fixed_ng > 0 ? s0 + j : qt_slots[s0 + j];
+        const int valid = cnts ? min(per, cnts[(size_t)sl * HB_QT + ql]) : per;
+        const size_t off = ((size_t)sl * HB_QT + ql) * klw;
+        for (int e = lane; e < valid; e += 64) { cs[n + e] = state_s[off + e]; ci[n + e] = state_i[off + e]; }
+        n += valid;
     }
     const size_t tmp_off = grp_size > 0 ? ((size_t)(qt * n_groups + grp) * HB_QT + ql) * klw : 0;
-    if (grp_size > 0)   // an empty or short group still yields a full sentinel-padded list
-        for (int e = lane; e < k; e += 64) { tmp_s[tmp_off + e] = -INFINITY; tmp_i[tmp_off + e] = HB_ID_NONE; }
     __syncthreads();
     for (int c = lane; c < n; c += 64) {
         const float s = cs[c];
@@ -259,34 +262,42 @@ __global__ __launch_bounds__(64) void knn_merge_kernel(const float* __restrict__
             }
         }
     }
+    for (int r = n + lane; r < k; r += 64) {   // fewer than k candidates: missing neighbours
+        if (grp_size > 0) { tmp_s[tmp_off + r] = -INFINITY; tmp_i[tmp_off + r] = HB_ID_NONE; continue; }
+        out_idx[q * (int64_t)k + r] = -1;
+        out_dist[q * (int64_t)k + r] = metric == 1 ? INFINITY : -INFINITY;
+    }
 }
 
-// Merge the partial lists of every query: one level when slots*k fits the merge block's LDS, two levels otherwise
-// (few query tiles against a big bank: up to one slot per workgroup).
-static int launch_merge(hb_index* ix, const float* state_s, const unsigned* state_i, const int* qt_off, const int* qt_slots,
-                        int max_slots, int nqt, int64_t nq, int k, int klw, int64_t id_base, int metric, const float* qn2,
-                        int64_t* out_idx, float* out_dist, hipStream_t s) {
+// Merge the partial lists / pools of every query: one level when the candidates of a query tile's slots fit the merge
+// block's LDS, two levels otherwise (few query tiles against a big bank: up to one slot per workgroup).
+// cnts == nullptr: sorted lists of k entries; otherwise pools of capacity klw with fill counts cnts.
+static int launch_merge(hb_index* ix, const float* state_s, const unsigned* state_i, const int* cnts, const int* qt_off,
+                        const int* qt_slots, int max_slots, int nqt, int64_t nq, int k, int klw, int64_t id_base, int metric,
+                        const float* qn2, int64_t* out_idx, float* out_dist, hipStream_t s) {
     const size_t lim = 48 * 1024;
-    if ((size_t)max_slots * k * 8 <= lim) {
-        knn_merge_kernel<<<dim3((unsigned)nq), dim3(64), (size_t)max_slots * k * 8, s>>>(state_s, state_i, qt_off, qt_slots, 0, 0, 0,
-                                                                                          nullptr, nullptr, nq, k, klw, id_base,
-                                                                                          metric, qn2, out_idx, out_dist);
+    const int per = cnts ? klw : k;
+    if ((size_t)max_slots * per * 8 <= lim) {
+        knn_merge_kernel<<<dim3((unsigned)nq), dim3(64), (size_t)max_slots * per * 8, s>>>(state_s, state_i, cnts, per, qt_off, qt_slots,
+                                                                                            0, 0, 0, nullptr, nullptr, nq, k, klw,
+                                                                                            id_base, metric, qn2, out_idx, out_dist);
         HB_HIP(hipGetLastError());
         return 0;
     }
-    const int grp = std::max<int>(2, (int)(lim / ((size_t)k * 8)));
+    const int grp = std::max<int>(2, (int)(lim / ((size_t)per * 8)));
     const int ng = (max_slots + grp - 1) / grp;
     if ((size_t)ng * k * 8 > lim) return hb_fail("hb_index_search: too many partial lists per query tile for the merge kernel");
     const size_t half = (size_t)nqt * ng * HB_QT * klw * 4;
     if (ensure_bytes(&ix->mtmp, &ix->mtmp_bytes, 2 * half)) return -1;
     float* ts = reinterpret_cast<float*>(ix->mtmp);
     unsigned* ti = reinterpret_cast<unsigned*>(ix->mtmp + half);
-    knn_merge_kernel<<<dim3((unsigned)nq, (unsigned)ng), dim3(64), (size_t)grp * k * 8, s>>>(state_s, state_i, qt_off, qt_slots, 0, grp, ng,
-                                                                                              ts, ti, nq, k, klw, 0, 0, nullptr,
-                                                                                              nullptr, nullptr);
+    knn_merge_kernel<<<dim3((unsigned)nq, (unsigned)ng), dim3(64), (size_t)grp * per * 8, s>>>(state_s, state_i, cnts, per, qt_off, qt_slots,
+                                                                                                0, grp, ng, ts, ti, nq, k, klw, 0, 0,
+                                                                                                nullptr, nullptr, nullptr);
     HB_HIP(hipGetLastError());
-    knn_merge_kernel<<<dim3((unsigned)nq), dim3(64), (size_t)ng * k * 8, s>>>(ts, ti, nullptr, nullptr, ng, 0, 0, nullptr, nullptr, nq, k,
-                                                                                klw, id_base, metric, qn2, out_idx, out_dist);
+    knn_merge_kernel<<<dim3((unsigned)nq), dim3(64), (size_t)ng * k * 8, s>>>(ts, ti, nullptr, k, nullptr, nullptr, ng, 0, 0, nullptr,
+                                                                                nullptr, nq, k, klw, id_base, metric, qn2, out_idx,
+                                                                                out_dist);
     HB_HIP(hipGetLastError());
     return 0;
 }
@@ -422,7 +433,7 @@ void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out) {
 // q_tiles / q_aux must already be prepared by the caller (hb_index_search).
 struct knn16_args_host {   // must match knn16_args in hbird_knn_f16.hip
     const void* bank16; const float* binit; const void* q16; const hb_seg* segs; const int* wg_off;
-    float* state_s; unsigned* state_i; int g16, k, klw;
+    float* state_s; unsigned* state_i; int g16, k, klw; int* state_cnt; float* state_thr;
 };
 
 int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t id_base, int64_t* out_idx, float* out_dist) {
@@ -431,7 +442,8 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // fp16 mode: the fused kernel collects kc >= 2k candidates, the fp32 chain arithmetic re-ranks them
     const int kc = f16 ? std::min(256, std::max(64, (2 * k + 63) / 64 * 64)) : k;
     const bool wide = f16 || k > HB_KL;
-    const int klw = wide ? (kc + 63) / 64 * 64 : HB_KL;
+    // pools (k > HB_KL): capacity >= 2 kc so that a compaction is paid for by >= kc cheap appends
+    const int klw = wide ? std::min(HB_POOL_MAX, (std::max(2 * kc, kc + 128) + 63) / 64 * 64) : HB_KL;
     if (nq == 0) return 0;
     const int nqt = (int)((nq + HB_QT - 1) / HB_QT);
     const int nbt = (int)((ix->ntotal + HB_BT - 1) / HB_BT);
@@ -466,7 +478,8 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         HB_HIP(hipStreamSynchronize(s));   // host vectors may be rebuilt by the next call
     }
     const size_t state_half = (size_t)sc.n_slots * HB_QT * klw * 4;
-    if (ensure_bytes(&ix->state, &ix->state_bytes, 2 * state_half)) return -1;
+    const size_t state_aux = wide ? (size_t)sc.n_slots * HB_QT * 4 : 0;   // pools: fill counts + thresholds
+    if (ensure_bytes(&ix->state, &ix->state_bytes, 2 * state_half + 2 * state_aux)) return -1;
 
     knn_args a;
     a.bank_tiles = ix->tiles; a.binit = ix->binit; a.q_tiles = ix->q_tiles;
@@ -475,6 +488,9 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     a.state_s = reinterpret_cast<float*>(ix->state);
     a.state_i = reinterpret_cast<unsigned*>(ix->state + state_half);
     a.g8 = ix->g8; a.k = k; a.klw = klw;
+    a.state_cnt = reinterpret_cast<int*>(ix->state + 2 * state_half);
+    a.state_thr = reinterpret_cast<float*>(ix->state + 2 * state_half + state_aux);
+    const int* pool_cnt = wide ? a.state_cnt : nullptr;
     if (f16) {
         // bring the fp16 copies of the bank / query fragment tiles up to date
         const int64_t need_rt = (ix->ntotal + 31) / 32;
@@ -499,11 +515,12 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         knn16_args_host h;
         h.bank16 = ix->tiles16; h.binit = ix->binit; h.q16 = ix->q16; h.segs = a.segs; h.wg_off = a.wg_off;
         h.state_s = a.state_s; h.state_i = a.state_i; h.g16 = ix->dp16 / 16; h.k = kc; h.klw = klw;
+        h.state_cnt = a.state_cnt; h.state_thr = a.state_thr;
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev0, s));
         hb_knn_f16_launch(&h, sc.G, s);
         HB_HIP(hipGetLastError());
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
-        if (launch_merge(ix, a.state_s, a.state_i, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
+        if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
                          reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, kc, klw, 0, 0, nullptr,
                          cand_idx, cand_dist, s)) return -1;
         if (ensure_bytes(&ix->fb, &ix->fb_bytes, (size_t)nq + 64)) return -1;
@@ -577,13 +594,13 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     if (!wide && ix->ablate)
         for (size_t i = 0; i < sizeof(variants) / sizeof(variants[0]); ++i) if (variant_bits[i] == ix->ablate) fn = variants[i];
     int threads = HB_THREADS;
-    if (ix->variant == 1) {
-        fn = hb_knn_w4_kernel(wide);
+    if (ix->variant == 1 && !wide) {   // the experimental 4-wave variant only has the LDS-list path
+        fn = hb_knn_w4_kernel(false);
         threads = 256;
-        static bool w4_attr[2] = {false, false};
-        if (!w4_attr[wide]) {
+        static bool w4_attr[1] = {false};
+        if (!w4_attr[0]) {
             HB_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, KN_LDS_TOTAL));
-            w4_attr[wide] = true;
+            w4_attr[0] = true;
         }
     }
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev0, s));
@@ -591,7 +608,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     HB_HIP(hipGetLastError());
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
     const float* qn2 = ix->q_aux;   // [nq] chain ||q||^2 (valid for L2)
-    if (launch_merge(ix, a.state_s, a.state_i, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
+    if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
                      reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, k, klw, id_base, ix->metric,
                      qn2, out_idx, out_dist, s)) return -1;
     if (ix->time_kernels) {

@@ -7,6 +7,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
+struct knn_args_pool_view { int* cnt; float* thr; };
+
 struct knn_args {
     const float* bank_tiles;
     const float* binit;
@@ -17,7 +19,9 @@ struct knn_args {
     unsigned* state_i;
     int g8;   // Dp / 8
     int k;
-    int klw;  // list row stride in the state buffer: HB_KL, or k rounded up to 64 when k > HB_KL
+    int klw;  // row stride in the state buffer: HB_KL (sorted lists), or the pool capacity when k > HB_KL
+    int* state_cnt;     // pools only: fill count and threshold per (slot, query), kept between segments
+    float* state_thr;
 };
 
 __device__ __forceinline__ void glds16(const float* gsrc, char* lds_base) {
@@ -40,36 +44,85 @@ __device__ __forceinline__ void list_insert(float* lst_s, unsigned* lst_i, int q
     if (lane == p) { lst_s[ql * HB_KL + p] = s; lst_i[ql * HB_KL + p] = id; }
 }
 
-// Same insertion for lists that live in global memory (k > HB_KL): row stride KLW = k rounded up to 64,
-// each lane holds KLW/64 entries.  Only the owning wave ever touches a query's list; loads bypass the L1 and
-// the stores are drained before the next insertion reads the list again.
-__device__ __forceinline__ void list_insert_wide(float* gs, unsigned* gi, int k, int klw, float s, unsigned id, int lane) {
-    float es[4];
-    unsigned ei[4];
-    const int E = klw >> 6;
-    int p = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (e < E) {
-            const int j = e * 64 + lane;
-            es[e] = __hip_atomic_load(gs + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ei[e] = __hip_atomic_load(gi + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool better = j < k && ((es[e] > s) || (es[e] == s && ei[e] < id));
-            p += __popcll(__ballot(better));
-        }
-    }
-    if (p >= k) return;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (e < E) {
-            const int j = e * 64 + lane;
-            if (j >= p && j < k - 1) { gs[j + 1] = es[e]; gi[j + 1] = ei[e]; }
-        }
-    }
-    if (lane == 0) { gs[p] = s; gi[p] = id; }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+// ---- candidate pools (k > HB_KL, and the fp16 candidate pass) ------------------------------------------------
+// A query's running best-k does not fit the LDS lists, so it lives in global memory as an UNSORTED pool of
+// `cap` entries (cap >= 2k, multiple of 64): a score above the query's threshold is simply appended (one store per
+// lane, all 32 queries of a wave in parallel, the fill count in LDS).  When a pool is full the wave compacts it to
+// its best k by (score desc, id asc) -- a radix select over the wave, no sorting -- and raises the threshold to the
+// k-th score.  The threshold is therefore only as fresh as the last compaction: a few more scores pass than with
+// sorted lists, but an append costs one store instead of a serialised read-modify-write of the list.
+// Only the owning wave ever touches a pool; pool loads bypass the L1 and follow an s_waitcnt vmcnt(0).
+
+// monotone key: larger float <=> larger unsigned
+__device__ __forceinline__ unsigned pool_key(float s) {
+    const unsigned u = __builtin_bit_cast(unsigned, s + 0.0f);   // -0 and +0 share a key
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// kk-th largest (1-based) of the keys flagged active, E entries per lane; wave-uniform result
+template <int EMAX>
+__device__ __forceinline__ unsigned pool_kth(const unsigned (&key)[EMAX], bool (&act)[EMAX], int E, int kk) {
+    unsigned prefix = 0;
+    for (int b = 31; b >= 0; --b) {
+        const unsigned bit = 1u << b;
+        int c1 = 0;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e)
+            if (e < E) c1 += __popcll(__ballot(act[e] && (key[e] & bit)));
+        const bool take = c1 >= kk;
+        if (take) prefix |= bit; else kk -= c1;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e)
+            if (e < E) act[e] = act[e] && (((key[e] & bit) != 0) == take);
+    }
+    return prefix;
+}
+
+// Compact the full pool (cap entries) at (gs, gi) to its best k in entries [0, k); returns the k-th best score.
+__device__ __forceinline__ float pool_compact(float* gs, unsigned* gi, int cap, int k, int lane) {
+    constexpr int EMAX = HB_POOL_MAX / 64;
+    const int E = cap >> 6;
+    float es[EMAX];
+    unsigned ei[EMAX], key[EMAX];
+    bool act[EMAX];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's appends have landed
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        es[e] = 0.f; ei[e] = 0; key[e] = 0; act[e] = false;
+        if (e < E) {
+            es[e] = __hip_atomic_load(gs + e * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ei[e] = __hip_atomic_load(gi + e * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            key[e] = pool_key(es[e]);
+            act[e] = true;
+        }
+    }
+    const unsigned kt = pool_kth<EMAX>(key, act, E, k);   // key of the k-th best score
+    int above = 0, tied = 0;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e)
+        if (e < E) { above += __popcll(__ballot(key[e] > kt)); tied += __popcll(__ballot(key[e] == kt)); }
+    unsigned id_cut = 0xFFFFFFFFu;   // among the tied scores the lower ids stay
+    if (above + tied > k) {
+        unsigned ik[EMAX];
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) { ik[e] = ~ei[e]; act[e] = (e < E) && key[e] == kt; }
+        id_cut = ~pool_kth<EMAX>(ik, act, E, k - above);
+    }
+    float kth = 0.f;
+    int base = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e)
+        if (e < E) {
+            const bool keep = key[e] > kt || (key[e] == kt && ei[e] <= id_cut);
+            const unsigned long long m = __ballot(keep);
+            if (keep) { const int p = base + __popcll(m & lt); gs[p] = es[e]; gi[p] = ei[e]; }
+            base += __popcll(m);
+            const unsigned long long mk = __ballot(key[e] == kt);
+            if (mk) kth = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, es[e]), __builtin_ctzll(mk)));
+        }
+    return kth;
+}
 
 // dump the 4 registers of quarter Q (rows 8Q .. 8Q+7 of the 32-row tile) of accumulator tile T
 #define HB_DUMP_CASE(T, Q)                                                                  \
@@ -79,10 +132,12 @@ __device__ __forceinline__ void list_insert_wide(float* gs, unsigned* gi, int k,
 #define HB_DUMP_TILE(T) HB_DUMP_CASE(T, 0) HB_DUMP_CASE(T, 1) HB_DUMP_CASE(T, 2) HB_DUMP_CASE(T, 3)
 
 // Epilogue of one (query tile, bank tile) pair for one wave: filter the wave's 256 x 32 scores against the
-// per-query thresholds (phase 1, always) and insert the rare survivors into the lists (phase 2).
+// per-query thresholds (phase 1, always) and hand the rare survivors to the lists / pools (phase 2).
+// WIDE = false: lst_s / lst_i are the sorted LDS lists.  WIDE = true: they are the slot's pools in global memory
+// (row stride klw = capacity) and `cnt` holds the fill counts of the workgroup's 256 queries in LDS.
 template <bool SLOW = true, bool WIDE = false>
 __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, float* lst_s, unsigned* lst_i, float* sc,
-                                              int w, int lane, int k, unsigned bt, int klw = HB_KL) {
+                                              int w, int lane, int k, unsigned bt, int klw = HB_KL, int* cnt = nullptr) {
     unsigned qmask = 0;   // bit 4t+q: quarter q (8 bank rows) of row tile t holds a score above its query's threshold
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -104,26 +159,57 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, floa
         for (int hh = 0; hh < 2; ++hh)
             for (int j = 0; j < 4; ++j) {
                 const float v = sc[j * 64 + lane];
-                unsigned long long m = __ballot(v > thr);
-                m &= hh ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
-                while (m) {
-                    const int l = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-                    const int n = l & 31;
-                    float kth;
-                    if constexpr (WIDE) {
-                        float* gs = lst_s + (size_t)(w * 32 + n) * klw;
-                        list_insert_wide(gs, lst_i + (size_t)(w * 32 + n) * klw, k, klw, s, row_base + hh * 4 + j, lane);
-                        kth = __hip_atomic_load(gs + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else {
-                        list_insert(lst_s, lst_i, w * 32 + n, k, s, row_base + hh * 4 + j, lane);
-                        kth = lst_s[(w * 32 + n) * HB_KL + (k - 1)];
+                if constexpr (WIDE) {
+                    // every passing lane appends to its own query's pool (one query per lane within a half)
+                    const bool pass = ((lane >> 5) == hh) && (v > thr);
+                    if (__ballot(pass) == 0ull) continue;
+                    const int myq = w * 32 + (lane & 31);
+                    int c = 0;
+                    if (pass) {
+                        c = cnt[myq];
+                        lst_s[(size_t)myq * klw + c] = v;
+                        lst_i[(size_t)myq * klw + c] = row_base + hh * 4 + j;
+                        cnt[myq] = c + 1;
                     }
-                    if ((lane & 31) == n) thr = kth;
+                    unsigned long long full = __ballot(pass && c + 1 == klw);
+                    while (full) {
+                        const int n = __builtin_ctzll(full) & 31;
+                        full &= full - 1;
+                        const size_t off = (size_t)(w * 32 + n) * klw;
+                        const float kth = pool_compact(lst_s + off, lst_i + off, klw, k, lane);
+                        if (lane == 0) cnt[w * 32 + n] = k;
+                        if ((lane & 31) == n) thr = kth;
+                    }
+                } else {
+                    unsigned long long m = __ballot(v > thr);
+                    m &= hh ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
+                    while (m) {
+                        const int l = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+                        const int n = l & 31;
+                        list_insert(lst_s, lst_i, w * 32 + n, k, s, row_base + hh * 4 + j, lane);
+                        const float kth = lst_s[(w * 32 + n) * HB_KL + (k - 1)];
+                        if ((lane & 31) == n) thr = kth;
+                    }
                 }
             }
     }
+}
+
+// pools: fill counts / thresholds of the wave's 32 queries at the start and the end of a segment
+__device__ __forceinline__ float pool_begin(const knn_args_pool_view& pv, int slot, bool first, int* cnt, int myq, int lane) {
+    float thr = -INFINITY;
+    int c = 0;
+    if (!first) {
+        c = __hip_atomic_load(pv.cnt + (size_t)slot * HB_QT + myq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        thr = __hip_atomic_load(pv.thr + (size_t)slot * HB_QT + myq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane < 32) cnt[myq] = c;
+    return thr;
+}
+__device__ __forceinline__ void pool_end(const knn_args_pool_view& pv, int slot, const int* cnt, float thr, int myq, int lane) {
+    if (lane < 32) { pv.cnt[(size_t)slot * HB_QT + myq] = cnt[myq]; pv.thr[(size_t)slot * HB_QT + myq] = thr; }
 }
 
 // LDS map shared by the variants (bytes): a 4-slot ring of k8 stages, two row-init buffers, the lists, the scratch

@@ -21,7 +21,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define F16_SLOT_BYTES (2 * 8 * F16_GROUPS * 1024)     // 32 KiB bank + 32 KiB query fragments
 #define F16_BINIT (2 * F16_SLOT_BYTES)
 #define F16_SCRATCH (F16_BINIT + 2048)
-#define F16_LDS_TOTAL (F16_SCRATCH + 8192)
+#define F16_PCNT (F16_SCRATCH + 8192)                  // pool fill counts of the 256 queries
+#define F16_LDS_TOTAL (F16_PCNT + 1024)
 
 // fp32 fragment tiles -> fp16 fragment tiles.  fp16 block(rt, g16) = 32 rows x 16 k = 1 KiB, element (i, kk) at half
 // index ((kk >> 3) * 32 + i) * 8 + (kk & 7): lane l = h*32 + i reads 8 halves = k = 16 g16 + 8h + 0..7, the A/B
@@ -65,7 +66,9 @@ struct knn16_args {
     unsigned* state_i;
     int g16;   // Dp16 / 16
     int k;     // k' (candidates per query)
-    int klw;
+    int klw;   // pool capacity
+    int* state_cnt;
+    float* state_thr;
 };
 
 __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
@@ -75,6 +78,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
     float* sc = reinterpret_cast<float*>(smem + F16_SCRATCH) + w * 256;
+    int* pcnt = reinterpret_cast<int*>(smem + F16_PCNT);
     const int g16 = a.g16, k = a.k, klw = a.klw;
     const int NS = g16 / F16_GROUPS;   // stages per bank tile
     const int myq = w * 32 + (lane & 31);
@@ -84,10 +88,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
         const hb_seg seg = a.segs[si];
         float* wl_s = a.state_s + (size_t)seg.slot * HB_QT * klw;
         unsigned* wl_i = a.state_i + (size_t)seg.slot * HB_QT * klw;
-        if (seg.first)
-            for (int e = lane; e < 32 * klw; e += 64) { wl_s[(size_t)w * 32 * klw + e] = -INFINITY; wl_i[(size_t)w * 32 * klw + e] = HB_ID_NONE; }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        float thr = __hip_atomic_load(wl_s + (size_t)myq * klw + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float thr = pool_begin(knn_args_pool_view{a.state_cnt, a.state_thr}, seg.slot, seg.first, pcnt, myq, lane);
         const int total = seg.n_tiles * NS;
         f32x16 acc[8];
 
@@ -143,11 +144,12 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(t * F16_GROUPS + g) * 64], b, acc[t], 0, 0, 0);
             }
             if (++ks == NS) {
-                tile_epilogue<true, true>(acc, thr, wl_s, wl_i, sc, w, lane, k, (unsigned)bt, klw);
+                tile_epilogue<true, true>(acc, thr, wl_s, wl_i, sc, w, lane, k, (unsigned)bt, klw, pcnt);
                 ks = 0;
                 ++bt;
             }
         }
+        pool_end(knn_args_pool_view{a.state_cnt, a.state_thr}, seg.slot, pcnt, thr, myq, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }

@@ -16,7 +16,6 @@
         break;
 #define W4_DUMP_TILE(T) W4_DUMP_CASE(T, 0, 0) W4_DUMP_CASE(T, 0, 1) W4_DUMP_CASE(T, 1, 0) W4_DUMP_CASE(T, 1, 1)
 
-template <bool WIDE>
 __device__ __forceinline__ void w4_epilogue(f32x16 (&acc)[16], float (&thr)[2], float* lst_s, unsigned* lst_i, float* sc,
                                             int w, int lane, int k, unsigned bt, int klw) {
     // phase 1: which (row tile, query tile, half) has a score above its query's threshold
@@ -54,15 +53,8 @@ __device__ __forceinline__ void w4_epilogue(f32x16 (&acc)[16], float (&thr)[2], 
                         m &= m - 1;
                         const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
                         const int n = l & 31;
-                        float kth;
-                        if constexpr (WIDE) {
-                            float* gs = lst_s + (size_t)(qbase + n) * klw;
-                            list_insert_wide(gs, lst_i + (size_t)(qbase + n) * klw, k, klw, s, row_base + gg * 8 + hh * 4 + j, lane);
-                            kth = __hip_atomic_load(gs + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        } else {
-                            list_insert(lst_s, lst_i, qbase + n, k, s, row_base + gg * 8 + hh * 4 + j, lane);
-                            kth = lst_s[(qbase + n) * HB_KL + (k - 1)];
-                        }
+                        list_insert(lst_s, lst_i, qbase + n, k, s, row_base + gg * 8 + hh * 4 + j, lane);
+                        const float kth = lst_s[(qbase + n) * HB_KL + (k - 1)];
                         if ((lane & 31) == n) th = kth;
                     }
                 }
@@ -74,7 +66,6 @@ __device__ __forceinline__ void w4_epilogue(f32x16 (&acc)[16], float (&thr)[2], 
     acc[2 * (T) + (NB)] = __builtin_amdgcn_mfma_f32_32x32x2f32(FR[(T) & 3][S], FB[NB][S], acc[2 * (T) + (NB)], 0, 0, 0);
 #define W4_MFMA2(T, FR, FB, S) W4_MFMA(T, 0, FR, FB, S) W4_MFMA(T, 1, FR, FB, S)
 
-template <bool WIDE>
 __global__ __launch_bounds__(W4_THREADS) void knn_fused_w4_kernel(knn_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -92,13 +83,7 @@ __global__ __launch_bounds__(W4_THREADS) void knn_fused_w4_kernel(knn_args a) {
         float* wl_s = a.state_s + (size_t)seg.slot * HB_QT * klw;
         unsigned* wl_i = a.state_i + (size_t)seg.slot * HB_QT * klw;
         float thr[2];
-        if constexpr (WIDE) {
-            if (seg.first)
-                for (int e = lane; e < 64 * klw; e += 64) { wl_s[(size_t)w * 64 * klw + e] = -INFINITY; wl_i[(size_t)w * 64 * klw + e] = HB_ID_NONE; }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            thr[0] = __hip_atomic_load(wl_s + (size_t)(w * 64 + (lane & 31)) * klw + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            thr[1] = __hip_atomic_load(wl_s + (size_t)(w * 64 + 32 + (lane & 31)) * klw + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
+        {
 #pragma nounroll
             for (int e = lane; e < 2048; e += 64) {   // this wave's 64 queries x 32 entries
                 lst_s[w * 2048 + e] = seg.first ? -INFINITY : wl_s[w * 2048 + e];
@@ -205,10 +190,9 @@ __global__ __launch_bounds__(W4_THREADS) void knn_fused_w4_kernel(knn_args a) {
                 KN_FENCE
                 slot_c = slot_n;
             }
-            if constexpr (WIDE) w4_epilogue<true>(acc, thr, wl_s, wl_i, sc, w, lane, k, (unsigned)bt, klw);
-            else w4_epilogue<false>(acc, thr, lst_s, lst_i, sc, w, lane, k, (unsigned)bt, HB_KL);
+            w4_epilogue(acc, thr, lst_s, lst_i, sc, w, lane, k, (unsigned)bt, HB_KL);
         }
-        if constexpr (!WIDE) {
+        {
 #pragma nounroll
             for (int e = lane; e < 2048; e += 64) { wl_s[w * 2048 + e] = lst_s[w * 2048 + e]; wl_i[w * 2048 + e] = lst_i[w * 2048 + e]; }
         }
@@ -217,6 +201,7 @@ __global__ __launch_bounds__(W4_THREADS) void knn_fused_w4_kernel(knn_args a) {
     }
 }
 
-hb_knn_fn hb_knn_w4_kernel(bool wide) {
-    return wide ? (hb_knn_fn)knn_fused_w4_kernel<true> : (hb_knn_fn)knn_fused_w4_kernel<false>;
+hb_knn_fn hb_knn_w4_kernel(bool wide) {   // LDS-list path only (k <= HB_KL); the caller keeps k > HB_KL on the 8-wave kernel
+    (void)wide;
+    return (hb_knn_fn)knn_fused_w4_kernel;
 }

@@ -235,6 +235,29 @@ def test_wide_k_bit_exact(cuda_device, M, D, nq, k, metric):
     _check_exact(idx, dist, q, bank, k, metric)
 
 
+@pytest.mark.parametrize("k,metric,fp16", [(40, "dot_product", False), (100, "dot_product", False), (64, "l2", False),
+                                           (30, "dot_product", True)])
+def test_candidate_pool_exact_ties_across_compactions(cuda_device, k, metric, fp16):
+    """k > 32 keeps unsorted candidate pools that are compacted by a radix select whenever they fill up: hundreds of
+    bit-identical scores (duplicate rows, zero rows under L2: scores of -0/+0) must still leave by ascending id."""
+    M, D, nq = 9000, 32, 70
+    bank = gi.unit_bank(M, D, seed=21)
+    rng = np.random.default_rng(22)
+    dup = rng.choice(M, size=700, replace=False)
+    bank[dup[:400]] = bank[dup[0]]             # 400 copies of one row
+    bank[dup[400:]] = 0.0                      # 300 zero rows
+    q = gi.vit_like_queries(nq, D, seed=23)
+    q[:10] = 3.0 * bank[dup[0]]                # these queries' top-400 are all ties
+    q[10:14] = 0.0                             # every score is (+-)0 for IP
+    ix = HipFlatIndex(D, 0 if metric == "dot_product" else 1, 0)
+    ix.add(bank)
+    ix.set_fp16(fp16)
+    for G, panel in ((0, 0), (3, 2)):
+        ix.set_tuning(G, panel)
+        idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
+        _check_exact(idx, dist, q, bank, k, metric)
+
+
 def test_wide_k_aggregate(cuda_device):
     M, D, C, nq, k = 20000, 128, 19, 300, 90
     bank = gi.unit_bank(M, D, seed=1); lab = gi.labels_from_masks(M, C, 196, seed=2)
