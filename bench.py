@@ -97,6 +97,15 @@ def cpu_baseline(D, k, M_total):
     for i in range(0, nqs, 256):
         (qb[i:i + 256] @ bb.T).topk(k, dim=1)
     dt_t = time.time() - t1
+    # the reference-equivalent CPU stage after the search (hbird_eval.py:631-637, 575-609, 235-243), one 37 x 37 image
+    S, C = 37, 151
+    idx1 = rng.integers(0, ms, size=(S * S, k))
+    lab = rng.random((ms, C), dtype=np.float32)
+    t2 = time.time()
+    kf, kl = oracle.gather_neighbours(idx1, bank, lab, 1, S * S)
+    lh = oracle.cross_attention(q[:1].repeat(S * S, 0)[None], kf, kl)
+    oracle.upsample_argmax(lh, S, 14 * S, 14 * S)
+    dt_p = time.time() - t2
     return {
         "value": qps_sample * ms / M_total,
         "unit": "query-patches/s",
@@ -107,6 +116,8 @@ def cpu_baseline(D, k, M_total):
                   f"backend) is not installed on this image",
         "torch_mm_topk": {"value": nqs / dt_t * ms / M_total, "unit": "query-patches/s", "threads": _t.get_num_threads(),
                           "sample_seconds": round(dt_t, 2)},
+        "post_knn_stage": {"value": S * S / dt_p, "unit": "query-patches/s",
+                           "what": "gather + cross-attention + bilinear upsample + argmax of one 37x37-token image, C=151"},
     }
 
 

@@ -39,6 +39,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--patch-size", type=_positive_int, required=True)
     p.add_argument("--batch-size", type=_positive_int, default=64)
     p.add_argument("--input-size", type=_positive_int, default=224)
+    p.add_argument("--frame-size", type=_positive_int, nargs=2, default=None, metavar=("H", "W"),
+                   help="deliver H x W frames and process them through --input-size sliding windows (not in the reference)")
+    p.add_argument("--window-stride", type=_positive_int, default=None, help="stride of the sliding windows (default: input size)")
     p.add_argument("--augmentation-epoch", type=_positive_int, default=1)
     p.add_argument("--num-workers", type=int, default=8)
     p.add_argument("--device", type=str, default="cuda")
@@ -144,7 +147,9 @@ def main(argv: Optional[List[str]] = None) -> None:
                               n_neighbours=args.n_neighbours, nn_method=args.nn_method, nn_params=nn_params,
                               ftr_extr_fn=default_ftr_extr_fn, memory_size=args.memory_size,
                               num_workers=args.num_workers, ignore_index=args.ignore_index,
-                              train_fs_path=args.train_fs_path, val_fs_path=args.val_fs_path)
+                              train_fs_path=args.train_fs_path, val_fs_path=args.val_fs_path,
+                              frame_size=tuple(args.frame_size) if args.frame_size else None,
+                              window_stride=args.window_stride)
     summary = {"miou": float(result), "seconds": round(time.time() - t0, 3), "nn_method": args.nn_method,
                "dataset": args.dataset_name, "n_neighbours": args.n_neighbours}
     print(json.dumps(summary))

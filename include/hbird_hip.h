@@ -106,6 +106,14 @@ int hb_gather_rows(const float* src, int64_t src_rows, int width, const int64_t*
  * out[B, 1, h, w] int64. */
 int hb_upsample_argmax(const float* label_hat, int64_t B, int S, int C, int h, int w, int64_t* out,
                        void* hip_stream);
+/* Sliding-window frames (BASELINE cfg-5; the reference has no tiler): one window's label_hat[B, S*S, C] is upsampled
+ * like hbird_eval.py:240 (bilinear, align_corners=False) to win_h x win_w and added into acc[B, H, W, C] (fp32,
+ * channels last, zeroed by the caller) at (y0, x0).  Windows of one frame must be accumulated in a fixed order
+ * (fp32 sums).  hb_argmax_channels then gives the frame's class map: out[n] = argmax_c acc[n, c], first maximum
+ * wins (the argmax of hbird_eval.py:243). */
+int hb_upsample_accumulate(const float* label_hat, int64_t B, int S, int C, int win_h, int win_w, float* acc, int H,
+                           int W, int y0, int x0, void* hip_stream);
+int hb_argmax_channels(const float* acc, int64_t n, int C, int64_t* out, void* hip_stream);
 /* PredsmIoU.update, hbird/utils/eval_metrics.py:73-104; conf[num_gt, num_pred] uint64 accumulated. */
 int hb_confusion_update(const int64_t* gt, const int64_t* pred, int64_t n, int num_gt, int num_pred,
                         int64_t ignore_index, int has_ignore, uint64_t* conf, void* hip_stream);

@@ -364,6 +364,13 @@ extern "C" int hb_upsample_argmax(const float* label_hat, int64_t B, int S, int 
                                   void* stream) {
     return hb_launch_upsample_argmax(label_hat, B, S, C, h, w, out, (hipStream_t)stream);
 }
+extern "C" int hb_upsample_accumulate(const float* label_hat, int64_t B, int S, int C, int win_h, int win_w, float* acc,
+                                      int H, int W, int y0, int x0, void* stream) {
+    return hb_launch_upsample_accumulate(label_hat, B, S, C, win_h, win_w, acc, H, W, y0, x0, (hipStream_t)stream);
+}
+extern "C" int hb_argmax_channels(const float* acc, int64_t n, int C, int64_t* out, void* stream) {
+    return hb_launch_argmax_channels(acc, n, C, out, (hipStream_t)stream);
+}
 extern "C" int hb_confusion_update(const int64_t* gt, const int64_t* pred, int64_t n, int num_gt, int num_pred,
                                    int64_t ignore_index, int has_ignore, uint64_t* conf, void* stream) {
     return hb_launch_confusion(gt, pred, n, num_gt, num_pred, ignore_index, has_ignore, (unsigned long long*)conf,

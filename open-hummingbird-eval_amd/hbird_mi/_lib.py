@@ -45,6 +45,9 @@ SIGNATURES = {
                                 c_void_p]),
     "hb_gather_rows": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "hb_upsample_argmax": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "hb_upsample_accumulate": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                       c_void_p]),
+    "hb_argmax_channels": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "hb_confusion_update": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int, c_void_p, c_void_p]),
     "hb_index_set_timing": (c_int, [c_void_p, c_int]),
     "hb_index_last_knn_ms": (c_int, [c_void_p, POINTER(c_double)]),

@@ -28,10 +28,11 @@ DATASET_INFO = {
 }
 
 
-def get_dataset(dataset_name: str, data_dir: str, batch_size: int, num_workers: int, input_size: int,
+def get_dataset(dataset_name: str, data_dir: str, batch_size: int, num_workers: int, input_size,
                 train_fs_path: Optional[str] = None, val_fs_path: Optional[str] = None) -> Tuple[object, int]:
     """Returns (datamodule, ignore_index).  `name*0.2` keeps that fraction of the training set
-    (hbird/data/__init__.py:46-50)."""
+    (hbird/data/__init__.py:46-50).  `input_size` is the reference's square side, or an (H, W) frame size when the
+    caller evaluates through sliding windows (hbird_mi/tiling.py)."""
     frac = 1.0
     name = dataset_name
     if "*" in dataset_name:

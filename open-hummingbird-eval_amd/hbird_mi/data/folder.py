@@ -47,15 +47,20 @@ def _to_tensor_mask(mask: Image.Image) -> torch.Tensor:
     return torch.from_numpy(a.astype(np.float32) / np.float32(255.0)).unsqueeze(0)
 
 
+def _wh(size) -> Tuple[int, int]:
+    """PIL (width, height) of an int (square, as in the reference) or an (H, W) frame size (sliding windows)."""
+    return (size, size) if isinstance(size, int) else (int(size[1]), int(size[0]))
+
+
 class ValTransform:
     """Resize both to (S,S): bilinear for the image, nearest for the mask (transforms.py:215-236)."""
 
-    def __init__(self, size: int):
+    def __init__(self, size):
         self.size = size
 
     def __call__(self, img, mask):
-        img = img.resize((self.size, self.size), Image.BILINEAR)
-        mask = mask.resize((self.size, self.size), Image.NEAREST)
+        img = img.resize(_wh(self.size), Image.BILINEAR)
+        mask = mask.resize(_wh(self.size), Image.NEAREST)
         return _to_tensor_img(img), _to_tensor_mask(mask)
 
 
@@ -63,7 +68,7 @@ class TrainTransform:
     """Colour jitter on the image (each of brightness/contrast/saturation/hue with p = 0.5, range 0.1) then a
     shared RandomResizedCrop(size, scale=(0.5, 2.0), ratio=(3/4, 4/3)) (transforms.py:166-212)."""
 
-    def __init__(self, size: int, jitter: float = 0.1, p: float = 0.5, scale=(0.5, 2.0), ratio=(3 / 4, 4 / 3)):
+    def __init__(self, size, jitter: float = 0.1, p: float = 0.5, scale=(0.5, 2.0), ratio=(3 / 4, 4 / 3)):
         self.size, self.jitter, self.p, self.scale, self.ratio = size, jitter, p, scale, ratio
 
     def _jitter(self, img):
@@ -105,8 +110,8 @@ class TrainTransform:
     def __call__(self, img, mask):
         img = self._jitter(img)
         box = self._crop_box(*img.size)
-        img = img.crop(box).resize((self.size, self.size), Image.BILINEAR)
-        mask = mask.crop(box).resize((self.size, self.size), Image.NEAREST)
+        img = img.crop(box).resize(_wh(self.size), Image.BILINEAR)
+        mask = mask.crop(box).resize(_wh(self.size), Image.NEAREST)
         return _to_tensor_img(img), _to_tensor_mask(mask)
 
 

@@ -24,6 +24,7 @@ import torch
 
 from hbird_mi import dist as hdist
 from hbird_mi import ops
+from hbird_mi import tiling
 from hbird_mi.models import FeatureExtractor, FeatureExtractorSimple
 from hbird_mi.nn.search_hip import HipFlatIndex, MAX_K, merge_topk, _METRICS
 from hbird_mi.utils.eval_metrics import PredsmIoU
@@ -297,7 +298,12 @@ class HbirdEvaluation:
         return kf.view(B, N, k, -1), kl.view(B, N, k, -1)
 
     def evaluate(self, val_loader, eval_spatial_resolution: int, return_knn_details: bool = False,
-                 ignore_index: int = 255):
+                 ignore_index: int = 255, window: Optional[Tuple[int, int]] = None):
+        """Reference evaluate (hbird_eval.py:205-263).  `window=(win, stride)` (not in the reference): the loader
+        yields frames larger than the extractor's input; every win x win window goes through the hot path and the
+        windows' upsampled soft predictions are summed on the device before the argmax (hbird_mi/tiling.py)."""
+        if window is not None and return_knn_details:
+            raise ValueError("return_knn_details is not available with sliding windows")
         metric = PredsmIoU(self.num_classes, self.num_classes, ignore_index=ignore_index, device=self.gpu_device,
                            store_reordered_preds=False)
         self.feature_extractor = self.feature_extractor.to(self.device)
@@ -306,14 +312,18 @@ class HbirdEvaluation:
         logger.info("Starting evaluation loop...")
         with torch.no_grad():
             if self.sharded:
-                self._evaluate_sharded(val_loader, S, metric, return_knn_details, knns, knns_labels, knns_ca_labels)
+                self._evaluate_sharded(val_loader, S, metric, return_knn_details, knns, knns_labels, knns_ca_labels,
+                                       window)
             else:
                 for bi, (x, y) in enumerate(tqdm(val_loader, desc="Evaluation loop")):
                     if self.world > 1 and bi % self.world != self.rank:
                         continue      # replica mode (idx_shard=False): validation batches are data-parallel
                     _, _, h, w = x.shape
-                    feats = self._tokens(x)                                       # 217 (stays on the GPU)
                     y = (y.to(self.gpu_device) * 255).long()                       # 219 (255 is NOT remapped here)
+                    if window is not None:
+                        metric.update(y, self._windowed_cluster_map(x, S, window))
+                        continue
+                    feats = self._tokens(x)                                       # 217 (stays on the GPU)
                     label_hat, idx, _ = self._label_hat(feats, return_knn_details)  # 224-227
                     if return_knn_details:
                         kf, kl = self._gather_details(idx, feats.shape[0], feats.shape[1])
@@ -330,9 +340,21 @@ class HbirdEvaluation:
         logger.info("Evaluation complete.")
         return jac
 
-    def _evaluate_sharded(self, val_loader, S, metric, want_details, knns, knns_labels, knns_ca_labels):
+    def _windowed_cluster_map(self, x: torch.Tensor, S: int, window: Tuple[int, int]) -> torch.Tensor:
+        """Frames x [B,3,H,W] -> class map [B,1,H,W]: hot path per window, stitched on the device."""
+        win, stride = window
+        B, _, h, w = x.shape
+        acc = torch.zeros((B, h, w, self.num_classes), dtype=torch.float32, device=self.gpu_device)
+        for y0, x0 in tiling.window_origins(h, w, win, stride):
+            feats = self._tokens(x[..., y0:y0 + win, x0:x0 + win])
+            label_hat, _, _ = self._label_hat(feats, False)
+            ops.upsample_accumulate(label_hat, S, acc, y0, x0, win, win)
+        return ops.argmax_channels(acc)
+
+    def _evaluate_sharded(self, val_loader, S, metric, want_details, knns, knns_labels, knns_ca_labels, window=None):
         """Validation batches are dealt round-robin; all ranks step together so that every search sees all
-        shards.  A rank that has run out of batches contributes zero queries."""
+        shards.  A rank that has run out of batches contributes zero queries.  With sliding windows the ranks also
+        step window by window (all frames of a step must have the same size)."""
         it = iter(val_loader)
         n_batches = len(val_loader)
         D = self.index.d
@@ -340,49 +362,64 @@ class HbirdEvaluation:
         k = self.n_neighbours
         bi = 0
         for _ in range(steps):
-            mine = None
+            mine, last = None, None
             for r in range(self.world):
                 if bi < n_batches:
-                    batch = next(it)
+                    last = next(it)
                     if r == self.rank:
-                        mine = batch
+                        mine = last
                     bi += 1
-            if mine is not None:
-                x, y = mine
-                h, w = x.shape[-2:]
-                feats = self._tokens(x)
-                B, N, _ = feats.shape
-                q = feats.reshape(B * N, D)
-            else:
-                q = torch.zeros((0, D), dtype=torch.float32, device=self.gpu_device)
-            qall, nq = hdist.allgather_rows(q)      # ragged query batches, zero-padded to the largest
-            mx = qall.shape[1]
-            if mx == 0:
-                continue
-            idx, dist = self.find_neighbours(qall.view(self.world * mx, D), k)   # collective inside
-            kf_all = None
-            if want_details:
-                # neighbour features live on their owning shard: every rank fills in its own rows, the
-                # all-reduce (sum with zeros) completes them -- a collective, so all ranks take part
-                flat = idx.reshape(-1)
-                own = (flat >= self.id_base) & (flat < self.id_base + self.index.ntotal)
-                kf_all = self.index.reconstruct(torch.where(own, flat, torch.full_like(flat, -1)),
-                                                id_base=self.id_base)
-                torch.distributed.all_reduce(kf_all)
-                kf_all = kf_all.view(self.world * mx, k, D)
+            fh, fw = last[0].shape[-2:]
+            origins = [(0, 0)] if window is None else tiling.window_origins(fh, fw, window[0], window[1])
+            acc, cluster_map = None, None
+            for y0, x0 in origins:
+                if mine is not None:
+                    x, y = mine
+                    if window is not None:
+                        x = x[..., y0:y0 + window[0], x0:x0 + window[0]]
+                    h, w = x.shape[-2:]
+                    feats = self._tokens(x)
+                    B, N, _ = feats.shape
+                    q = feats.reshape(B * N, D)
+                else:
+                    q = torch.zeros((0, D), dtype=torch.float32, device=self.gpu_device)
+                qall, nq = hdist.allgather_rows(q)      # ragged query batches, zero-padded to the largest
+                mx = qall.shape[1]
+                if mx == 0:
+                    continue
+                idx, dist = self.find_neighbours(qall.view(self.world * mx, D), k)   # collective inside
+                kf_all = None
+                if want_details:
+                    # neighbour features live on their owning shard: every rank fills in its own rows, the
+                    # all-reduce (sum with zeros) completes them -- a collective, so all ranks take part
+                    flat = idx.reshape(-1)
+                    own = (flat >= self.id_base) & (flat < self.id_base + self.index.ntotal)
+                    kf_all = self.index.reconstruct(torch.where(own, flat, torch.full_like(flat, -1)),
+                                                    id_base=self.id_base)
+                    torch.distributed.all_reduce(kf_all)
+                    kf_all = kf_all.view(self.world * mx, k, D)
+                if mine is None:
+                    continue
+                lo = self.rank * mx
+                my_idx, my_dist = idx[lo:lo + q.shape[0]].contiguous(), dist[lo:lo + q.shape[0]].contiguous()
+                self.index.use_current_stream()
+                label_hat = self.index.aggregate(q.contiguous(), my_idx, my_dist, beta=0.02).view(B, N, -1)
+                if want_details:
+                    kl = ops.gather_rows(self._label_table[0], my_idx.reshape(-1)).view(B, N, k, -1)
+                    knns.append(kf_all[lo:lo + q.shape[0]].reshape(B, N, k, D).cpu())
+                    knns_labels.append(kl.cpu())
+                    knns_ca_labels.append(label_hat.cpu())
+                if window is None:
+                    cluster_map = ops.upsample_argmax(label_hat, S, h, w)
+                else:
+                    if acc is None:
+                        acc = torch.zeros((B, fh, fw, self.num_classes), dtype=torch.float32, device=self.gpu_device)
+                    ops.upsample_accumulate(label_hat, S, acc, y0, x0, h, w)
             if mine is None:
                 continue
-            lo = self.rank * mx
-            my_idx, my_dist = idx[lo:lo + q.shape[0]].contiguous(), dist[lo:lo + q.shape[0]].contiguous()
-            self.index.use_current_stream()
-            label_hat = self.index.aggregate(q.contiguous(), my_idx, my_dist, beta=0.02).view(B, N, -1)
-            if want_details:
-                kl = ops.gather_rows(self._label_table[0], my_idx.reshape(-1)).view(B, N, k, -1)
-                knns.append(kf_all[lo:lo + q.shape[0]].reshape(B, N, k, D).cpu())
-                knns_labels.append(kl.cpu())
-                knns_ca_labels.append(label_hat.cpu())
-            y = (y.to(self.gpu_device) * 255).long()
-            metric.update(y, ops.upsample_argmax(label_hat, S, h, w))
+            if window is not None:
+                cluster_map = ops.argmax_channels(acc)
+            metric.update((mine[1].to(self.gpu_device) * 255).long(), cluster_map)
         if want_details and not knns:
             z = torch.zeros(0)
             knns.append(z); knns_labels.append(z); knns_ca_labels.append(z)
@@ -393,8 +430,13 @@ def hbird_evaluation(model, d_model: int, patch_size: int, dataset_name: str, da
                      return_knn_details: bool = False, n_neighbours: int = 30, nn_method: str = "scann",
                      nn_params: Optional[Dict[str, Any]] = None, ftr_extr_fn=None,
                      memory_size: Optional[int] = None, num_workers: int = 8, ignore_index: int = 255,
-                     train_fs_path: Optional[str] = None, val_fs_path: Optional[str] = None):
-    """High-level entry point with the reference's signature (hbird_eval.py:640-660)."""
+                     train_fs_path: Optional[str] = None, val_fs_path: Optional[str] = None,
+                     frame_size: Optional[Tuple[int, int]] = None, window_stride: Optional[int] = None):
+    """High-level entry point with the reference's signature (hbird_eval.py:640-660).
+
+    Two trailing keywords are not in the reference: `frame_size=(H, W)` makes the datasets deliver H x W frames that
+    are processed through `input_size` windows with stride `window_stride` (default: input_size, i.e. no overlap) --
+    bank build from the window crops, evaluation stitched over the windows (BASELINE cfg-5, hbird_mi/tiling.py)."""
     if nn_params is None:
         nn_params = {}
     eval_spatial_resolution = input_size // patch_size                                   # 671
@@ -404,15 +446,26 @@ def hbird_evaluation(model, d_model: int, patch_size: int, dataset_name: str, da
         feature_extractor = FeatureExtractorSimple(model, ftr_extr_fn=ftr_extr_fn,
                                                    eval_spatial_resolution=eval_spatial_resolution, d_model=d_model)
     from hbird_mi.data import get_dataset
-    dataset, ignore_index_local = get_dataset(dataset_name, data_dir, batch_size, num_workers, input_size,
-                                              train_fs_path, val_fs_path)
+    window = None
+    if frame_size is not None:
+        fh, fw = int(frame_size[0]), int(frame_size[1])
+        window = (input_size, int(window_stride) if window_stride else input_size)
+        if fh < input_size or fw < input_size:
+            raise ValueError(f"frame_size {frame_size} smaller than the {input_size} x {input_size} window")
+    elif window_stride is not None:
+        raise ValueError("window_stride needs frame_size")
+    dataset, ignore_index_local = get_dataset(dataset_name, data_dir, batch_size, num_workers,
+                                              input_size if window is None else (fh, fw), train_fs_path, val_fs_path)
     dataset_size = dataset.get_train_dataset_size()
     num_classes = dataset.get_num_classes()
     train_loader = dataset.train_dataloader()
     val_loader = dataset.val_dataloader()
+    if window is not None:
+        train_loader = tiling.WindowedLoader(train_loader, window[0], window[1], frame_hw=(fh, fw))
+        dataset_size *= train_loader.windows_per_frame()       # every window is a bank image
     evaluator = HbirdEvaluation(feature_extractor, train_loader, num_classes=num_classes, n_neighbours=n_neighbours,
                                 augmentation_epoch=augmentation_epoch, device=device, nn_method=nn_method,
                                 nn_params=nn_params, memory_size=memory_size, dataset_size=dataset_size)
     effective_ignore = ignore_index if ignore_index != 255 else ignore_index_local        # 715
     return evaluator.evaluate(val_loader, eval_spatial_resolution=eval_spatial_resolution,
-                              return_knn_details=return_knn_details, ignore_index=effective_ignore)
+                              return_knn_details=return_knn_details, ignore_index=effective_ignore, window=window)

@@ -97,6 +97,32 @@ def upsample_argmax(label_hat: torch.Tensor, S: int, h: int, w: int) -> torch.Te
     return out
 
 
+def upsample_accumulate(label_hat: torch.Tensor, S: int, acc: torch.Tensor, y0: int, x0: int, win_h: int,
+                        win_w: int) -> None:
+    """Sliding windows: acc[B,H,W,C] (fp32, channels last) += bilinear upsample of one window's label_hat
+    [B, S*S, C] to win_h x win_w, placed at (y0, x0) (the per-image upsample of hbird_eval.py:235-240)."""
+    _need_cuda(label_hat)
+    _need_cuda(acc)
+    label_hat = label_hat.contiguous().float()
+    B, N, C = label_hat.shape
+    if N != S * S:
+        raise ValueError(f"label_hat has {N} patches, expected {S}x{S}")
+    if acc.dtype != torch.float32 or not acc.is_contiguous() or acc.dim() != 4 or acc.shape[0] != B or acc.shape[3] != C:
+        raise ValueError("acc must be a contiguous float32 [B, H, W, C] tensor matching label_hat")
+    _lib.check(_lib.lib().hb_upsample_accumulate(_p(label_hat), B, int(S), C, int(win_h), int(win_w), _p(acc),
+                                                 acc.shape[1], acc.shape[2], int(y0), int(x0), _stream(label_hat)))
+
+
+def argmax_channels(acc: torch.Tensor) -> torch.Tensor:
+    """acc [B,H,W,C] float32 -> [B,1,H,W] int64 class map (first maximum wins, hbird_eval.py:243)."""
+    _need_cuda(acc)
+    acc = acc.contiguous().float()
+    B, H, W, C = acc.shape
+    out = torch.empty((B, 1, H, W), dtype=torch.int64, device=acc.device)
+    _lib.check(_lib.lib().hb_argmax_channels(_p(acc), B * H * W, C, _p(out), _stream(acc)))
+    return out
+
+
 def confusion_update(conf: torch.Tensor, gt: torch.Tensor, pred: torch.Tensor, ignore_index) -> None:
     """conf [G,P] int64 (CUDA) += confusion counts (reference eval_metrics.py:73-104)."""
     _need_cuda(conf, gt, pred)

@@ -25,7 +25,7 @@ __all__ = [
     "build", "lib", "knn_chain_f32", "knn_f64", "chain_sqnorm", "normalize_rows",
     "patchify_gt", "patch_label_hist", "cross_attention", "sample_patches", "sample_num_nonempty",
     "upsample_bilinear", "upsample_argmax", "confusion_matrix", "PredsMIoUOracle", "num_threads",
-    "gather_neighbours", "near_tie_report",
+    "gather_neighbours", "near_tie_report", "window_origins", "sliding_window_argmax",
 ]
 
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -243,6 +243,28 @@ def upsample_argmax(label_hat: np.ndarray, S: int, h: int, w: int) -> np.ndarray
     x = label_hat.reshape(B, S, S, C).transpose(0, 3, 1, 2)
     up = upsample_bilinear(x, h, w)
     return up.argmax(axis=1)[:, None].astype(np.int64)
+
+
+def window_origins(H: int, W: int, win: int, stride: int):
+    """Row-major window origins, last row / column flush with the border (sliding-window frames, cfg-5)."""
+    def axis(n):
+        o = list(range(0, n - win + 1, stride))
+        if o[-1] != n - win:
+            o.append(n - win)
+        return o
+    return [(y, x) for y in axis(H) for x in axis(W)]
+
+
+def sliding_window_argmax(label_hats, origins, S: int, win: int, H: int, W: int):
+    """Stitch the windows of a frame: every window's label_hat [B, S*S, C] is upsampled as hbird_eval.py:235-240
+    does per image, summed (fp32, in the given order) into the frame, then argmax.  Returns (cluster_map
+    [B,1,H,W] int64, acc [B,C,H,W] fp32)."""
+    B, _, C = label_hats[0].shape
+    acc = np.zeros((B, C, H, W), dtype=np.float32)
+    for lh, (y0, x0) in zip(label_hats, origins):
+        x = _f32(lh).reshape(B, S, S, C).transpose(0, 3, 1, 2)
+        acc[:, :, y0:y0 + win, x0:x0 + win] += upsample_bilinear(x, win, win)
+    return acc.argmax(axis=1)[:, None].astype(np.int64), acc
 
 
 def confusion_matrix(gt: np.ndarray, pred: np.ndarray, num_gt: int, num_pred: int,

@@ -59,3 +59,48 @@ def test_two_rank_sharded_evaluation(cuda_device, golden_dir, name):
     mp.spawn(_worker, args=(world, port, golden_dir, name, ret), nprocs=world, join=True)
     assert ret[0][0] and ret[1][0], dict(ret)
     assert ret[0][1] == ret[1][1]          # every rank reports the same (all-reduced) mIoU
+
+
+def _window_worker(rank, world, port, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "open-hummingbird-eval_amd"), os.path.join(root, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as td
+    if world > 1:
+        td.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from hbird_mi import tiling
+    from hbird_mi.data.synthetic import SyntheticSegDataModule
+    from hbird_mi.hbird_eval import HbirdEvaluation
+    from hbird_mi.models import FeatureExtractorSimple
+    torch.manual_seed(2)
+    D, ps, win, stride, C = 48, 8, 64, 32, 6
+    conv = torch.nn.Conv2d(3, D, ps, ps).eval()
+
+    def fn(model, imgs):
+        with torch.no_grad():
+            return model(imgs).flatten(2).transpose(1, 2).float().contiguous(), None
+
+    dm = SyntheticSegDataModule(batch_size=2, input_size=(64, 128), num_classes=C, n_train=8, n_val=6, seed=9)   # 3 val batches
+    ext = FeatureExtractorSimple(conv, fn, eval_spatial_resolution=win // ps, d_model=D)
+    train = tiling.WindowedLoader(dm.train_dataloader(), win, stride, frame_hw=(64, 128))
+    ev = HbirdEvaluation(ext, train, num_classes=C, n_neighbours=20, device="cuda:0", nn_method="hip",
+                         nn_params={"idx_shard": True})
+    jac = ev.evaluate(dm.val_dataloader(), win // ps, ignore_index=255, window=(win, stride))
+    ret[(world, rank)] = (bool(ev.sharded), int(ev.total_rows), float(jac))
+    if world > 1:
+        td.destroy_process_group()
+
+
+def test_two_rank_sliding_window_evaluation_equals_single_process(cuda_device):
+    """Sliding windows under a row-sharded bank: ranks step window by window (3 val batches over 2 ranks: the last
+    step has an idle rank); the all-reduced mIoU equals the single-process one."""
+    ret = mp.Manager().dict()
+    mp.spawn(_window_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+    mp.spawn(_window_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    single = ret[(1, 0)]
+    assert not single[0] and ret[(2, 0)][0] and ret[(2, 1)][0]
+    assert ret[(2, 0)][1] == ret[(2, 1)][1] == single[1]
+    assert ret[(2, 0)][2] == ret[(2, 1)][2]
+    assert abs(ret[(2, 0)][2] - single[2]) < 1e-6, dict(ret)

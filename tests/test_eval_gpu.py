@@ -176,3 +176,86 @@ def test_evaluate_with_use_fp16_equals_fp32(cuda_device, golden_dir):
     assert outs[0][0] == outs[1][0]
     assert torch.equal(outs[0][1]["knns_ca_labels"], outs[1][1]["knns_ca_labels"])
     assert torch.equal(outs[0][1]["knns_labels"], outs[1][1]["knns_labels"])
+
+
+def test_sliding_window_evaluation_vs_oracle(cuda_device):
+    """BASELINE cfg-5 geometry in small: frames larger than the extractor's input are processed through overlapping
+    windows -- bank from the window crops, evaluation stitched on the device; the oracle replays everything."""
+    from hbird_mi import tiling
+    from hbird_mi.data.synthetic import SyntheticSegDataModule
+    from hbird_mi.models import FeatureExtractorSimple
+    torch.manual_seed(1)
+    D, ps, win, stride, C, k, B = 64, 8, 64, 40, 7, 40, 3
+    fh, fw = 96, 160
+    S = win // ps
+
+    class Conv(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = torch.nn.Conv2d(3, D, ps, ps)
+
+    tokens = []
+
+    def fn(model, imgs):
+        assert imgs.shape[-2:] == (win, win)
+        with torch.no_grad():
+            t = model.c(imgs).flatten(2).transpose(1, 2).float().contiguous()
+        tokens.append(t.cpu().numpy())
+        return t, None
+
+    dm = SyntheticSegDataModule(batch_size=B, input_size=(fh, fw), num_classes=C, n_train=6, n_val=5, seed=5)
+    ext = FeatureExtractorSimple(Conv().eval(), fn, eval_spatial_resolution=S, d_model=D)
+    origins = tiling.window_origins(fh, fw, win, stride)
+    train = tiling.WindowedLoader(dm.train_dataloader(), win, stride, frame_hw=(fh, fw))
+    ev = HbirdEvaluation(ext, train, num_classes=C, n_neighbours=k, device="cuda", nn_method="hip")
+    assert ev.index.ntotal == 6 * len(origins) * S * S
+    n_train = len(tokens)
+    assert n_train == len(train)
+    jac = ev.evaluate(dm.val_dataloader(), S, ignore_index=255, window=(win, stride))
+    fm, lm = ev.feature_memory.numpy(), ev.label_memory.numpy()
+    m = oracle.PredsMIoUOracle(C, C, 255)
+    ti = n_train
+    for x, y in dm.val_dataloader():
+        lhs = []
+        for _ in origins:
+            tok = tokens[ti]; ti += 1
+            idx, _ = oracle.knn_chain_f32(tok.reshape(-1, D), fm, k)
+            kf, kl = oracle.gather_neighbours(idx, fm, lm, tok.shape[0], S * S)
+            lhs.append(oracle.cross_attention(tok, kf, kl))
+        cm, _ = oracle.sliding_window_argmax(lhs, origins, S, win, fh, fw)
+        m.update(np.rint(y.numpy() * 255).astype(np.int64), cm)
+    assert ti == len(tokens)
+    assert abs(jac - m.compute()[0]) < 1e-4, (jac, m.compute()[0])
+    with pytest.raises(ValueError):
+        ev.evaluate(dm.val_dataloader(), S, return_knn_details=True, window=(win, stride))
+
+
+def test_one_window_per_frame_equals_the_plain_path(cuda_device, golden_dir):
+    g = np.load(f"{golden_dir}/g67_memory_evaluate.npz")
+    c = golden_case(g, "unb")
+    ext = ReplayExtractor(c["tr_tok"] + c["va_tok"] + c["va_tok"], c["S"], c["D"])
+    ev = HbirdEvaluation(ext, c["train"], num_classes=c["C"], n_neighbours=c["k"], device="cuda", nn_method="hip")
+    plain = ev.evaluate(c["val"], c["S"], ignore_index=c["ign"])
+    windowed = ev.evaluate(c["val"], c["S"], ignore_index=c["ign"], window=(c["H"], c["H"]))
+    assert plain == windowed
+
+
+def test_hbird_evaluation_entry_point_with_frames(cuda_device):
+    from hbird_mi.hbird_eval import hbird_evaluation
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = torch.nn.Conv2d(3, 32, 8, 8)
+
+    def fn(model, imgs):
+        return model.c(imgs).flatten(2).transpose(1, 2), None
+
+    torch.manual_seed(0)
+    miou = hbird_evaluation(Net().cuda().eval(), d_model=32, patch_size=8, dataset_name="synthetic", data_dir="", batch_size=4,
+                            input_size=64, device="cuda", n_neighbours=10, nn_method="hip", ftr_extr_fn=fn,
+                            frame_size=(64, 128), window_stride=32)
+    assert 0.3 < miou <= 1.0
+    with pytest.raises(ValueError):
+        hbird_evaluation(Net(), d_model=32, patch_size=8, dataset_name="synthetic", data_dir="", input_size=64, device="cuda",
+                         nn_method="hip", ftr_extr_fn=fn, window_stride=32)

@@ -176,3 +176,33 @@ def test_k7_large_class_count_global_path(cuda_device):
     conf = torch.zeros((C, C), dtype=torch.int64, device="cuda")
     ops.confusion_update(conf, torch.from_numpy(gt).cuda(), torch.from_numpy(pred).cuda(), None)
     assert np.array_equal(conf.cpu().numpy(), oracle.confusion_matrix(gt, pred, C, C, None))
+
+
+@pytest.mark.parametrize("S,C,win,H,W,stride", [(4, 5, 32, 48, 80, 24), (16, 21, 224, 224, 320, 96), (37, 19, 518, 600, 900, 300)])
+def test_sliding_window_accumulate_and_argmax_bit_exact(cuda_device, S, C, win, H, W, stride):
+    """hb_upsample_accumulate + hb_argmax_channels against the oracle's stitching: same fp32 sums, same class map."""
+    rng = np.random.default_rng(S + C)
+    B = 2
+    origins = oracle.window_origins(H, W, win, stride)
+    lhs = [rng.random((B, S * S, C), dtype=np.float32) for _ in origins]
+    acc = torch.zeros((B, H, W, C), device="cuda")
+    for lh, (y0, x0) in zip(lhs, origins):
+        ops.upsample_accumulate(torch.from_numpy(lh).cuda(), S, acc, y0, x0, win, win)
+    cm = ops.argmax_channels(acc)
+    rcm, racc = oracle.sliding_window_argmax(lhs, origins, S, win, H, W)
+    got = acc.permute(0, 3, 1, 2).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), racc.view(np.uint32))
+    assert np.array_equal(cm.cpu().numpy(), rcm)
+
+
+def test_sliding_window_ops_errors(cuda_device):
+    acc = torch.zeros((1, 16, 16, 3), device="cuda")
+    lh = torch.rand((1, 16, 3), device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.upsample_accumulate(lh, 4, acc, 8, 0, 16, 16)        # window sticks out of the frame
+    with pytest.raises(ValueError):
+        ops.upsample_accumulate(lh, 5, acc, 0, 0, 16, 16)        # 16 tokens are not 5 x 5
+    with pytest.raises(ValueError):
+        ops.upsample_accumulate(lh, 4, acc[..., :2], 0, 0, 16, 16)
+    ties = torch.zeros((1, 2, 2, 4), device="cuda")
+    assert int(ops.argmax_channels(ties).sum()) == 0             # first maximum wins
