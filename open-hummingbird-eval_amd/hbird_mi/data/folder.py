@@ -2,7 +2,8 @@
 (counterparts of hbird/data/{voc,ade20k,cityscapes}/*_data.py and hbird/utils/{transforms,
 image_transformations}.py; host-side I/O, "next" row f3 of SURVEY.md section 8).
 
-Directory conventions follow the reference (DATASET.md):
+The dataset root may be a directory or a .tar archive (`/data/voc.tar`, `/data/all.tar!/VOC`, as the reference's
+hbird/utils/io.py and voc_tar_data.py accept).  Directory conventions follow the reference (DATASET.md):
   voc         <root>/images/*.jpg, <root>/SegmentationClassAug/*.png (train), <root>/SegmentationClass/*.png (val),
               <root>/sets/{trainaug,val}.txt                                   (voc_data.py:137-160)
   ade20k      <root>/images/{training,validation}/*.jpg, <root>/annotations/{training,validation}/*.png
@@ -29,7 +30,94 @@ IMAGENET_MEAN = [0.485, 0.456, 0.406]
 IMAGENET_STD = [0.229, 0.224, 0.255]      # sic: the reference's value (hbird/utils/transforms.py:29)
 
 
+class DiskStore:
+    """A dataset root on disk; paths are relative to it."""
+
+    def __init__(self, root: str):
+        self.root = root
+
+    def isdir(self, rel: str) -> bool:
+        return os.path.isdir(os.path.join(self.root, rel))
+
+    def listdir(self, rel: str) -> List[str]:
+        return sorted(os.listdir(os.path.join(self.root, rel)))
+
+    def open(self, rel: str):
+        return open(os.path.join(self.root, rel), "rb")
+
+
+class TarStore:
+    """A dataset root inside a .tar archive: `/data/voc.tar` or `/data/all.tar!/VOC/` (the notation of the
+    reference's hbird/utils/io.py:10-15 and voc_tar_data.py).  The member table is read once; the archive itself
+    is opened lazily per process, because a TarFile handle must not be shared with DataLoader workers
+    (voc_tar_data.py:228-231)."""
+
+    def __init__(self, path: str):
+        tar_path, _, inner = path.partition(".tar")
+        for ext in (".gz", ".bz2", ".xz"):
+            if inner.startswith(ext):
+                tar_path, inner = tar_path + ".tar" + ext, inner[len(ext):]
+                break
+        else:
+            tar_path += ".tar"
+        if not os.path.isfile(tar_path):
+            raise FileNotFoundError(f"Tar archive not found: {tar_path}")                # io.py:34-35
+        self.tar_path = tar_path
+        self.prefix = inner.lstrip("!").strip("/")
+        self._tar, self._pid = None, None
+        self.files, self.dirs = {}, {""}
+        import tarfile
+        with tarfile.open(tar_path, "r:*") as t:
+            for m in t.getmembers():
+                name = os.path.normpath(m.name).lstrip("./")
+                if self.prefix:
+                    if not name.startswith(self.prefix + "/"):
+                        continue
+                    name = name[len(self.prefix) + 1:]
+                if m.isfile():
+                    self.files[name] = m
+                    d = os.path.dirname(name)
+                    while d and d not in self.dirs:
+                        self.dirs.add(d)
+                        d = os.path.dirname(d)
+                elif m.isdir():
+                    self.dirs.add(name.rstrip("/"))
+
+    def isdir(self, rel: str) -> bool:
+        return rel.strip("/") in self.dirs
+
+    def listdir(self, rel: str) -> List[str]:
+        rel = rel.strip("/")
+        pre = rel + "/" if rel else ""
+        names = {n[len(pre):].split("/", 1)[0] for n in list(self.files) + list(self.dirs) if n.startswith(pre) and n != rel}
+        return sorted(n for n in names if n)
+
+    def open(self, rel: str):
+        import io
+        import tarfile
+        if self._tar is None or self._pid != os.getpid():
+            self._tar, self._pid = tarfile.open(self.tar_path, "r:*"), os.getpid()
+        if rel not in self.files:
+            raise FileNotFoundError(f"File '{rel}' not found inside {self.tar_path}")     # io.py:91
+        return io.BytesIO(self._tar.extractfile(self.files[rel]).read())
+
+    def __getstate__(self):           # DataLoader workers (spawn) get a copy without the open handle
+        d = dict(self.__dict__)
+        d["_tar"], d["_pid"] = None, None
+        return d
+
+
+def open_store(root: str):
+    return TarStore(root) if ".tar" in root else DiskStore(root)
+
+
 def read_file_set(path: str) -> List[str]:
+    """Lines of a split file, on disk or inside an archive (`/x/a.tar!/sets/val.txt`, io.py:60-103)."""
+    if ".tar" in path:
+        head, _, inner = path.partition("!")
+        if inner:
+            with TarStore(head).open(inner.strip("/")) as f:
+                return [ln.strip() for ln in f.read().decode().splitlines() if ln.strip()]
     with open(path) as f:
         return [ln.strip() for ln in f if ln.strip()]
 
@@ -123,37 +211,40 @@ _CITY_KEY = np.array([255, 255, 255, 255, 255, 255, 255, 255, 0, 1, 255, 255, 2,
 class SegFolder(Dataset):
     def __init__(self, name: str, root: str, split: str, transform, file_set: Optional[List[str]] = None):
         self.name, self.root, self.split, self.transform = name, root, split, transform
+        self.store = open_store(root)
         self.pairs = self._collect(file_set)
         if not self.pairs:
             raise RuntimeError(f"Dataset not found or corrupted: no {name}/{split} samples under {root}")
 
+    def _read_lines(self, rel: str) -> List[str]:
+        with self.store.open(rel) as f:
+            return [ln.strip() for ln in f.read().decode().splitlines() if ln.strip()]
+
     def _collect(self, fs) -> List[Tuple[str, str]]:
-        r = self.root
+        st = self.store
         if self.name == "voc":
             seg = "SegmentationClassAug" if self.split == "train" else "SegmentationClass"
-            img_dir, seg_dir = os.path.join(r, "images"), os.path.join(r, seg)
-            if not (os.path.isdir(img_dir) and os.path.isdir(seg_dir)):
+            if not (st.isdir("images") and st.isdir(seg)):
                 raise RuntimeError("Dataset not found or corrupted.")                 # voc_data.py:146-147
             if fs is None:
-                fs = read_file_set(os.path.join(r, "sets", "trainaug.txt" if self.split == "train" else "val.txt"))
-            return [(os.path.join(img_dir, f"{f}.jpg"), os.path.join(seg_dir, f"{f}.png")) for f in sorted(fs)]
+                fs = self._read_lines("sets/" + ("trainaug.txt" if self.split == "train" else "val.txt"))
+            return [(f"images/{f}.jpg", f"{seg}/{f}.png") for f in sorted(fs)]
         if self.name == "ade20k":
             sub = "training" if self.split == "train" else "validation"
-            img_dir, ann_dir = os.path.join(r, "images", sub), os.path.join(r, "annotations", sub)
             if fs is None:
-                fs = [f[:-4] for f in sorted(os.listdir(img_dir)) if f.endswith(".jpg")]
-            return [(os.path.join(img_dir, f"{f}.jpg"), os.path.join(ann_dir, f"{f}.png")) for f in sorted(fs)]
+                fs = [f[:-4] for f in st.listdir(f"images/{sub}") if f.endswith(".jpg")]
+            return [(f"images/{sub}/{f}.jpg", f"annotations/{sub}/{f}.png") for f in sorted(fs)]
         if self.name == "cityscapes":
-            img_root, gt_root = os.path.join(r, "leftImg8bit", self.split), os.path.join(r, "gtFine", self.split)
+            img_root, gt_root = f"leftImg8bit/{self.split}", f"gtFine/{self.split}"
             out = []
-            for city in sorted(os.listdir(img_root)):
-                for f in sorted(os.listdir(os.path.join(img_root, city))):
+            for city in st.listdir(img_root):
+                for f in st.listdir(f"{img_root}/{city}"):
                     if not f.endswith("_leftImg8bit.png"):
                         continue
                     stem = f[: -len("_leftImg8bit.png")]
                     if fs is not None and stem not in fs:
                         continue
-                    out.append((os.path.join(img_root, city, f), os.path.join(gt_root, city, stem + "_gtFine_labelIds.png")))
+                    out.append((f"{img_root}/{city}/{f}", f"{gt_root}/{city}/{stem}_gtFine_labelIds.png"))
             return out
         if self.name in ("coco-thing", "coco-stuff"):
             return self._collect_coco(fs)
@@ -165,14 +256,15 @@ class SegFolder(Dataset):
         256-entry lookup table on the uint8 mask (before the nearest-neighbour resize, which commutes with it)."""
         import json
         thing = self.name == "coco-thing"
-        r, sp = self.root, self.split
-        seg_dir = os.path.join(r, f"annotations/{sp}2017/" if thing else f"annotations/stuff_annotations/stuff_{sp}2017_pixelmaps/")
-        js = os.path.join(r, "annotations/panoptic_annotations/panoptic_val2017.json" if thing
-                          else "annotations/stuff_annotations/stuff_val2017.json")
-        img_dir = os.path.join(r, "images", f"{sp}2017")
-        if not os.path.isdir(seg_dir) or not os.path.isdir(img_dir):
+        st, sp = self.store, self.split
+        seg_dir = f"annotations/{sp}2017" if thing else f"annotations/stuff_annotations/stuff_{sp}2017_pixelmaps"
+        js = ("annotations/panoptic_annotations/panoptic_val2017.json" if thing
+              else "annotations/stuff_annotations/stuff_val2017.json")
+        img_dir = f"images/{sp}2017"
+        if not st.isdir(seg_dir) or not st.isdir(img_dir):
             raise RuntimeError("Dataset not found or corrupted.")                        # coco_data.py:129-132
-        cats = json.load(open(js))["categories"]
+        with st.open(js) as f:
+            cats = json.loads(f.read().decode())["categories"]
         lut = np.full(256, 255, dtype=np.uint8)
         if thing:
             sup = sorted({c["supercategory"] for c in cats if c["isthing"] == 1})
@@ -188,19 +280,22 @@ class SegFolder(Dataset):
             lut[0] = 255                                                                  # things -> id 183 'other' -> ignored (155-160)
         self._lut = lut
         if fs is None:
-            imgs = [os.path.join(img_dir, f) for f in sorted(os.listdir(img_dir))]
-            msks = [os.path.join(seg_dir, f) for f in sorted(os.listdir(seg_dir))]
+            imgs = [f"{img_dir}/{f}" for f in st.listdir(img_dir)]
+            msks = [f"{seg_dir}/{f}" for f in st.listdir(seg_dir)]
             return list(zip(imgs, msks))
         fs = sorted(f.replace(".jpg", "").replace(".png", "") for f in fs)
-        return [(os.path.join(img_dir, f"{f}.jpg"), os.path.join(seg_dir, f"{f}.png")) for f in fs]
+        return [(f"{img_dir}/{f}.jpg", f"{seg_dir}/{f}.png") for f in fs]
 
     def __len__(self):
         return len(self.pairs)
 
     def __getitem__(self, i):
         ip, mp = self.pairs[i]
-        img = Image.open(ip).convert("RGB")
-        mask = Image.open(mp)
+        with self.store.open(ip) as f:
+            img = Image.open(f).convert("RGB")
+        with self.store.open(mp) as f:
+            mask = Image.open(f)
+            mask.load()
         if self.name == "cityscapes":
             ids = np.asarray(mask, dtype=np.int32)
             mask = Image.fromarray(_CITY_KEY[np.clip(ids + 1, 0, len(_CITY_KEY) - 1)])   # cityscapes_data.py:50-58

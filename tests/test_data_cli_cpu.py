@@ -161,3 +161,39 @@ def test_coco_stuff_and_cityscapes_folder(tmp_path):
     dm, ign = get_dataset("cityscapes", str(croot), 1, 0, 32)
     x, y = next(iter(dm.val_dataloader()))
     assert set((y * 255).long().unique().tolist()) <= {0, 1, 13, 18, 255}    # 7->0 road, 8->1, 26->13 car, 33->18 bicycle
+
+
+def test_voc_from_a_tar_archive_equals_the_folder(tmp_path):
+    """The dataset root may be `/x/voc.tar` or `/x/all.tar!/inner` (hbird/utils/io.py:10-15, voc_tar_data.py): same
+    samples as the unpacked tree, also through DataLoader workers; frames may be rectangular (sliding windows)."""
+    import tarfile
+    from hbird_mi.data import get_dataset
+    from hbird_mi.data.folder import TarStore, read_file_set
+    tree = tmp_path / "VOC"
+    _make_voc(str(tree))
+    plain, nested = tmp_path / "voc.tar", tmp_path / "all.tar.gz"
+    with tarfile.open(plain, "w") as t:
+        for d in sorted(os.listdir(tree)):
+            t.add(tree / d, arcname=d)
+    with tarfile.open(nested, "w:gz") as t:
+        t.add(tree, arcname="data/VOC")
+    ref, _ = get_dataset("voc", str(tree), 2, 0, (32, 48))
+    want = [(x.clone(), y.clone()) for x, y in ref.val_dataloader()]
+    for root, workers in ((str(plain), 0), (str(nested) + "!/data/VOC/", 0), (str(plain), 2)):
+        dm, ign = get_dataset("voc", root, 2, workers, (32, 48))
+        assert ign == 255 and dm.get_train_dataset_size() == 4
+        got = list(dm.val_dataloader())
+        assert len(got) == len(want)
+        for (x, y), (rx, ry) in zip(got, want):
+            assert x.shape[-2:] == (32, 48) and torch.equal(x, rx) and torch.equal(y, ry)
+    st = TarStore(str(nested) + "!/data/VOC")
+    assert st.isdir("images") and not st.isdir("nope") and st.listdir("sets") == ["trainaug.txt", "val.txt"]
+    assert st.listdir("") == ["SegmentationClass", "SegmentationClassAug", "images", "sets"]
+    assert read_file_set(str(nested) + "!/data/VOC/sets/val.txt") == ["img004", "img005"]
+    assert read_file_set(str(tree / "sets" / "val.txt")) == ["img004", "img005"]
+    with pytest.raises(FileNotFoundError):
+        TarStore(str(tmp_path / "missing.tar"))
+    with pytest.raises(FileNotFoundError):
+        st.open("images/none.jpg")
+    with pytest.raises(RuntimeError):
+        get_dataset("voc", str(nested) + "!/data/other", 2, 0, 32)
