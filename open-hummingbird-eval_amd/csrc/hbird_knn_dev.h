@@ -22,6 +22,9 @@ struct knn_args {
     int klw;  // row stride in the state buffer: HB_KL (sorted lists), or the pool capacity when k > HB_KL
     int* state_cnt;     // pools only: fill count and threshold per (slot, query), kept between segments
     float* state_thr;
+    unsigned* gthr;     // [query]: shared threshold floor (monotone key of a score that k rows are known to reach)
+    unsigned* xcd_bar;  // [8]: arrival counters of the XCD-wide rendezvous of the grid rounds
+    int xcd_wgs;        // workgroups per XCD (launch size / 8)
 };
 
 __device__ __forceinline__ void glds16(const float* gsrc, char* lds_base) {
@@ -133,11 +136,12 @@ __device__ __forceinline__ float pool_compact(float* gs, unsigned* gi, int cap, 
 
 // Epilogue of one (query tile, bank tile) pair for one wave: filter the wave's 256 x 32 scores against the
 // per-query thresholds (phase 1, always) and hand the rare survivors to the lists / pools (phase 2).
+// qb = first of the 32 queries (of the workgroup's 256) that `acc` holds.
 // WIDE = false: lst_s / lst_i are the sorted LDS lists.  WIDE = true: they are the slot's pools in global memory
 // (row stride klw = capacity) and `cnt` holds the fill counts of the workgroup's 256 queries in LDS.
 template <bool SLOW = true, bool WIDE = false>
 __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, float* lst_s, unsigned* lst_i, float* sc,
-                                              int w, int lane, int k, unsigned bt, int klw = HB_KL, int* cnt = nullptr) {
+                                              int qb, int lane, int k, unsigned bt, int klw = HB_KL, int* cnt = nullptr) {
     unsigned qmask = 0;   // bit 4t+q: quarter q (8 bank rows) of row tile t holds a score above its query's threshold
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -163,7 +167,7 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, floa
                     // every passing lane appends to its own query's pool (one query per lane within a half)
                     const bool pass = ((lane >> 5) == hh) && (v > thr);
                     if (__ballot(pass) == 0ull) continue;
-                    const int myq = w * 32 + (lane & 31);
+                    const int myq = qb + (lane & 31);
                     int c = 0;
                     if (pass) {
                         c = cnt[myq];
@@ -175,10 +179,10 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, floa
                     while (full) {
                         const int n = __builtin_ctzll(full) & 31;
                         full &= full - 1;
-                        const size_t off = (size_t)(w * 32 + n) * klw;
+                        const size_t off = (size_t)(qb + n) * klw;
                         const float kth = pool_compact(lst_s + off, lst_i + off, klw, k, lane);
-                        if (lane == 0) cnt[w * 32 + n] = k;
-                        if ((lane & 31) == n) thr = kth;
+                        if (lane == 0) cnt[qb + n] = k;
+                        if ((lane & 31) == n) thr = fmaxf(thr, kth);
                     }
                 } else {
                     unsigned long long m = __ballot(v > thr);
@@ -188,13 +192,51 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, floa
                         m &= m - 1;
                         const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
                         const int n = l & 31;
-                        list_insert(lst_s, lst_i, w * 32 + n, k, s, row_base + hh * 4 + j, lane);
-                        const float kth = lst_s[(w * 32 + n) * HB_KL + (k - 1)];
-                        if ((lane & 31) == n) thr = kth;
+                        list_insert(lst_s, lst_i, qb + n, k, s, row_base + hh * 4 + j, lane);
+                        const float kth = lst_s[(qb + n) * HB_KL + (k - 1)];
+                        if ((lane & 31) == n) thr = fmaxf(thr, kth);
                     }
                 }
             }
     }
+}
+
+// ---- shared threshold floor ----------------------------------------------------------------------------------
+// A query tile's bank rows are spread over several slots (workgroups / panels), each with its own running best-k.
+// The k-th best score of ANY slot is a lower bound of the final k-th best, so slots publish theirs (atomic max of the
+// monotone key) when a segment ends and start their next segment from the best bound published so far: a slot no
+// longer has to rediscover a threshold that another one already knows (the cold start of every new slot, and the
+// k ln(rows/k) insertions of a slot that only ever sees a slice of the bank).  A foreign bound g admits ties
+// (score == g may still win on the id), hence the floor is the float just below g; own k-th scores keep the strict
+// rule.  Which scores get filtered early depends on timing, the merged result does not.
+__device__ __forceinline__ float floor_load(const unsigned* gthr, int q) {
+    unsigned g = __hip_atomic_load(gthr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (g <= 0x007FFFFFu) return -INFINITY;                 // key(-inf): nothing published yet
+    g -= 1u;
+    if (g == 0x7FFFFFFFu) g = 0x7FFFFFFEu;                  // skip -0.0 (equal to +0.0): largest float below zero
+    return __builtin_bit_cast(float, (g & 0x80000000u) ? (g ^ 0x80000000u) : ~g);
+}
+__device__ __forceinline__ void floor_publish(unsigned* gthr, int q, float thr) {
+    if (thr > -INFINITY) atomicMax(gthr + q, pool_key(thr));
+}
+
+// Rendezvous of the workgroups of one XCD at the start of a grid round (hb_build_schedule): the round's workgroups
+// share bank and query fragments through the XCD's L2 only while they move in step -- the L2 (4 MiB) turns over in
+// a few microseconds at LDS-DMA rates -- so every round starts aligned.  Purely a performance device: the wait is
+// bounded (~0.3 ms of the 100 MHz real-time counter), a workgroup that is late or not resident only costs the others
+// their alignment, never a hang.
+__device__ __forceinline__ void xcd_rendezvous(unsigned* bar, int xcd_wgs, int round) {
+    if (threadIdx.x == 0) {
+        unsigned* c = bar + (blockIdx.x & 7);
+        __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned want = (unsigned)round * (unsigned)xcd_wgs;
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(4);
+            if (__builtin_readcyclecounter() - t0 > 1000000ull) break;
+        }
+    }
+    __syncthreads();
 }
 
 // pools: fill counts / thresholds of the wave's 32 queries at the start and the end of a segment
