@@ -46,8 +46,6 @@ def parse():
     ap.add_argument("--panel", type=int, default=0)
     ap.add_argument("--fp16", action="store_true", help="use_fp16: fp16 candidate pass + exact fp32 re-rank")
     ap.add_argument("--variant", type=int, default=0, help="kNN kernel variant (0: 8 waves, 1: 4 waves)")
-    ap.add_argument("--schedule", choices=["grid", "linear"], default="grid",
-                    help="work list: XCD grid rounds (L2 sharing, default) or linear ranges")
     return ap.parse_args()
 
 
@@ -154,8 +152,6 @@ def main():
         index.set_tuning(a.workgroups, a.panel)
     if a.variant:
         index.set_variant(a.variant)
-    if a.schedule == "linear":
-        index.set_schedule(1)
     if a.fp16:
         index.set_fp16(True)
     t_build = time.time()

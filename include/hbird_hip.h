@@ -135,21 +135,14 @@ int hb_index_last_fp16_fallbacks(const hb_index_t* ix, int64_t* n);
 /* kNN kernel variant: 0 = 8 waves per workgroup (two per SIMD, default), 1 = 4 waves (one per SIMD, 256
  * accumulator registers per lane).  Same results; for tuning. */
 int hb_index_set_variant(hb_index_t* ix, int variant);
-/* How a panel's (query tile, bank tile) pairs are dealt to the workgroups: 0 (default) = XCD grid rounds -- the
- * workgroups of an XCD take s query tiles x L/s bank ranges in step, so that bank and query fragments are shared
- * through the XCD's L2 (needs a multiple of 8 workgroups, else linear); 1 = linear ranges of the q-major pair list.
- * Same results either way. */
-int hb_index_set_schedule(hb_index_t* ix, int mode);
 /* Work-list statistics of the last search: out[0]=workgroups, [1]=segments, [2]=slots, [3]=panel tiles,
- * [4]=max slots per query tile, [5]=query tiles, [6]=bank tiles, [7]=schedule mode built (0 grid, 1 linear). */
+ * [4]=max slots per query tile, [5]=query tiles, [6]=bank tiles. */
 int hb_index_schedule_info(const hb_index_t* ix, int64_t out[8]);
 
 /* Host-only (no GPU needed): the work list the kNN kernel would run for nqt query tiles (256 rows) x nbt bank tiles
- * (256 rows) on `workgroups` workgroups; panel_tiles = 0 selects the automatic panel; mode as hb_index_set_schedule.
- * segs_out (may be NULL) receives up to max_segs rows {block, q_tile, b_tile0, n_tiles, slot, first, sync}; stats as
- * hb_index_schedule_info.  sync > 0 numbers the XCD-wide rendezvous a block passes before the segment (grid rounds;
- * a row with n_tiles = 0 is a block that only takes part in the rendezvous). */
-int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, int mode, int* segs_out, int64_t max_segs,
+ * (256 rows) on `workgroups` workgroups; panel_tiles = 0 selects the automatic panel.  segs_out (may be NULL) receives
+ * up to max_segs rows {block, q_tile, b_tile0, n_tiles, slot, first}; stats as hb_index_schedule_info. */
+int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, int* segs_out, int64_t max_segs,
                      int64_t stats[8]);
 
 #ifdef __cplusplus

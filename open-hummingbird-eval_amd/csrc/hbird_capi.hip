@@ -74,23 +74,23 @@ extern "C" int hb_index_set_fp16(hb_index_t* ix, int enable) {
 
 extern "C" int hb_index_last_fp16_fallbacks(const hb_index_t* ix, int64_t* n) { *n = ix->last_fp16_fallbacks; return 0; }
 
-extern "C" int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, int mode, int* segs_out,
-                                int64_t max_segs, int64_t stats[8]) {
+extern "C" int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, int* segs_out, int64_t max_segs,
+                                int64_t stats[8]) {
     if (nqt <= 0 || nbt <= 0 || workgroups <= 0 || d <= 0) return hb_fail("hb_schedule_plan: bad arguments");
     const int dp = (d + HB_KC - 1) / HB_KC * HB_KC;
     const int G = (int)std::min<long long>(workgroups, (long long)nqt * nbt);
     const int panel = panel_tiles > 0 ? panel_tiles : hb_default_panel(nqt, G, (size_t)HB_BT * dp * 4);
     hb_schedule sc;
-    hb_build_schedule(nqt, nbt, workgroups, panel, sc, mode);
+    hb_build_schedule(nqt, nbt, workgroups, panel, sc);
     stats[0] = sc.G; stats[1] = (int64_t)sc.segs.size(); stats[2] = sc.n_slots; stats[3] = sc.panel;
-    stats[4] = sc.max_slots_per_qt; stats[5] = sc.nqt; stats[6] = sc.nbt; stats[7] = sc.mode;
+    stats[4] = sc.max_slots_per_qt; stats[5] = sc.nqt; stats[6] = sc.nbt; stats[7] = 0;
     if (segs_out) {
         int64_t n = 0;
         for (int b = 0; b < sc.G; ++b)
             for (int i = sc.wg_off[b]; i < sc.wg_off[b + 1] && n < max_segs; ++i, ++n) {
                 const hb_seg& g = sc.segs[i];
-                int* o = segs_out + n * 7;
-                o[0] = b; o[1] = g.q_tile; o[2] = g.b_tile0; o[3] = g.n_tiles; o[4] = g.slot; o[5] = g.first; o[6] = g.sync;
+                int* o = segs_out + n * 6;
+                o[0] = b; o[1] = g.q_tile; o[2] = g.b_tile0; o[3] = g.n_tiles; o[4] = g.slot; o[5] = g.first;
             }
     }
     return 0;
@@ -101,15 +101,10 @@ extern "C" int hb_index_set_variant(hb_index_t* ix, int variant) {
     ix->variant = variant;
     return 0;
 }
-extern "C" int hb_index_set_schedule(hb_index_t* ix, int mode) {
-    if (mode < 0 || mode > 1) return hb_fail("hb_index_set_schedule: mode must be 0 (XCD grid) or 1 (linear)");
-    ix->sched_mode = mode;
-    return 0;
-}
 extern "C" int hb_index_schedule_info(const hb_index_t* ix, int64_t out[8]) {
     const hb_schedule& s = ix->sched;
     out[0] = s.G; out[1] = (int64_t)s.segs.size(); out[2] = s.n_slots; out[3] = s.panel; out[4] = s.max_slots_per_qt;
-    out[5] = s.nqt; out[6] = s.nbt; out[7] = s.mode;
+    out[5] = s.nqt; out[6] = s.nbt; out[7] = 0;
     return 0;
 }
 

@@ -29,7 +29,6 @@ struct hb_seg {
     int n_tiles;   // consecutive bank tiles
     int slot;      // partial-list slot this segment accumulates into
     int first;     // 1: slot starts empty, 0: continue from the stored lists
-    int sync;      // grid rounds: > 0 = number of the XCD-wide rendezvous to pass before this segment (0: none)
 };
 
 struct hb_schedule {
@@ -40,12 +39,9 @@ struct hb_schedule {
     std::vector<int> qt_slots;       // slots that hold partial lists of each query tile
     int n_slots = 0;
     int max_slots_per_qt = 0;
-    int mode = 0;        // 0: XCD grid rounds, 1: linear ranges (what was built)
-    int want_mode = 0;   // what was asked for (cache key)
 };
 
-// mode 0: grid rounds when the launch has 8 equal XCD groups (else linear); mode 1: linear ranges
-void hb_build_schedule(int nqt, int nbt, int G, int panel_tiles, hb_schedule& out, int mode = 0);
+void hb_build_schedule(int nqt, int nbt, int G, int panel_tiles, hb_schedule& out);
 int hb_default_panel(int nqt, int G, size_t tile_bytes);
 
 struct hb_index {
@@ -79,7 +75,6 @@ struct hb_index {
     char* fb = nullptr; size_t fb_bytes = 0;             // fallback workspace (uncertified queries)
     int64_t last_fp16_fallbacks = 0;
     int variant = 0;                                     // 0: 8-wave kernel, 1: 4-wave (one wave per SIMD) kernel
-    int sched_mode = 0;                                  // 0: XCD grid rounds (auto), 1: linear ranges
     int ablate = 0;                                      // timing-only kernel ablation (HB_ABLATION builds)
     double last_knn_ms = 0.0;                            // HIP-event time of the last knn kernel launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

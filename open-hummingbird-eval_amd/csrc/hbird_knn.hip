@@ -47,8 +47,6 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
     for (int si = seg_begin; si < seg_end; ++si) {
         const hb_seg seg = a.segs[si];
-        if (seg.sync) xcd_rendezvous(a.xcd_bar, a.xcd_wgs, seg.sync);
-        if (seg.n_tiles == 0) continue;   // a workgroup idle in this grid round only keeps the rendezvous count
         const int klw = a.klw;   // list row stride (HB_KL on the LDS path)
         float* wl_s = a.state_s + (size_t)seg.slot * HB_QT * klw;      // this slot's lists in global memory
         unsigned* wl_i = a.state_i + (size_t)seg.slot * HB_QT * klw;
@@ -358,23 +356,18 @@ int hb_launch_merge_parts(const float* dist_parts, const int64_t* idx_parts, int
 }
 
 // ---- host-side work list ------------------------------------------------------------------------------
-// Pairs (query tile q, bank tile b) are processed panel by panel (a panel = `panel` consecutive bank tiles, sized to
-// stay resident in the 256 MiB Infinity Cache together with the queries), so that every bank byte leaves HBM about
-// once per search.  Bank tiles are visited in ascending order for every slot, which the strict `score > threshold`
-// filter relies on for ties.  Two ways to deal a panel's pairs to the workgroups:
+// Pairs (query tile q, bank tile b) are processed panel by panel (a panel = `panel` consecutive bank
+// tiles, sized to stay resident in the 256 MiB Infinity Cache together with the queries): inside a
+// panel the q-major pair list is cut into G equal contiguous ranges, one per workgroup, so at any time
+// all workgroups read the same panel (each bank byte leaves HBM about once per search) while every
+// workgroup keeps working on the same <= 2 query tiles for the whole search.  Bank tiles are visited in
+// ascending order for every slot, which the strict `score > threshold` filter relies on for ties.
 //
-//  * GRID (default when the launch has 8 equal XCD groups): the hardware deals workgroups round-robin over the 8
-//    XCDs (block b runs on XCD b % 8), each with a private 4 MiB L2.  An LDS-DMA stream that misses the L2 is fed by
-//    the fabric at 22-32 GB/s per CU, one that hits it at ~70 GB/s (tools/ubench/dma_l2.hip), so the L = G/8
-//    workgroups of an XCD work as a grid: in a ROUND they take s query tiles x (L/s) contiguous ranges of the panel,
-//    workgroup (i, j) = query tile i x range j.  All workgroups of a round start together and every pair tile
-//    costs the same, so they move in step: the s workgroups of a column read the same bank fragments at the same
-//    time, the L/s workgroups of a row the same query fragments -- one L2 fill serves them all ((s + L/s) / 2L of the
-//    private-stream traffic: 19 % for 4 x 8).  XCD x owns the query tiles of the interval [x nqt/8, (x+1) nqt/8); a
-//    tile cut by an interval boundary alternates between its owners from panel to panel in proportion to the
-//    overlap, which balances the XCDs to within one (query tile x panel) unit.  Whole tiles go in rounds of 4 (the
-//    rest in one round of 1-3), cut tiles in rounds of their own (1 x L).
-//  * LINEAR (any G): the q-major pair list of the panel is cut into G equal contiguous ranges.
+// Tried and dropped (round 1, 10 M x 768): dealing each XCD's 32 workgroups a grid of 4 query tiles x 8 bank ranges
+// per round, started together by an XCD-wide rendezvous, so that fragments are shared through the XCD's L2.  The
+// sharing works (L2 hit rate 26 % -> 68 %, fabric reads -58 %, profiles/r01/README.md) but buys nothing: the fp32
+// kernel is bound by the matrix pipe (2438 vs 2413 ms) and the fp16 candidate kernel by the latency of a stage's slowest
+// line, which a 68 % hit rate does not shorten, while 3.4x more partial-list slots cost more (454 vs 413 ms).
 int hb_default_panel(int nqt, int G, size_t tile_bytes) {
     auto gcd = [](int x, int y) { while (y) { int t = x % y; x = y; y = t; } return x; };
     int p0 = G / gcd(nqt, G);   // smallest panel for which nqt*panel divides evenly over G workgroups
@@ -383,114 +376,15 @@ int hb_default_panel(int nqt, int G, size_t tile_bytes) {
     return p0 * j;
 }
 
-namespace {
-struct sched_builder {
-    hb_schedule& out;
-    std::vector<std::vector<hb_seg>> per_block;
-    std::map<std::pair<int, int>, int> slot_of;   // (block, q_tile) -> slot
-    std::vector<std::vector<int>> slots_of_qt;
-    sched_builder(hb_schedule& o, int G, int nqt) : out(o), per_block(G), slots_of_qt(nqt) {}
-    void add_idle(int block, int sync) {   // rendezvous only
-        hb_seg sg;
-        sg.q_tile = 0; sg.b_tile0 = 0; sg.n_tiles = 0; sg.slot = 0; sg.first = 0; sg.sync = sync;
-        per_block[block].push_back(sg);
-    }
-    void add(int block, int q, int b0, int cnt, int sync = 0) {
-        if (cnt <= 0) { if (sync) add_idle(block, sync); return; }
-        auto key = std::make_pair(block, q);
-        auto it = slot_of.find(key);
-        hb_seg sg;
-        sg.q_tile = q; sg.b_tile0 = b0; sg.n_tiles = cnt; sg.sync = sync;
-        if (it == slot_of.end()) {
-            sg.slot = out.n_slots++; sg.first = 1;
-            slot_of[key] = sg.slot;
-            slots_of_qt[q].push_back(sg.slot);
-        } else { sg.slot = it->second; sg.first = 0; }
-        // coalesce with the previous segment when it continues the same slot contiguously
-        if (!per_block[block].empty() && !sync) {
-            hb_seg& pv = per_block[block].back();
-            if (pv.n_tiles > 0 && pv.slot == sg.slot && pv.b_tile0 + pv.n_tiles == sg.b_tile0) { pv.n_tiles += cnt; return; }
-        }
-        per_block[block].push_back(sg);
-    }
-    void finish(const std::vector<int>* logical_of_block) {
-        const int G = (int)per_block.size(), nqt = (int)slots_of_qt.size();
-        out.wg_off.assign(G + 1, 0);
-        for (int b = 0; b < G; ++b) {
-            const std::vector<hb_seg>& v = per_block[logical_of_block ? (*logical_of_block)[b] : b];
-            out.wg_off[b + 1] = out.wg_off[b] + (int)v.size();
-            out.segs.insert(out.segs.end(), v.begin(), v.end());
-        }
-        out.qt_off.assign(nqt + 1, 0);
-        for (int q = 0; q < nqt; ++q) {
-            out.qt_off[q + 1] = out.qt_off[q] + (int)slots_of_qt[q].size();
-            out.qt_slots.insert(out.qt_slots.end(), slots_of_qt[q].begin(), slots_of_qt[q].end());
-            out.max_slots_per_qt = std::max(out.max_slots_per_qt, (int)slots_of_qt[q].size());
-        }
-    }
-};
-
-void build_grid(int nqt, int nbt, int G, int panel, hb_schedule& out) {
-    const int L = G / 8;   // workgroups per XCD; block x + 8 m is workgroup m of XCD x
-    sched_builder sb(out, G, nqt);
-    // owners of every query tile: XCD x overlaps tile q by the length of [q, q+1) within [x nqt/8, (x+1) nqt/8)
-    struct own { int x; double w; };
-    std::vector<std::vector<own>> owners(nqt);
-    for (int q = 0; q < nqt; ++q)
-        for (int x = 0; x < 8; ++x) {
-            const double lo = std::max<double>(q, (double)x * nqt / 8.0), hi = std::min<double>(q + 1, (double)(x + 1) * nqt / 8.0);
-            if (hi - lo > 1e-9) owners[q].push_back({x, hi - lo});
-        }
-    std::vector<double> credit(nqt * 8, 0.0);   // weighted round-robin state of the cut tiles
-    const int qx_max = std::min(4, L);
-    std::vector<int> whole[8], cut[8];
-    int rounds_done[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int b0 = 0; b0 < nbt; b0 += panel) {
-        const int pp = std::min(panel, nbt - b0);
-        for (int x = 0; x < 8; ++x) { whole[x].clear(); cut[x].clear(); }
-        for (int q = 0; q < nqt; ++q) {
-            if (owners[q].size() == 1) { whole[owners[q][0].x].push_back(q); continue; }
-            // the owner with the largest accumulated credit takes this panel (smooth weighted round-robin)
-            int best = 0;
-            for (size_t o = 0; o < owners[q].size(); ++o) {
-                credit[q * 8 + o] += owners[q][o].w;
-                if (credit[q * 8 + o] > credit[q * 8 + best] + 1e-12) best = (int)o;
-            }
-            double tot = 0;
-            for (const own& o : owners[q]) tot += o.w;
-            credit[q * 8 + best] -= tot;
-            cut[owners[q][best].x].push_back(q);
-        }
-        for (int x = 0; x < 8; ++x) {
-            auto round = [&](const int* qs, int s) {
-                const int lanes = L / s, r = ++rounds_done[x];
-                for (int i = 0; i < s; ++i)
-                    for (int j = 0; j < lanes; ++j) {
-                        const int t0 = (int)((long long)pp * j / lanes), t1 = (int)((long long)pp * (j + 1) / lanes);
-                        sb.add(x + 8 * (i * lanes + j), qs[i], b0 + t0, t1 - t0, r);
-                    }
-                for (int m = s * lanes; m < L; ++m) sb.add_idle(x + 8 * m, r);
-            };
-            const std::vector<int>& wq = whole[x];
-            for (size_t i = 0; i < wq.size(); i += qx_max) round(&wq[i], (int)std::min<size_t>(qx_max, wq.size() - i));
-            for (int q : cut[x]) round(&q, 1);
-        }
-    }
-    sb.finish(nullptr);
-}
-}  // namespace
-
-void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out, int mode) {
+void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out) {
     out = hb_schedule();
     out.nqt = nqt; out.nbt = nbt; out.panel = panel;
     const long long total_pairs = (long long)nqt * nbt;
     if (total_pairs < G) G = (int)std::max<long long>(1, total_pairs);
     out.G = G;
-    // the grid needs 8 equal XCD groups, at least one query tile per XCD (fewer: every workgroup shares the query
-    // tile anyway) and enough panels for the cut tiles to balance out
-    out.mode = (mode != 1 && G % 8 == 0 && nqt >= 8 && (nbt + panel - 1) / panel >= 4) ? 0 : 1;
-    if (out.mode == 0) { build_grid(nqt, nbt, G, panel, out); return; }
-    sched_builder sb(out, G, nqt);
+    std::vector<std::vector<hb_seg>> per_wg(G);
+    std::map<std::pair<int, int>, int> slot_of;   // (wg, q_tile) -> slot
+    std::vector<std::vector<int>> slots_of_qt(nqt);
     for (int b0 = 0; b0 < nbt; b0 += panel) {
         const int pp = std::min(panel, nbt - b0);
         const long long W = (long long)nqt * pp;
@@ -499,14 +393,29 @@ void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out, int
             while (e0 < e1) {
                 const int q = (int)(e0 / pp), b = (int)(e0 % pp);
                 const int cnt = (int)std::min<long long>(pp - b, e1 - e0);
-                sb.add(w, q, b0 + b, cnt);
+                auto key = std::make_pair(w, q);
+                auto it = slot_of.find(key);
+                hb_seg sg;
+                sg.q_tile = q; sg.b_tile0 = b0 + b; sg.n_tiles = cnt;
+                if (it == slot_of.end()) {
+                    sg.slot = out.n_slots++; sg.first = 1;
+                    slot_of[key] = sg.slot;
+                    slots_of_qt[q].push_back(sg.slot);
+                } else { sg.slot = it->second; sg.first = 0; }
+                // coalesce with the previous segment when it continues the same slot contiguously
+                if (!per_wg[w].empty()) {
+                    hb_seg& pv = per_wg[w].back();
+                    if (pv.slot == sg.slot && pv.b_tile0 + pv.n_tiles == sg.b_tile0) { pv.n_tiles += cnt; e0 += cnt; continue; }
+                }
+                per_wg[w].push_back(sg);
                 e0 += cnt;
             }
         }
     }
-    // XCD-aware placement (speed only, never correctness): logical ranges v = 0..G-1 -- neighbours share a query
-    // tile -- are laid out so that each XCD gets a contiguous run of them: block b runs logical range
-    // (b % 8) * (G / 8) + b / 8.
+    // XCD-aware placement (speed only, never correctness): hardware deals workgroups round-robin over the 8 XCDs
+    // (block b runs on XCD b % 8, checked with tools/ubench/xcc_map.hip; blocks b and b+8 share an L2), so logical
+    // ranges v = 0..G-1 -- neighbours share a query tile -- are laid out so that each XCD gets a contiguous run of
+    // them: block b runs logical range (b % 8) * (G / 8) + b / 8.
     std::vector<int> logical_of_block(G);
     for (int b = 0; b < G; ++b) {
         if (G % 8 == 0) logical_of_block[b] = (b % 8) * (G / 8) + b / 8;
@@ -515,15 +424,25 @@ void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out, int
             logical_of_block[b] = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
         }
     }
-    sb.finish(&logical_of_block);
+    out.wg_off.assign(G + 1, 0);
+    for (int b = 0; b < G; ++b) {
+        const int w = logical_of_block[b];
+        out.wg_off[b + 1] = out.wg_off[b] + (int)per_wg[w].size();
+        out.segs.insert(out.segs.end(), per_wg[w].begin(), per_wg[w].end());
+    }
+    out.qt_off.assign(nqt + 1, 0);
+    for (int q = 0; q < nqt; ++q) {
+        out.qt_off[q + 1] = out.qt_off[q] + (int)slots_of_qt[q].size();
+        out.qt_slots.insert(out.qt_slots.end(), slots_of_qt[q].begin(), slots_of_qt[q].end());
+        out.max_slots_per_qt = std::max(out.max_slots_per_qt, (int)slots_of_qt[q].size());
+    }
 }
 
 
 // q_tiles / q_aux must already be prepared by the caller (hb_index_search).
 struct knn16_args_host {   // must match knn16_args in hbird_knn_f16.hip
     const void* bank16; const float* binit; const void* q16; const hb_seg* segs; const int* wg_off;
-    float* state_s; unsigned* state_i; int g16, k, klw; int* state_cnt; float* state_thr; unsigned* gthr; unsigned* xcd_bar;
-    int xcd_wgs;
+    float* state_s; unsigned* state_i; int g16, k, klw; int* state_cnt; float* state_thr; unsigned* gthr;
 };
 
 int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t id_base, int64_t* out_idx, float* out_dist) {
@@ -551,9 +470,8 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     const size_t tile_bytes = (size_t)HB_BT * ix->dp * 4;
     const int panel = ix->force_panel > 0 ? ix->force_panel : hb_default_panel(nqt, std::min<long long>(G, (long long)nqt * nbt), tile_bytes);
     hb_schedule& sc = ix->sched;
-    const bool rebuilt = !(sc.nqt == nqt && sc.nbt == nbt && sc.panel == panel && (sc.G == G || (long long)nqt * nbt < G) &&
-                           sc.want_mode == ix->sched_mode);
-    if (rebuilt) { hb_build_schedule(nqt, nbt, G, panel, sc, ix->sched_mode); sc.want_mode = ix->sched_mode; }
+    const bool rebuilt = !(sc.nqt == nqt && sc.nbt == nbt && sc.panel == panel && (sc.G == G || (long long)nqt * nbt < G));
+    if (rebuilt) hb_build_schedule(nqt, nbt, G, panel, sc);
     // device copy of the work list: [segs][wg_off][qt_off][qt_slots]
     const size_t b_segs = sc.segs.size() * sizeof(hb_seg), b_wg = sc.wg_off.size() * 4, b_qo = sc.qt_off.size() * 4,
                  b_qs = sc.qt_slots.size() * 4;
@@ -571,7 +489,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     const size_t state_half = (size_t)sc.n_slots * HB_QT * klw * 4;
     const size_t state_aux = wide ? (size_t)sc.n_slots * HB_QT * 4 : 0;   // pools: fill counts + thresholds
     const size_t floor_bytes = (size_t)nqt * HB_QT * 4;                   // shared threshold floors, one per query
-    if (ensure_bytes(&ix->state, &ix->state_bytes, 2 * state_half + 2 * state_aux + floor_bytes + 64)) return -1;
+    if (ensure_bytes(&ix->state, &ix->state_bytes, 2 * state_half + 2 * state_aux + floor_bytes)) return -1;
 
     knn_args a;
     a.bank_tiles = ix->tiles; a.binit = ix->binit; a.q_tiles = ix->q_tiles;
@@ -585,9 +503,6 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     const int* pool_cnt = wide ? a.state_cnt : nullptr;
     a.gthr = reinterpret_cast<unsigned*>(ix->state + 2 * state_half + 2 * state_aux);
     HB_HIP(hipMemsetD32Async((hipDeviceptr_t)a.gthr, 0x007FFFFF, (size_t)nqt * HB_QT, s));   // key(-inf)
-    a.xcd_bar = reinterpret_cast<unsigned*>(ix->state + 2 * state_half + 2 * state_aux + floor_bytes);
-    a.xcd_wgs = sc.G / 8;
-    HB_HIP(hipMemsetD32Async((hipDeviceptr_t)a.xcd_bar, 0, 16, s));
     if (f16) {
         // bring the fp16 copies of the bank / query fragment tiles up to date
         const int64_t need_rt = (ix->ntotal + 31) / 32;
@@ -612,8 +527,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         knn16_args_host h;
         h.bank16 = ix->tiles16; h.binit = ix->binit; h.q16 = ix->q16; h.segs = a.segs; h.wg_off = a.wg_off;
         h.state_s = a.state_s; h.state_i = a.state_i; h.g16 = ix->dp16 / 16; h.k = kc; h.klw = klw;
-        h.state_cnt = a.state_cnt; h.state_thr = a.state_thr; h.gthr = a.gthr; h.xcd_bar = a.xcd_bar;
-        h.xcd_wgs = a.xcd_wgs;
+        h.state_cnt = a.state_cnt; h.state_thr = a.state_thr; h.gthr = a.gthr;
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev0, s));
         hb_knn_f16_launch(&h, sc.G, s);
         HB_HIP(hipGetLastError());

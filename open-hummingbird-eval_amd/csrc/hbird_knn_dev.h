@@ -23,8 +23,6 @@ struct knn_args {
     int* state_cnt;     // pools only: fill count and threshold per (slot, query), kept between segments
     float* state_thr;
     unsigned* gthr;     // [query]: shared threshold floor (monotone key of a score that k rows are known to reach)
-    unsigned* xcd_bar;  // [8]: arrival counters of the XCD-wide rendezvous of the grid rounds
-    int xcd_wgs;        // workgroups per XCD (launch size / 8)
 };
 
 __device__ __forceinline__ void glds16(const float* gsrc, char* lds_base) {
@@ -218,25 +216,6 @@ __device__ __forceinline__ float floor_load(const unsigned* gthr, int q) {
 }
 __device__ __forceinline__ void floor_publish(unsigned* gthr, int q, float thr) {
     if (thr > -INFINITY) atomicMax(gthr + q, pool_key(thr));
-}
-
-// Rendezvous of the workgroups of one XCD at the start of a grid round (hb_build_schedule): the round's workgroups
-// share bank and query fragments through the XCD's L2 only while they move in step -- the L2 (4 MiB) turns over in
-// a few microseconds at LDS-DMA rates -- so every round starts aligned.  Purely a performance device: the wait is
-// bounded (~0.3 ms of the 100 MHz real-time counter), a workgroup that is late or not resident only costs the others
-// their alignment, never a hang.
-__device__ __forceinline__ void xcd_rendezvous(unsigned* bar, int xcd_wgs, int round) {
-    if (threadIdx.x == 0) {
-        unsigned* c = bar + (blockIdx.x & 7);
-        __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned want = (unsigned)round * (unsigned)xcd_wgs;
-        const unsigned long long t0 = __builtin_readcyclecounter();
-        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-            __builtin_amdgcn_s_sleep(4);
-            if (__builtin_readcyclecounter() - t0 > 1000000ull) break;
-        }
-    }
-    __syncthreads();
 }
 
 // pools: fill counts / thresholds of the wave's 32 queries at the start and the end of a segment

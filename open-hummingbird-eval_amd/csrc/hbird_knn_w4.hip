@@ -80,8 +80,6 @@ __global__ __launch_bounds__(W4_THREADS) void knn_fused_w4_kernel(knn_args a) {
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
     for (int si = seg_begin; si < seg_end; ++si) {
         const hb_seg seg = a.segs[si];
-        if (seg.sync) xcd_rendezvous(a.xcd_bar, a.xcd_wgs, seg.sync);
-        if (seg.n_tiles == 0) continue;
         float* wl_s = a.state_s + (size_t)seg.slot * HB_QT * klw;
         unsigned* wl_i = a.state_i + (size_t)seg.slot * HB_QT * klw;
         float thr[2];

@@ -206,19 +206,14 @@ class HipFlatIndex:
         _lib.check(_lib.lib().hb_index_last_fp16_fallbacks(self._h, ctypes.byref(n)))
         return int(n.value)
 
-    def set_schedule(self, mode: int):
-        """0 = XCD grid rounds (default), 1 = linear ranges; same results."""
-        _lib.check(_lib.lib().hb_index_set_schedule(self._h, int(mode)))
-
     def set_variant(self, variant: int):
         _lib.check(_lib.lib().hb_index_set_variant(self._h, int(variant)))
 
     def schedule_info(self) -> dict:
         out = (ctypes.c_int64 * 8)()
         _lib.check(_lib.lib().hb_index_schedule_info(self._h, out))
-        keys = ["workgroups", "segments", "slots", "panel_tiles", "max_slots_per_qtile", "query_tiles", "bank_tiles",
-                "mode"]
-        return dict(zip(keys, list(out)[:8]))
+        keys = ["workgroups", "segments", "slots", "panel_tiles", "max_slots_per_qtile", "query_tiles", "bank_tiles"]
+        return dict(zip(keys, list(out)[:7]))
 
 
 def merge_topk(dist_parts: torch.Tensor, idx_parts: torch.Tensor, metric: int):
