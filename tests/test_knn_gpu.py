@@ -212,6 +212,40 @@ def test_full_batch_properties_at_scale(cuda_device, M, D, nq):
     _check_exact(idx[sel.to(dev)], dist[sel.to(dev)], q[sel.to(dev)].cpu().numpy(), bank, k, "dot_product")
 
 
+def _random_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for i in range(n):
+        M = int(rng.choice([1, 31, 255, 256, 257, 1000, 4097, 20000]))
+        D = int(rng.choice([1, 7, 8, 17, 64, 100, 384, 768]))
+        nq = int(rng.choice([1, 32, 255, 256, 257, 700]))
+        k = int(rng.choice([1, 2, 29, 32, 33, 64, 65, 130, 256]))
+        metric = str(rng.choice(["dot_product", "l2"]))
+        fp16 = bool(rng.integers(0, 2)) and k <= 128
+        G = int(rng.choice([0, 1, 7, 64, 300]))
+        panel = int(rng.choice([0, 1, 3, 16]))
+        cases.append((M, D, nq, k, metric, fp16, G, panel, 1000 + i))
+    return cases
+
+
+@pytest.mark.parametrize("M,D,nq,k,metric,fp16,G,panel,seed", _random_cases(24, seed=2026))
+def test_seeded_random_shapes_bit_exact(cuda_device, M, D, nq, k, metric, fp16, G, panel, seed):
+    """A seeded sweep over ragged sizes (rows / dims / queries around the 256 and 32 tile edges), k on both sides of the
+    LDS-list and pool limits, both metrics, fp16 mode, and arbitrary work partitions: always the oracle's bits."""
+    rng = np.random.default_rng(seed)
+    bank = gi.unit_bank(M, D, seed=seed)
+    if M > 40:
+        bank[rng.integers(0, M, size=5)] = bank[0]          # a few exact ties
+    q = gi.vit_like_queries(nq, D, seed=seed + 1)
+    ix = HipFlatIndex(D, 0 if metric == "dot_product" else 1, 0)
+    half = M // 2
+    ix.add(bank[:half]); ix.add(torch.from_numpy(bank[half:]).cuda())     # host + device appends
+    ix.set_fp16(fp16)
+    ix.set_tuning(G, panel)
+    idx, dist = ix.search(torch.from_numpy(q).cuda(), k, id_base=7)
+    _check_exact(idx, dist, q, bank, k, metric, id_base=7)
+
+
 @pytest.mark.parametrize("M,D,nq,k,metric", [
     (3000, 32, 70, 33, "dot_product"),
     (5000, 64, 300, 64, "dot_product"),
