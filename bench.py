@@ -179,7 +179,7 @@ def main():
             return index.search_aggregate(q, k, beta=0.02)
         # every rank searches all queries on its shard; one all-gather of the per-rank top-k + local merge;
         # each rank then aggregates the labels for its own slice of the queries
-        idx, dist = hdist.sharded_search(index.search, merge_topk, q, k, lo, 0)
+        idx, dist = hdist.sharded_search(index.search_scores, merge_topk, q, k, lo, 0, finish=index.distances_from_scores)
         return index.aggregate(q[qs_lo:qs_hi], idx[qs_lo:qs_hi], dist[qs_lo:qs_hi], beta=0.02)
 
     def sync():

@@ -79,6 +79,14 @@ int hb_index_set_label_table(hb_index_t* ix, const float* labels, const float* n
                              int64_t id_base);
 int hb_index_copy_norms(hb_index_t* ix, float* out, int on_device);
 
+/* Sharded searches (faiss.IndexShards, search_faiss.py:53-63): with score output enabled a search returns the
+ * ORDERING score in out_dist (inner product: q.b; L2: q.b - |b|^2/2; larger is better; missing neighbours -inf)
+ * instead of the metric's distance.  Squared L2 distances round away differences that the ordering still sees, so the
+ * cross-shard merge must run on the scores (hb_merge_topk with metric 0) to reproduce the single-index order bit for
+ * bit; hb_index_distances_from_scores then converts the merged scores in place (device pointers; a no-op for the
+ * inner product) exactly as the single-index search does. */
+int hb_index_set_score_output(hb_index_t* ix, int enable);
+int hb_index_distances_from_scores(hb_index_t* ix, const float* q, int64_t nq, int k, float* dist_inout);
 /* k-way merge of per-shard results laid out [parts][nq][k] (faiss.IndexShards' merge, search_faiss.py:
  * 53-63; here fed by an RCCL all-gather).  Device pointers. */
 int hb_merge_topk(const float* dist_parts, const int64_t* idx_parts, int parts, int64_t nq, int k, int metric,

@@ -3,10 +3,31 @@
 #include "hbird_internal.h"
 #include <cmath>
 #include <cstring>
+#include <dlfcn.h>
 
 static thread_local std::string g_err;
 void hb_set_error(const std::string& msg) { g_err = msg; }
 int hb_fail(const std::string& msg) { g_err = msg; return -1; }
+
+namespace {
+struct roctx_api {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    roctx_api() {
+        for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            void* h = dlopen(lib, RTLD_LAZY | RTLD_GLOBAL);
+            if (!h) continue;
+            push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+const roctx_api& roctx() { static const roctx_api api; return api; }
+}  // namespace
+hb_range::hb_range(const char* name) { if (roctx().push) roctx().push(name); }
+hb_range::~hb_range() { if (roctx().pop) roctx().pop(); }
 
 extern "C" const char* hb_last_error(void) { return g_err.c_str(); }
 
@@ -167,6 +188,7 @@ extern "C" int hb_index_add(hb_index_t* ix, const float* x, int64_t n, int x_on_
     if (n < 0) return hb_fail("hb_index_add: negative row count");
     if (n == 0) return 0;
     if (!x) return hb_fail("hb_index_add: x is NULL");
+    hb_range range("hbird:index_add");
     HB_HIP(hipSetDevice(ix->device));
     if (ix->ntotal + n > ix->cap_rows) {
         int64_t want = std::max<int64_t>(ix->ntotal + n, ix->cap_rows + ix->cap_rows / 2);
@@ -224,6 +246,7 @@ static int search_impl(hb_index* ix, const float* q, int64_t nq, int k, int64_t 
     if (k < 1 || k > HB_MAX_K) return hb_fail("hb_index_search: k must be in [1, " + std::to_string(HB_MAX_K) + "]");
     if (nq == 0) return 0;
     if (!q) return hb_fail("hb_index_search: q is NULL");
+    hb_range range(aggregate ? "hbird:search_aggregate" : "hbird:search");
     HB_HIP(hipSetDevice(ix->device));
     const int64_t nqp = (nq + HB_QT - 1) / HB_QT * HB_QT;
     if (grow((void**)&ix->q_tiles, &ix->q_tiles_bytes, (size_t)nqp * ix->dp * 4)) return -1;
@@ -248,10 +271,17 @@ static int search_impl(hb_index* ix, const float* q, int64_t nq, int k, int64_t 
     if (t_idx) { d_idx = (int64_t*)cur; cur += b_idx; }
     if (t_dist) { d_dist = (float*)cur; cur += b_dist; }
     if (b_lab) { d_lab = (float*)cur; cur += b_lab; }
-    if (hb_launch_rows_to_tiles(qd, nq, ix->d, ix->dp, 0, ix->q_tiles, nullptr, nullptr, ix->metric, 0, 0, ix->stream)) return -1;
-    if (hb_launch_query_aux(qd, nq, ix->d, ix->q_aux, ix->q_aux + nq, ix->stream)) return -1;
-    if (hb_launch_knn(ix, qd, nq, k, id_base, d_idx, d_dist)) return -1;
+    {
+        hb_range r("hbird:query_tiles");
+        if (hb_launch_rows_to_tiles(qd, nq, ix->d, ix->dp, 0, ix->q_tiles, nullptr, nullptr, ix->metric, 0, 0, ix->stream)) return -1;
+        if (hb_launch_query_aux(qd, nq, ix->d, ix->q_aux, ix->q_aux + nq, ix->stream)) return -1;
+    }
+    {
+        hb_range r("hbird:knn");
+        if (hb_launch_knn(ix, qd, nq, k, id_base, d_idx, d_dist)) return -1;
+    }
     if (aggregate) {
+        hb_range r("hbird:aggregate");
         if (hb_launch_aggregate(ix, ix->q_aux + nq, d_idx, d_dist, nq, k, id_base, beta, d_lab, ix->stream)) return -1;
     }
     if (!io_on_device) {
@@ -283,6 +313,7 @@ extern "C" int hb_index_aggregate(hb_index_t* ix, const float* q, int64_t nq, co
     if (nq == 0) return 0;
     if (!io_on_device) return hb_fail("hb_index_aggregate: host pointers are not supported, pass device memory");
     if (!(beta > 0.f)) return hb_fail("hb_index_aggregate: beta must be positive");
+    hb_range range("hbird:aggregate");
     HB_HIP(hipSetDevice(ix->device));
     if (grow((void**)&ix->q_aux, &ix->q_aux_bytes, (size_t)nq * 2 * 4)) return -1;
     if (hb_launch_query_aux(q, nq, ix->d, ix->q_aux, ix->q_aux + nq, ix->stream)) return -1;
@@ -343,8 +374,20 @@ extern "C" int hb_index_copy_norms(hb_index_t* ix, float* out, int on_device) {
     return 0;
 }
 
+extern "C" int hb_index_set_score_output(hb_index_t* ix, int enable) { ix->score_output = enable ? 1 : 0; return 0; }
+
+extern "C" int hb_index_distances_from_scores(hb_index_t* ix, const float* q, int64_t nq, int k, float* dist_inout) {
+    if (nq == 0 || ix->metric != 1) return 0;            // inner product: the score is the distance
+    if (!q || !dist_inout) return hb_fail("hb_index_distances_from_scores: NULL pointer");
+    HB_HIP(hipSetDevice(ix->device));
+    if (grow((void**)&ix->q_aux, &ix->q_aux_bytes, (size_t)nq * 2 * 4)) return -1;
+    if (hb_launch_query_aux(q, nq, ix->d, ix->q_aux, ix->q_aux + nq, ix->stream)) return -1;
+    return hb_launch_scores_to_l2(ix->q_aux, nq, k, dist_inout, ix->stream);
+}
+
 extern "C" int hb_merge_topk(const float* dist_parts, const int64_t* idx_parts, int parts, int64_t nq, int k, int metric,
                              int64_t* out_idx, float* out_dist, void* stream) {
+    hb_range range("hbird:merge_topk");
     if (parts < 1 || k < 1) return hb_fail("hb_merge_topk: bad shape");
     return hb_launch_merge_parts(dist_parts, idx_parts, parts, nq, k, metric, out_idx, out_dist, (hipStream_t)stream);
 }
@@ -354,6 +397,7 @@ extern "C" int hb_normalize_rows(const float* x, int64_t n, int d, float* out, v
 }
 extern "C" int hb_patch_label_hist(const int64_t* y, int64_t B, int H, int W, int ps, int C, int map255, float* out,
                                    void* stream) {
+    hb_range range("hbird:patch_label_hist");
     return hb_launch_patch_label_hist(y, B, H, W, ps, C, map255, out, (hipStream_t)stream);
 }
 extern "C" int hb_gather_rows(const float* src, int64_t src_rows, int width, const int64_t* ids, int64_t n, float* out,
@@ -362,10 +406,12 @@ extern "C" int hb_gather_rows(const float* src, int64_t src_rows, int width, con
 }
 extern "C" int hb_upsample_argmax(const float* label_hat, int64_t B, int S, int C, int h, int w, int64_t* out,
                                   void* stream) {
+    hb_range range("hbird:upsample_argmax");
     return hb_launch_upsample_argmax(label_hat, B, S, C, h, w, out, (hipStream_t)stream);
 }
 extern "C" int hb_upsample_accumulate(const float* label_hat, int64_t B, int S, int C, int win_h, int win_w, float* acc,
                                       int H, int W, int y0, int x0, void* stream) {
+    hb_range range("hbird:upsample_accumulate");
     return hb_launch_upsample_accumulate(label_hat, B, S, C, win_h, win_w, acc, H, W, y0, x0, (hipStream_t)stream);
 }
 extern "C" int hb_argmax_channels(const float* acc, int64_t n, int C, int64_t* out, void* stream) {
@@ -373,6 +419,7 @@ extern "C" int hb_argmax_channels(const float* acc, int64_t n, int C, int64_t* o
 }
 extern "C" int hb_confusion_update(const int64_t* gt, const int64_t* pred, int64_t n, int num_gt, int num_pred,
                                    int64_t ignore_index, int has_ignore, uint64_t* conf, void* stream) {
+    hb_range range("hbird:confusion_update");
     return hb_launch_confusion(gt, pred, n, num_gt, num_pred, ignore_index, has_ignore, (unsigned long long*)conf,
                                (hipStream_t)stream);
 }

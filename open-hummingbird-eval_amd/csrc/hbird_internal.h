@@ -23,6 +23,15 @@
 
 #define HB_ID_NONE 0xFFFFFFFFu
 
+// Optional ROCTx range around a host-side phase (shows up under `rocprofv3 --marker-trace`).  The marker library
+// (librocprofiler-sdk-roctx.so, else libroctx64.so) is looked up at run time; without it the ranges are no-ops.
+struct hb_range {
+    explicit hb_range(const char* name);
+    ~hb_range();
+    hb_range(const hb_range&) = delete;
+    hb_range& operator=(const hb_range&) = delete;
+};
+
 struct hb_seg {
     int q_tile;    // query tile index (HB_QT rows)
     int b_tile0;   // first bank tile (HB_BT rows)
@@ -74,6 +83,7 @@ struct hb_index {
     char* mtmp = nullptr; size_t mtmp_bytes = 0;         // first-level lists of a two-level merge
     char* fb = nullptr; size_t fb_bytes = 0;             // fallback workspace (uncertified queries)
     int64_t last_fp16_fallbacks = 0;
+    int score_output = 0;                                // 1: searches return ordering scores instead of distances
     int variant = 0;                                     // 0: 8-wave kernel, 1: 4-wave (one wave per SIMD) kernel
     int ablate = 0;                                      // timing-only kernel ablation (HB_ABLATION builds)
     double last_knn_ms = 0.0;                            // HIP-event time of the last knn kernel launch
@@ -93,6 +103,7 @@ int hb_fail(const std::string& msg);
 // kernels/launchers (each returns 0 or a negative status after hb_set_error)
 int hb_launch_rows_to_tiles(const float* src, int64_t n_rows, int d, int dp, int64_t row0, float* tiles,
                             float* binit, float* bnorm, int metric, int normalize, int is_bank, hipStream_t s);
+int hb_launch_scores_to_l2(const float* qn2, int64_t nq, int k, float* dist_inout, hipStream_t s);
 int hb_launch_query_aux(const float* q, int64_t nq, int d, float* qn2, float* qnorm, hipStream_t s);
 int hb_launch_tiles_to_rows(const float* tiles, int g8, int d, const int64_t* ids, int64_t n, int64_t id_base,
                             float* out, hipStream_t s);
@@ -100,12 +111,13 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
 int hb_launch_tiles_to_f16(const float* t32, int g8, _Float16* t16, int g16, int64_t n_row_tiles, int64_t rt0, hipStream_t s);
 int hb_launch_rerank(const float* tiles, const float* binit, int g8, int d, const float* q, const float* qn2,
                      const int64_t* cand, const float* cand_score, const float* qnorm, const float* bmax,
-                     unsigned char* certified, int kc, int64_t nq, int k, int64_t id_base, int metric, int64_t* out_idx,
+                     unsigned char* certified, int kc, int64_t nq, int k, int64_t id_base, int metric, int out_metric, int64_t* out_idx,
                      float* out_dist, hipStream_t s);
 int hb_launch_bnorm_max(const float* bnorm, int64_t n, float* bmax, hipStream_t s);
 int hb_launch_scatter_rows(const int64_t* rows, int64_t n, int k, const int64_t* src_idx, const float* src_dist,
                            int64_t* out_idx, float* out_dist, hipStream_t s);
-void hb_knn_f16_launch(const void* args, int grid, hipStream_t s);
+struct knn16_args;
+int hb_knn_f16_launch(const knn16_args& args, int grid, hipStream_t s);
 int hb_launch_aggregate(const hb_index* ix, const float* qnorm, const int64_t* idx, const float* dist, int64_t nq,
                         int k, int64_t id_base, float beta, float* out, hipStream_t s);
 int hb_launch_merge_parts(const float* dist_parts, const int64_t* idx_parts, int parts, int64_t nq, int k, int metric,

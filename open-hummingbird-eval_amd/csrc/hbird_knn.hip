@@ -440,11 +440,6 @@ void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out) {
 
 
 // q_tiles / q_aux must already be prepared by the caller (hb_index_search).
-struct knn16_args_host {   // must match knn16_args in hbird_knn_f16.hip
-    const void* bank16; const float* binit; const void* q16; const hb_seg* segs; const int* wg_off;
-    float* state_s; unsigned* state_i; int g16, k, klw; int* state_cnt; float* state_thr; unsigned* gthr;
-};
-
 int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t id_base, int64_t* out_idx, float* out_dist) {
     if (k < 1 || k > 256) return hb_fail("hb_index_search: k must be in [1, 256]");
     const bool f16 = ix->fp16 != 0 && k <= 128;
@@ -454,13 +449,15 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // pools (k > HB_KL): capacity >= 2 kc so that a compaction is paid for by >= kc cheap appends
     const int klw = wide ? std::min(HB_POOL_MAX, (std::max(2 * kc, kc + 128) + 63) / 64 * 64) : HB_KL;
     if (nq == 0) return 0;
+    // score output (sharded searches): the ordering score goes out as it is, whatever the metric
+    const int out_metric = ix->score_output ? 0 : ix->metric;
     const int nqt = (int)((nq + HB_QT - 1) / HB_QT);
     const int nbt = (int)((ix->ntotal + HB_BT - 1) / HB_BT);
     hipStream_t s = ix->stream;
     if (nbt == 0) {
         // empty index: every neighbour is missing (faiss returns -1 labels)
         std::vector<int64_t> hi((size_t)nq * k, -1);
-        std::vector<float> hd((size_t)nq * k, ix->metric == 1 ? INFINITY : -INFINITY);
+        std::vector<float> hd((size_t)nq * k, out_metric == 1 ? INFINITY : -INFINITY);
         HB_HIP(hipMemcpyAsync(out_idx, hi.data(), hi.size() * 8, hipMemcpyHostToDevice, s));
         HB_HIP(hipMemcpyAsync(out_dist, hd.data(), hd.size() * 4, hipMemcpyHostToDevice, s));
         HB_HIP(hipStreamSynchronize(s));
@@ -524,13 +521,12 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         if (ensure_bytes(&ix->cand, &ix->cand_bytes, (size_t)nq * kc * 12)) return -1;
         int64_t* cand_idx = reinterpret_cast<int64_t*>(ix->cand);
         float* cand_dist = reinterpret_cast<float*>(ix->cand + (size_t)nq * kc * 8);
-        knn16_args_host h;
-        h.bank16 = ix->tiles16; h.binit = ix->binit; h.q16 = ix->q16; h.segs = a.segs; h.wg_off = a.wg_off;
+        knn16_args h;
+        h.bank16 = reinterpret_cast<const _Float16*>(ix->tiles16); h.binit = ix->binit; h.q16 = reinterpret_cast<const _Float16*>(ix->q16); h.segs = a.segs; h.wg_off = a.wg_off;
         h.state_s = a.state_s; h.state_i = a.state_i; h.g16 = ix->dp16 / 16; h.k = kc; h.klw = klw;
         h.state_cnt = a.state_cnt; h.state_thr = a.state_thr; h.gthr = a.gthr;
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev0, s));
-        hb_knn_f16_launch(&h, sc.G, s);
-        HB_HIP(hipGetLastError());
+        if (hb_knn_f16_launch(h, sc.G, s)) return -1;
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
         if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
                          reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, kc, klw, 0, 0, nullptr,
@@ -538,7 +534,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         if (ensure_bytes(&ix->fb, &ix->fb_bytes, (size_t)nq + 64)) return -1;
         unsigned char* cert = reinterpret_cast<unsigned char*>(ix->fb);
         if (hb_launch_rerank(ix->tiles, ix->binit, ix->g8, ix->d, q_dev, ix->q_aux, cand_idx, cand_dist, ix->q_aux + nq, ix->bmax,
-                             cert, kc, nq, k, id_base, ix->metric, out_idx, out_dist, s)) return -1;
+                             cert, kc, nq, k, id_base, ix->metric, out_metric, out_idx, out_dist, s)) return -1;
         if (ix->time_kernels) {
             HB_HIP(hipEventSynchronize(ix->ev1));
             float ms = 0.f;
@@ -621,7 +617,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
     const float* qn2 = ix->q_aux;   // [nq] chain ||q||^2 (valid for L2)
     if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
-                     reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, k, klw, id_base, ix->metric,
+                     reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, k, klw, id_base, out_metric,
                      qn2, out_idx, out_dist, s)) return -1;
     if (ix->time_kernels) {
         HB_HIP(hipEventSynchronize(ix->ev1));

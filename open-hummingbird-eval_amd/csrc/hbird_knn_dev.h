@@ -25,6 +25,23 @@ struct knn_args {
     unsigned* gthr;     // [query]: shared threshold floor (monotone key of a score that k rows are known to reach)
 };
 
+// arguments of the fp16 candidate kernel (hbird_knn_f16.hip); the fields shared with knn_args mean the same
+struct knn16_args {
+    const _Float16* bank16;   // fp16 copies of the bank fragment tiles
+    const float* binit;
+    const _Float16* q16;      // fp16 copies of the query fragment tiles
+    const hb_seg* segs;
+    const int* wg_off;
+    float* state_s;
+    unsigned* state_i;
+    int g16;   // Dp16 / 16
+    int k;     // k' (candidates per query)
+    int klw;   // pool capacity
+    int* state_cnt;
+    float* state_thr;
+    unsigned* gthr;
+};
+
 __device__ __forceinline__ void glds16(const float* gsrc, char* lds_base) {
     // 64 lanes x 16 B: per-lane global source, LDS destination = wave-uniform base + 16*lane
     __builtin_amdgcn_global_load_lds((gbl_cvoid*)gsrc, (lds_void*)lds_base, 16, 0, 0);

@@ -65,22 +65,6 @@ int hb_launch_tiles_to_f16(const float* t32, int g8, _Float16* t16, int g16, int
     return 0;
 }
 
-struct knn16_args {
-    const _Float16* bank16;
-    const float* binit;
-    const _Float16* q16;
-    const hb_seg* segs;
-    const int* wg_off;
-    float* state_s;
-    unsigned* state_i;
-    int g16;   // Dp16 / 16
-    int k;     // k' (candidates per query)
-    int klw;   // pool capacity
-    int* state_cnt;
-    float* state_thr;
-    unsigned* gthr;
-};
-
 // 8 waves (two per SIMD); wave w owns queries [32w, 32w + 32) against all 256 bank rows of the tile (8 accumulator
 // tiles).  The kernel is bound by the latency of its LDS-DMA stream: a stage is usable when its last line has arrived
 // (about 2.5 us from the Infinity Cache) and the bytes in flight are capped by the LDS, so the ring keeps every slot but
@@ -191,7 +175,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ t
                                                      const int64_t* __restrict__ cand, const float* __restrict__ cand_score,
                                                      const float* __restrict__ qnorm, const float* __restrict__ bmax,
                                                      unsigned char* __restrict__ certified, int kc, int64_t nq, int k,
-                                                     int64_t id_base, int metric, int64_t* __restrict__ out_idx,
+                                                     int64_t id_base, int metric, int out_metric, int64_t* __restrict__ out_idx,
                                                      float* __restrict__ out_dist) {
     __shared__ float s_sc[4][256];
     __shared__ int64_t s_id[4][256];
@@ -250,10 +234,10 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ t
         }
         if (rank < k) {
             const int64_t o = qi * (int64_t)k + rank;
-            if (id < 0) { out_idx[o] = -1; out_dist[o] = metric == 1 ? INFINITY : -INFINITY; }
+            if (id < 0) { out_idx[o] = -1; out_dist[o] = out_metric == 1 ? INFINITY : -INFINITY; }
             else {
                 out_idx[o] = id + id_base;
-                if (metric == 1) { const float d2 = fmaf(-2.0f, s, qn2[qi]); out_dist[o] = d2 > 0.0f ? d2 : 0.0f; }
+                if (out_metric == 1) { const float d2 = fmaf(-2.0f, s, qn2[qi]); out_dist[o] = d2 > 0.0f ? d2 : 0.0f; }
                 else out_dist[o] = s;
             }
         }
@@ -262,20 +246,22 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ t
 
 int hb_launch_rerank(const float* tiles, const float* binit, int g8, int d, const float* q, const float* qn2,
                      const int64_t* cand, const float* cand_score, const float* qnorm, const float* bmax,
-                     unsigned char* certified, int kc, int64_t nq, int k, int64_t id_base, int metric, int64_t* out_idx,
-                     float* out_dist, hipStream_t s) {
+                     unsigned char* certified, int kc, int64_t nq, int k, int64_t id_base, int metric, int out_metric,
+                     int64_t* out_idx, float* out_dist, hipStream_t s) {
     if (nq == 0) return 0;
     if (kc > 256) return hb_fail("hb_index_search: too many candidates for the re-rank kernel");
     rerank_kernel<<<dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s>>>(tiles, binit, g8, d, q, qn2, cand, cand_score, qnorm, bmax,
-                                                                     certified, kc, nq, k, id_base, metric, out_idx, out_dist);
+                                                                     certified, kc, nq, k, id_base, metric, out_metric, out_idx, out_dist);
     HB_HIP(hipGetLastError());
     return 0;
 }
 
-void hb_knn_f16_launch(const void* args, int grid, hipStream_t s) {
+int hb_knn_f16_launch(const knn16_args& args, int grid, hipStream_t s) {
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)knn_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F16_LDS_TOTAL); attr = true; }
-    knn_f16_kernel<<<dim3((unsigned)grid), dim3(HB_THREADS), F16_LDS_TOTAL, s>>>(*reinterpret_cast<const knn16_args*>(args));
+    if (!attr) { HB_HIP(hipFuncSetAttribute((const void*)knn_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F16_LDS_TOTAL)); attr = true; }
+    knn_f16_kernel<<<dim3((unsigned)grid), dim3(HB_THREADS), F16_LDS_TOTAL, s>>>(args);
+    HB_HIP(hipGetLastError());
+    return 0;
 }
 
 // max over bank-row norms (all positive), kept in a device scalar for the certificate above

@@ -140,6 +140,25 @@ __global__ __launch_bounds__(256) void query_aux_kernel(const float* __restrict_
     qnorm[r] = (float)sqrt(a2);
 }
 
+// sharded searches: ordering scores s = q.b - |b|^2/2 of the L2 metric -> squared distances, exactly as the
+// single-index merge converts them: d = max(0, fma(-2, s, |q|^2)) with the chain |q|^2; missing neighbours -> +inf
+__global__ __launch_bounds__(256) void scores_to_l2_kernel(const float* __restrict__ qn2, int64_t n, int k, float* __restrict__ dist) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float s = dist[i];
+    if (s == -INFINITY) { dist[i] = INFINITY; return; }
+    const float d2 = fmaf(-2.0f, s, qn2[i / k]);
+    dist[i] = d2 > 0.0f ? d2 : 0.0f;
+}
+
+int hb_launch_scores_to_l2(const float* qn2, int64_t nq, int k, float* dist_inout, hipStream_t s) {
+    const int64_t n = nq * k;
+    if (n == 0) return 0;
+    scores_to_l2_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(qn2, n, k, dist_inout);
+    HB_HIP(hipGetLastError());
+    return 0;
+}
+
 int hb_launch_query_aux(const float* q, int64_t nq, int d, float* qn2, float* qnorm, hipStream_t s) {
     if (nq == 0) return 0;
     query_aux_kernel<<<dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s>>>(q, nq, d, qn2, qnorm);

@@ -37,6 +37,8 @@ SIGNATURES = {
     "hb_index_gather_labels": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int]),
     "hb_index_set_label_table": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64]),
     "hb_index_copy_norms": (c_int, [c_void_p, c_void_p, c_int]),
+    "hb_index_set_score_output": (c_int, [c_void_p, c_int]),
+    "hb_index_distances_from_scores": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "hb_merge_topk": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "hb_normalize_rows": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "hb_patch_label_hist": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

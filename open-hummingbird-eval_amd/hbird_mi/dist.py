@@ -8,7 +8,7 @@ Message sizes at cfg-3 (21,904 queries, k = 30): 21,904 x 30 x (8 + 4) B = 7.9 M
 """
 from __future__ import annotations
 
-from typing import Callable, List, Tuple
+from typing import Callable, Optional, List, Tuple
 
 import torch
 import torch.distributed as td
@@ -51,19 +51,24 @@ def allgather_rows(x: torch.Tensor) -> Tuple[torch.Tensor, List[int]]:
     return out.view((world,) + tuple(pad.shape)), counts
 
 
-def sharded_search(local_search: Callable, merge: Callable, q: torch.Tensor, k: int, id_base: int, metric: int):
+def sharded_search(local_search: Callable, merge: Callable, q: torch.Tensor, k: int, id_base: int, metric: int,
+                   finish: Optional[Callable] = None):
     """Every rank searches ALL queries on its shard, the per-rank lists are all-gathered and merged.
 
     local_search(q, k, id_base) -> (idx int64 [nq,k] global ids, dist fp32 [nq,k]);
     merge(dist_parts [world,nq,k], idx_parts [world,nq,k], metric) -> (idx, dist).
+    With `finish`, local_search returns ORDERING scores (larger is better) instead of distances, the merge runs on them
+    (metric 0 ordering) and finish(q, scores) -> distances converts the merged list: squared L2 distances round away
+    score differences that the single-index search still orders by, so only this reproduces it bit for bit.
     Every rank ends up with the same merged result (faiss.IndexShards semantics)."""
     rank, world = rank_world()
     idx, dist = local_search(q, k, id_base)
     if world == 1:
-        return idx, dist
+        return idx, (finish(q, dist) if finish else dist)
     nq = idx.shape[0]
     pi = torch.empty((world * nq, k), dtype=idx.dtype, device=idx.device)
     pd = torch.empty((world * nq, k), dtype=dist.dtype, device=dist.device)
     td.all_gather_into_tensor(pi, idx.contiguous())
     td.all_gather_into_tensor(pd, dist.contiguous())
-    return merge(pd.view(world, nq, k), pi.view(world, nq, k), metric)
+    mi, md = merge(pd.view(world, nq, k), pi.view(world, nq, k), 0 if finish else metric)
+    return mi, (finish(q, md) if finish else md)

@@ -268,7 +268,8 @@ class HbirdEvaluation:
         self.index.use_current_stream()
         if not self.sharded:
             return self.index.search(q_flat, k, id_base=self.id_base)
-        return hdist.sharded_search(self.index.search, merge_topk, q_flat, k, self.id_base, self.metric)
+        return hdist.sharded_search(self.index.search_scores, merge_topk, q_flat, k, self.id_base, self.metric,
+                                    finish=self.index.distances_from_scores)
 
     def _label_hat(self, feats: torch.Tensor, want_details: bool):
         """feats [B,N,D] -> label_hat [B,N,C] (+ neighbours when details are requested)."""

@@ -92,6 +92,23 @@ class HipFlatIndex:
             return False, x
         return False, np.ascontiguousarray(x, dtype=np.float32)
 
+    def search_scores(self, q, k: int, id_base: int = 0):
+        """Like `search`, but the second output holds the ORDERING scores (larger is better; L2: q.b - |b|^2/2), the
+        input of a cross-shard merge (hb_index_set_score_output); convert with `distances_from_scores`."""
+        lib = _lib.lib()
+        _lib.check(lib.hb_index_set_score_output(self._h, 1))
+        try:
+            return self.search(q, k, id_base)
+        finally:
+            _lib.check(lib.hb_index_set_score_output(self._h, 0))
+
+    def distances_from_scores(self, q: torch.Tensor, scores: torch.Tensor) -> torch.Tensor:
+        """Merged ordering scores [nq,k] (CUDA) -> the metric's distances, in place (no-op for the inner product)."""
+        assert q.is_cuda and scores.is_cuda and scores.is_contiguous() and scores.dtype == torch.float32
+        q = q.contiguous().float()
+        _lib.check(_lib.lib().hb_index_distances_from_scores(self._h, _ptr(q), q.shape[0], scores.shape[1], _ptr(scores)))
+        return scores
+
     def search(self, q, k: int, id_base: int = 0):
         """-> (idx int64 [nq,k], dist float32 [nq,k]); torch CUDA tensors for CUDA queries, numpy otherwise."""
         on_dev, q = self._as_f32(q)
@@ -305,6 +322,6 @@ class NearestNeighborSearchHIP(NearestNeighborSearchBase):
         self.index.use_current_stream()
         if self.idx_shard and self.world > 1:
             from hbird_mi import dist as hdist
-            return hdist.sharded_search(self.index.search, merge_topk, q, k, self.id_base,
-                                        _METRICS[self.distance_measure])
+            return hdist.sharded_search(self.index.search_scores, merge_topk, q, k, self.id_base,
+                                        _METRICS[self.distance_measure], finish=self.index.distances_from_scores)
         return self.index.search(q, k, self.id_base)

@@ -104,3 +104,40 @@ def test_two_rank_sliding_window_evaluation_equals_single_process(cuda_device):
     assert ret[(2, 0)][1] == ret[(2, 1)][1] == single[1]
     assert ret[(2, 0)][2] == ret[(2, 1)][2]
     assert abs(ret[(2, 0)][2] - single[2]) < 1e-6, dict(ret)
+
+
+def _l2_worker(rank, world, port, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "open-hummingbird-eval_amd"), os.path.join(root, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as td
+    if world > 1:
+        td.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import golden_inputs as gi
+    from hbird_mi.nn.search_hip import NearestNeighborSearchHIP
+    M, D, nq, k = 60_000, 48, 500, 30
+    bank = gi.unit_bank(M, D, seed=5)
+    q = gi.vit_like_queries(nq, D, seed=6)
+    nn = NearestNeighborSearchHIP(torch.from_numpy(bank), n_neighbors=k, distance_measure="l2", gpu_ids=[0], idx_shard=True)
+    idx, dist = nn.find_nearest_neighbors(torch.from_numpy(q))
+    ret[(world, rank)] = (np.asarray(idx).copy(), np.asarray(dist).copy())
+    if world > 1:
+        td.destroy_process_group()
+
+
+def test_two_rank_l2_plugin_search_is_bit_identical_to_single_process(cuda_device):
+    """The reference-named plugin under the L2 metric with a row-sharded bank: same indices and the same distance bits
+    as one process (the cross-shard merge runs on ordering scores, not on rounded squared distances)."""
+    import oracle
+    import golden_inputs as gi
+    ret = mp.Manager().dict()
+    mp.spawn(_l2_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+    mp.spawn(_l2_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    i1, d1 = ret[(1, 0)]
+    for r in (0, 1):
+        i2, d2 = ret[(2, r)]
+        assert np.array_equal(i1, i2) and np.array_equal(d1.view(np.uint32), d2.view(np.uint32))
+    ridx, rdist = oracle.knn_chain_f32(gi.vit_like_queries(500, 48, seed=6), gi.unit_bank(60_000, 48, seed=5), 30, "l2")
+    assert np.array_equal(i1, ridx) and np.array_equal(d1.view(np.uint32), rdist.view(np.uint32))

@@ -456,3 +456,51 @@ def test_few_queries_against_a_big_bank_two_level_merge(cuda_device, k, fp16):
     idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
     assert ix.schedule_info()["max_slots_per_qtile"] == 256
     _check_exact(idx, dist, q, bank, k, "dot_product")
+
+
+@pytest.mark.parametrize("metric", ["dot_product", "l2"])
+def test_repeatable_and_invariant_under_1_2_4_8_way_sharding(cuda_device, metric):
+    """The slots exchange threshold floors while they run, so which scores are filtered early depends on timing -- the
+    answer must not: ten searches return the same bits, and so does the bank cut into 2, 4 or 8 row shards (each its
+    own index with successive ids; per-shard ORDERING scores merged by hb_merge_topk, then converted -- the multi-GPU
+    path on one device.  Merging squared L2 distances instead would reorder rows whose distances round equal)."""
+    from hbird_mi.nn.search_hip import merge_topk
+    M, D, nq, k = 120_000, 64, 600, 30
+    bank = gi.unit_bank(M, D, seed=77)
+    bank[50_000:50_040] = bank[7]                        # ties that straddle shard boundaries
+    bank[119_990:] = bank[7]
+    q = gi.vit_like_queries(nq, D, seed=78)
+    q[:20] = 3.0 * bank[7]
+    m = 0 if metric == "dot_product" else 1
+    qd = torch.from_numpy(q).cuda()
+    ix = HipFlatIndex(D, m, 0)
+    ix.add(torch.from_numpy(bank).cuda())
+    ix.set_tuning(64, 8)                                 # many segments and slots per query tile
+    ref_i, ref_d = ix.search(qd, k)
+    _check_exact(ref_i, ref_d, q, bank, k, metric)
+    for _ in range(9):
+        i2, d2 = ix.search(qd, k)
+        assert torch.equal(i2, ref_i) and torch.equal(d2.view(torch.int32), ref_d.view(torch.int32))
+    for parts in (2, 4, 8):
+        per = (M + parts - 1) // parts
+        idxs, dists = [], []
+        for p in range(parts):
+            lo, hi = p * per, min(M, (p + 1) * per)
+            sh = HipFlatIndex(D, m, 0)
+            sh.add(torch.from_numpy(bank[lo:hi]).cuda())
+            i, sc = sh.search_scores(qd, k, id_base=lo)
+            idxs.append(i); dists.append(sc)
+        im, dm = merge_topk(torch.stack(dists), torch.stack(idxs), 0)
+        dm = ix.distances_from_scores(qd, dm.contiguous())
+        assert torch.equal(im, ref_i), parts
+        assert torch.equal(dm.view(torch.int32), ref_d.view(torch.int32)), parts
+    # score output: inner product = the distance itself; L2 = q.b - |b|^2 / 2, ordered like the distances
+    i3, s3 = ix.search_scores(qd, k)
+    assert torch.equal(i3, ref_i)
+    if m == 0:
+        assert torch.equal(s3, ref_d)
+    else:
+        assert (s3[:, :-1] >= s3[:, 1:]).all()
+        assert torch.equal(ix.distances_from_scores(qd, s3.clone()).view(torch.int32), ref_d.view(torch.int32))
+    i4, d4 = ix.search(qd, k)                              # the mode does not stick
+    assert torch.equal(d4.view(torch.int32), ref_d.view(torch.int32))
