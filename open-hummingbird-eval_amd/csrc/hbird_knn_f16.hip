@@ -16,21 +16,14 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-#ifndef F16_GROUPS
-#define F16_GROUPS 2                                   // k16 fragment groups per stage
-#endif
-#ifndef F16_RING
-#define F16_RING 4                                     // ring slots: one being computed, the others in flight
-#endif
+#define F16_GROUPS 2                                   // k16 fragment groups per stage (k = 32)
+#define F16_RING 4                                     // ring slots: one being read, three in flight
 #define F16_HALF (8 * F16_GROUPS * 1024)               // bank fragments of a stage, then as many bytes of query fragments
 #define F16_SLOT_BYTES (2 * F16_HALF)
-#define F16_COPIES (4 * F16_GROUPS)                    // 1 KiB copies per stage and issuing wave (waves 0-3)
 #define F16_BINIT (F16_RING * F16_SLOT_BYTES)
 #define F16_SCRATCH (F16_BINIT + 2048)
 #define F16_PCNT (F16_SCRATCH + 8192)                  // pool fill counts of the 256 queries
 #define F16_LDS_TOTAL (F16_PCNT + 1024)
-#define F16_INFLIGHT ((F16_RING - 2) * F16_COPIES)     // copies a wave may leave in flight when it needs the oldest stage
-static_assert(F16_INFLIGHT <= 62, "vmcnt is a 6-bit counter");
 static_assert(F16_LDS_TOTAL <= 160 * 1024, "LDS budget");
 
 // fp32 fragment tiles -> fp16 fragment tiles.  fp16 block(rt, g16) = 32 rows x 16 k = 1 KiB, element (i, kk) at half
@@ -66,11 +59,17 @@ int hb_launch_tiles_to_f16(const float* t32, int g8, _Float16* t16, int g16, int
 }
 
 // 8 waves (two per SIMD); wave w owns queries [32w, 32w + 32) against all 256 bank rows of the tile (8 accumulator
-// tiles).  The kernel is bound by the latency of its LDS-DMA stream: a stage is usable when its last line has arrived
-// (about 2.5 us from the Infinity Cache) and the bytes in flight are capped by the LDS, so the ring keeps every slot but
-// the one being computed in flight.  Measured alternatives that did not pay (10 M x 768, k = 30, kernel ms): 2 slots of
-// k64 388; 4 waves x (64 queries x 256 rows) with 256 AGPR accumulators, compiler-scheduled 434, hand-pipelined 404
-// (with one wave per SIMD the copies' issue stalls the MFMA stream; an 8-wave workgroup has a partner wave to cover it).
+// tiles).  A 32x32x16 f16 MFMA takes 32 cycles, so per k16 group a SIMD has 512 cycles of matrix work against 72 KiB of
+// fragment reads (576 LDS cycles for the workgroup) plus the copies: the loop only works if reads, copies and MFMAs
+// overlap completely.  Software pipeline: while the 8 MFMAs of a group run, the 9 fragments of the next group are read
+// into the other register set and -- in the second group of a k32 stage, waves 0-3 only -- the 8 copies of the stage four
+// ahead are issued, one filler per MFMA, pinned with sched_barrier.  The stage's barrier sits between its two groups:
+// after it everybody has read both groups of this stage (its slot is free for the new copies) and the next stage, whose
+// first fragments are read next, has landed for everyone.
+// Measured alternatives (10 M x 768, k = 30, kernel ms; this kernel: see DESIGN.md): unpipelined 8 waves with a 2-slot
+// k64 ring 388, 4-slot k32 ring 388-397, 9-slot k16 ring 440; 4 waves x (64 queries x 256 rows) with 256 AGPR
+// accumulators, compiler-scheduled 434, pipelined like this 404 (one wave per SIMD: every stall of the copies' issue
+// stalls the MFMA stream, there is no partner wave to cover it).
 __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -80,7 +79,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
     float* sc = reinterpret_cast<float*>(smem + F16_SCRATCH) + w * 256;
     int* pcnt = reinterpret_cast<int*>(smem + F16_PCNT);
     const int g16 = a.g16, k = a.k, klw = a.klw;
-    const int NS = g16 / F16_GROUPS;   // stages per bank tile
+    const int NS = g16 / F16_GROUPS;   // k32 stages per bank tile
     const int myq = w * 32 + (lane & 31);
 
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
@@ -94,31 +93,38 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
         const int total = seg.n_tiles * NS;
         f32x16 acc[8];
 
-        // stage (bt, ks): 8 row tiles x F16_GROUPS k16 groups of 1 KiB of the bank, as many of the query tile; waves 0-3
-        // issue F16_COPIES copies each: row tiles w and w+4 (consecutive KiB) of the bank and of the query tile
-        auto issue = [&](int bt, int ks, int slot) {
+        // stage (bt, ks): 16 bank blocks (8 row tiles x 2 k16 groups) + 16 query blocks of 1 KiB; waves 0-3 issue 8 copies
+        // each.  Copy i of wave w: row tile w + 4 (i >> 2), k16 group (i >> 1) & 1, bank (i even) or query (i odd).
+        // Addresses = wave-uniform 64-bit base + 32-bit lane offset.
+        const char* bank_w = reinterpret_cast<const char*>(a.bank16) + (size_t)w * g16 * 1024;
+        const char* query_w = reinterpret_cast<const char*>(a.q16) + (size_t)(seg.q_tile * 8 + w) * g16 * 1024;
+        const unsigned lane_off = (unsigned)lane * 16u;
+        auto issue_one = [&](int i, int bt, int ks, int slot) {
             if (w < 4) {
-                char* sb = smem + slot * F16_SLOT_BYTES;
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int rt = w + 4 * r;
-                    const _Float16* bsrc = a.bank16 + ((size_t)(bt * 8 + rt) * g16 + ks * F16_GROUPS) * 512 + lane * 8;
-                    const _Float16* qsrc = a.q16 + ((size_t)(seg.q_tile * 8 + rt) * g16 + ks * F16_GROUPS) * 512 + lane * 8;
-#pragma unroll
-                    for (int g = 0; g < F16_GROUPS; ++g) {
-                        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(bsrc + g * 512), (lds_void*)(sb + (rt * F16_GROUPS + g) * 1024), 16, 0, 0);
-                        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(qsrc + g * 512), (lds_void*)(sb + F16_HALF + (rt * F16_GROUPS + g) * 1024), 16, 0, 0);
-                    }
-                }
-                if (ks == 0 && w == 0) glds16(a.binit + (size_t)bt * HB_BT + lane * 4, smem + F16_BINIT + (bt & 1) * 1024);
+                const int r = i >> 2, g = (i >> 1) & 1;
+                char* dst = smem + slot * F16_SLOT_BYTES + ((w + 4 * r) * F16_GROUPS + g) * 1024;
+                const size_t off = ((size_t)4 * r * g16 + ks * F16_GROUPS + g) * 1024;
+#if defined(F16_ABL) && (F16_ABL & 2)
+                bt &= 3;   // timing only: 4 bank tiles, L2-resident
+#endif
+#if defined(F16_ABL) && (F16_ABL & 8)
+                const char* qw = reinterpret_cast<const char*>(a.q16) + (size_t)w * g16 * 1024;   // timing only: one query tile for all
+#else
+                const char* qw = query_w;
+#endif
+                if (i & 1) __builtin_amdgcn_global_load_lds((gbl_cvoid*)(qw + off + lane_off), (lds_void*)(dst + F16_HALF), 16, 0, 0);
+                else __builtin_amdgcn_global_load_lds((gbl_cvoid*)(bank_w + (size_t)bt * 8 * g16 * 1024 + off + lane_off), (lds_void*)dst, 16, 0, 0);
             }
         };
+        auto issue_binit = [&](int bt, int ks) {
+            if (ks == 0 && w == 0) glds16(a.binit + (size_t)bt * HB_BT + lane * 4, smem + F16_BINIT + (bt & 1) * 1024);
+        };
 
-        // vmcnt is counted by hand as in the fp32 kernel: an issuing wave has F16_COPIES copies per stage in flight (wave 0
-        // one more, the row-init values, at the first stage of a tile; epilogue stores only make the wait stricter), so
-        // "all but the newest (F16_RING - 2) stages' worth" covers the stage about to be computed.  Past the last stage
-        // the fetch position stays put and re-fills a free slot.
-        int bt = seg.b_tile0, ks = 0;          // stage being computed
+        // vmcnt is counted by hand as in the fp32 kernel: an issuing wave has 8 copies per stage in flight (wave 0 a ninth,
+        // the row-init values, with the first stage of a tile; epilogue stores only make the wait stricter), so "all but
+        // the newest 16" = the next stage has landed, two more are in flight.  Past the last stage the fetch position
+        // stays put and re-fills a free slot; the fragment reads past the end are unused.
+        int bt = seg.b_tile0;                  // tile being computed
         int fbt = seg.b_tile0, fks = 0;        // next stage to fetch
         int slot_c = 0, slot_f = 0;
         int left = total;
@@ -126,40 +132,74 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
             if (--left > 0) { if (++fks == NS) { fks = 0; ++fbt; } }
             if (++slot_f == F16_RING) slot_f = 0;
         };
-        for (int p = 0; p < F16_RING - 1; ++p) { issue(fbt, fks, slot_f); advance_fetch(); }
-        for (int st = 0; st < total; ++st) {
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(F16_INFLIGHT) : "memory");   // my copies of stage st have landed
-            __syncthreads();                              // ... everyone's have; the slot of stage st-1 is free
-            issue(fbt, fks, slot_f);                      // F16_RING - 1 stages ahead (or a harmless re-fill past the end)
+        for (int p = 0; p < F16_RING; ++p) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) issue_one(i, fbt, fks, slot_f);
+            issue_binit(fbt, fks);
             advance_fetch();
-            const char* sb = smem + slot_c * F16_SLOT_BYTES;
-            if (ks == 0) {
+        }
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // stage 0 has landed; stages 1-3 in flight
+        __syncthreads();
+        f16x8 fa[8], ga[8], fb, gb;                         // fragments of the current / the next k16 group
+#define F16_MM(T, FA, FB) acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[T], FB, acc[T], 0, 0, 0);
+        for (int tl = 0; tl < seg.n_tiles; ++tl, ++bt) {
+            {   // first fragments of the tile (read again rather than kept live across the epilogue: fewer registers)
+                const f16x8* A = reinterpret_cast<const f16x8*>(smem + slot_c * F16_SLOT_BYTES) + lane;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) fa[t] = A[(t * F16_GROUPS) * 64];
+                fb = A[F16_HALF / 16 + (w * F16_GROUPS) * 64];
+            }
+            {   // accumulators start from the bank rows' init values (landed with the tile's first stage)
                 const f32x4* bi = reinterpret_cast<const f32x4*>(smem + F16_BINIT + (bt & 1) * 1024);
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        f32x4 v = bi[8 * t + 2 * g + h];
+                        const f32x4 v = bi[8 * t + 2 * g + h];
                         acc[t][4 * g + 0] = v[0]; acc[t][4 * g + 1] = v[1];
                         acc[t][4 * g + 2] = v[2]; acc[t][4 * g + 3] = v[3];
                     }
             }
-            const f16x8* A = reinterpret_cast<const f16x8*>(sb) + lane;
-            const f16x8* B = reinterpret_cast<const f16x8*>(sb + F16_HALF) + lane;
-#pragma unroll
-            for (int g = 0; g < F16_GROUPS; ++g) {
-                const f16x8 b = B[(w * F16_GROUPS + g) * 64];
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(t * F16_GROUPS + g) * 64], b, acc[t], 0, 0, 0);
+#pragma nounroll
+            for (int ks = 0; ks < NS; ++ks) {
+                int slot_n = slot_c + 1; if (slot_n == F16_RING) slot_n = 0;
+                const f16x8* Ac = reinterpret_cast<const f16x8*>(smem + slot_c * F16_SLOT_BYTES) + lane;
+                const f16x8* An = reinterpret_cast<const f16x8*>(smem + slot_n * F16_SLOT_BYTES) + lane;
+                // ---- group 0 of the stage; fillers: the fragments of group 1 ----
+                KN_FENCE F16_MM(0, fa, fb) KN_FENCE ga[0] = Ac[(0 * F16_GROUPS + 1) * 64]; gb = Ac[F16_HALF / 16 + (w * F16_GROUPS + 1) * 64];
+                KN_FENCE F16_MM(1, fa, fb) KN_FENCE ga[1] = Ac[(1 * F16_GROUPS + 1) * 64];
+                KN_FENCE F16_MM(2, fa, fb) KN_FENCE ga[2] = Ac[(2 * F16_GROUPS + 1) * 64];
+                KN_FENCE F16_MM(3, fa, fb) KN_FENCE ga[3] = Ac[(3 * F16_GROUPS + 1) * 64];
+                KN_FENCE F16_MM(4, fa, fb) KN_FENCE ga[4] = Ac[(4 * F16_GROUPS + 1) * 64];
+                KN_FENCE F16_MM(5, fa, fb) KN_FENCE ga[5] = Ac[(5 * F16_GROUPS + 1) * 64];
+                KN_FENCE F16_MM(6, fa, fb) KN_FENCE ga[6] = Ac[(6 * F16_GROUPS + 1) * 64];
+                KN_FENCE F16_MM(7, fa, fb) KN_FENCE ga[7] = Ac[(7 * F16_GROUPS + 1) * 64];
+                KN_FENCE
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // my copies of the next stage have landed
+                __syncthreads();                                      // ... everyone's have, and this stage's slot has been read
+                // ---- group 1; fillers: the first fragments of the next stage and the copies of the stage four ahead ----
+                KN_FENCE F16_MM(0, ga, gb) KN_FENCE fa[0] = An[(0 * F16_GROUPS) * 64]; fb = An[F16_HALF / 16 + (w * F16_GROUPS) * 64];
+                issue_one(0, fbt, fks, slot_f);
+                KN_FENCE F16_MM(1, ga, gb) KN_FENCE fa[1] = An[(1 * F16_GROUPS) * 64]; issue_one(1, fbt, fks, slot_f);
+                KN_FENCE F16_MM(2, ga, gb) KN_FENCE fa[2] = An[(2 * F16_GROUPS) * 64]; issue_one(2, fbt, fks, slot_f);
+                KN_FENCE F16_MM(3, ga, gb) KN_FENCE fa[3] = An[(3 * F16_GROUPS) * 64]; issue_one(3, fbt, fks, slot_f);
+                KN_FENCE F16_MM(4, ga, gb) KN_FENCE fa[4] = An[(4 * F16_GROUPS) * 64]; issue_one(4, fbt, fks, slot_f);
+                KN_FENCE F16_MM(5, ga, gb) KN_FENCE fa[5] = An[(5 * F16_GROUPS) * 64]; issue_one(5, fbt, fks, slot_f);
+                KN_FENCE F16_MM(6, ga, gb) KN_FENCE fa[6] = An[(6 * F16_GROUPS) * 64]; issue_one(6, fbt, fks, slot_f);
+                KN_FENCE F16_MM(7, ga, gb) KN_FENCE fa[7] = An[(7 * F16_GROUPS) * 64]; issue_one(7, fbt, fks, slot_f);
+                issue_binit(fbt, fks);
+                advance_fetch();
+                KN_FENCE
+                slot_c = slot_n;
             }
-            if (++slot_c == F16_RING) slot_c = 0;
-            if (++ks == NS) {
-                tile_epilogue<true, true>(acc, thr, wl_s, wl_i, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
-                ks = 0;
-                ++bt;
-            }
+#if defined(F16_ABL) && (F16_ABL & 1)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) asm volatile("" :: "v"(acc[t]));   // timing only: no epilogue
+#else
+            tile_epilogue<true, true>(acc, thr, wl_s, wl_i, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
+#endif
         }
+#undef F16_MM
         pool_end(pv, seg.slot, pcnt, thr, myq, lane);
         if (lane < 32) floor_publish(a.gthr, seg.q_tile * HB_QT + myq, thr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
