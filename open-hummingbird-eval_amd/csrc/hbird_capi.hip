@@ -118,7 +118,7 @@ extern "C" int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tile
 }
 
 extern "C" int hb_index_set_variant(hb_index_t* ix, int variant) {
-    if (variant < 0 || variant > 2) return hb_fail("hb_index_set_variant: unknown kernel variant");
+    if (variant < 0 || variant > 1) return hb_fail("hb_index_set_variant: unknown kernel variant");
     ix->variant = variant;
     return 0;
 }

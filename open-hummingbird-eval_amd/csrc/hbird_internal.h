@@ -84,7 +84,7 @@ struct hb_index {
     char* fb = nullptr; size_t fb_bytes = 0;             // fallback workspace (uncertified queries)
     int64_t last_fp16_fallbacks = 0;
     int score_output = 0;                                // 1: searches return ordering scores instead of distances
-    int variant = 0;                                     // 0: 8-wave kernels, 1: 4-wave fp32 kernel, 2: register-staged 4-wave fp16 kernel
+    int variant = 0;                                     // 0: 8-wave kernel, 1: 4-wave (one wave per SIMD) kernel
     int ablate = 0;                                      // timing-only kernel ablation (HB_ABLATION builds)
     double last_knn_ms = 0.0;                            // HIP-event time of the last knn kernel launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -118,7 +118,6 @@ int hb_launch_scatter_rows(const int64_t* rows, int64_t n, int k, const int64_t*
                            int64_t* out_idx, float* out_dist, hipStream_t s);
 struct knn16_args;
 int hb_knn_f16_launch(const knn16_args& args, int grid, hipStream_t s);
-int hb_knn_f16r_launch(const knn16_args& args, int grid, hipStream_t s);   // register-staged 4-wave variant, Dp16 % 128 == 0
 int hb_launch_aggregate(const hb_index* ix, const float* qnorm, const int64_t* idx, const float* dist, int64_t nq,
                         int k, int64_t id_base, float beta, float* out, hipStream_t s);
 int hb_launch_merge_parts(const float* dist_parts, const int64_t* idx_parts, int parts, int64_t nq, int k, int metric,

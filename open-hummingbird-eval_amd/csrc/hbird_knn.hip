@@ -526,8 +526,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         h.state_s = a.state_s; h.state_i = a.state_i; h.g16 = ix->dp16 / 16; h.k = kc; h.klw = klw;
         h.state_cnt = a.state_cnt; h.state_thr = a.state_thr; h.gthr = a.gthr;
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev0, s));
-        if (ix->variant == 2 && ix->dp16 % 128 == 0 && klw <= 256) { if (hb_knn_f16r_launch(h, sc.G, s)) return -1; }
-        else if (hb_knn_f16_launch(h, sc.G, s)) return -1;
+        if (hb_knn_f16_launch(h, sc.G, s)) return -1;
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
         if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
                          reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, kc, klw, 0, 0, nullptr,

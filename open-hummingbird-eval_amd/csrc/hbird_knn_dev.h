@@ -97,8 +97,8 @@ __device__ __forceinline__ unsigned pool_kth(const unsigned (&key)[EMAX], bool (
 }
 
 // Compact the full pool (cap entries) at (gs, gi) to its best k in entries [0, k); returns the k-th best score.
-template <int EMAX = HB_POOL_MAX / 64>
 __device__ __forceinline__ float pool_compact(float* gs, unsigned* gi, int cap, int k, int lane) {
+    constexpr int EMAX = HB_POOL_MAX / 64;
     const int E = cap >> 6;
     float es[EMAX];
     unsigned ei[EMAX], key[EMAX];
@@ -211,54 +211,6 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, floa
                         const float kth = lst_s[(qb + n) * HB_KL + (k - 1)];
                         if ((lane & 31) == n) thr = fmaxf(thr, kth);
                     }
-                }
-            }
-    }
-}
-
-// Pool epilogue of ONE 32 x 32 accumulator tile (bank row tile t of the pair tile, the 32 queries qb..qb+31): same
-// filter, same ascending row order and same appends as tile_epilogue<true, true>, but only 16 accumulator values are
-// alive at a time -- for kernels whose accumulators sit in AGPRs and would otherwise be copied out wholesale.
-template <int EMAX>
-__device__ __forceinline__ void tile_epilogue_pool_one(const f32x16 v16, int t, float& thr, float* ps, unsigned* pi, float* sc,
-                                                       int qb, int lane, int k, unsigned bt, int klw, int* cnt) {
-    unsigned m4 = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const bool any = (v16[4 * q] > thr) | (v16[4 * q + 1] > thr) | (v16[4 * q + 2] > thr) | (v16[4 * q + 3] > thr);
-        if (__ballot(any) != 0ull) m4 |= 1u << q;
-    }
-    while (m4) {
-        const int q = __builtin_ctz(m4);
-        m4 &= m4 - 1;
-        switch (q) {
-            case 0: _Pragma("unroll") for (int r = 0; r < 4; ++r) sc[r * 64 + lane] = v16[r]; break;
-            case 1: _Pragma("unroll") for (int r = 0; r < 4; ++r) sc[r * 64 + lane] = v16[4 + r]; break;
-            case 2: _Pragma("unroll") for (int r = 0; r < 4; ++r) sc[r * 64 + lane] = v16[8 + r]; break;
-            default: _Pragma("unroll") for (int r = 0; r < 4; ++r) sc[r * 64 + lane] = v16[12 + r]; break;
-        }
-        const unsigned row_base = bt * HB_BT + t * 32 + q * 8;
-        for (int hh = 0; hh < 2; ++hh)
-            for (int j = 0; j < 4; ++j) {
-                const float v = sc[j * 64 + lane];
-                const bool pass = ((lane >> 5) == hh) && (v > thr);
-                if (__ballot(pass) == 0ull) continue;
-                const int myq = qb + (lane & 31);
-                int c = 0;
-                if (pass) {
-                    c = cnt[myq];
-                    ps[(size_t)myq * klw + c] = v;
-                    pi[(size_t)myq * klw + c] = row_base + hh * 4 + j;
-                    cnt[myq] = c + 1;
-                }
-                unsigned long long full = __ballot(pass && c + 1 == klw);
-                while (full) {
-                    const int n = __builtin_ctzll(full) & 31;
-                    full &= full - 1;
-                    const size_t off = (size_t)(qb + n) * klw;
-                    const float kth = pool_compact<EMAX>(ps + off, pi + off, klw, k, lane);
-                    if (lane == 0) cnt[qb + n] = k;
-                    if ((lane & 31) == n) thr = fmaxf(thr, kth);
                 }
             }
     }
