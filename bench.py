@@ -28,7 +28,8 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+PEAK_FP32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+PEAK_FP16_MFMA_TFLOPS = 2516.6   # 256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz (dense, no sparsity)
 
 
 def parse():
@@ -216,6 +217,8 @@ def main():
         kms = float(np.mean(knn_ms))
         flops = 2.0 * nq * (hi - lo) * D
         ach = flops / (kms * 1e-3) / 1e12
+        # --fp16 prices the candidate kernel against the dense fp16 matrix peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s)
+        peak = PEAK_FP16_MFMA_TFLOPS if a.fp16 else PEAK_FP32_MFMA_TFLOPS
         res = {
             "metric": "query-patches/sec", "value": nq * a.steps / dt, "unit": "query-patches/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -227,10 +230,10 @@ def main():
                        "parallelism": f"bank-shard{world}" if world > 1 else "single-gpu",
                        "bank_build_s": round(t_build, 2), "schedule": index.schedule_info(),
                        "use_fp16": bool(a.fp16), "fp16_fallback_queries": index.last_fp16_fallbacks() if a.fp16 else None},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                         "frac": ach / peak, "traffic": traffic,
                          "traffic_unit": "bytes/launch (L2-miss side, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
-                         "kernel": "knn_fused_kernel", "avg_kernel_ms": kms,
+                         "kernel": "knn_f16_kernel" if a.fp16 else "knn_fused_kernel", "avg_kernel_ms": kms,
                          "algorithmic_flops_per_launch": flops},
         }
         if world == 1 and not a.fp16:
