@@ -123,6 +123,29 @@ def cpu_baseline(D, k, M_total):
     }
 
 
+def miou_parity(device):
+    """BASELINE.json's second metric, 'mIoU delta vs ref': replay the fixtures that tests/golden/gen_golden.py produced
+    with the reference's own HbirdEvaluation (bank build + evaluation from recorded tokens) through this engine."""
+    path = os.path.join(ROOT, "tests", "golden", "g67_memory_evaluate.npz")
+    if not os.path.exists(path):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import ReplayExtractor, golden_case
+    from hbird_mi.hbird_eval import HbirdEvaluation
+    g = np.load(path)
+    out = {}
+    for name in ("unb", "bnd", "ade"):
+        c = golden_case(g, name)
+        torch.set_rng_state(torch.from_numpy(g[f"rng_state_{name}"]))      # the reference run started from this state
+        ext = ReplayExtractor(c["tr_tok"] + c["va_tok"], c["S"], c["D"])
+        ev = HbirdEvaluation(ext, c["train"], num_classes=c["C"], n_neighbours=c["k"], augmentation_epoch=c["aug"],
+                             device=str(device), nn_method="hip", memory_size=c["mem"], dataset_size=c["nb"] * c["B"])
+        jac = ev.evaluate(c["val"], c["S"], ignore_index=c["ign"])
+        out[name] = abs(float(jac) - float(g[f"jac_{name}"]))
+    return {"max_abs_miou_delta_vs_reference": max(out.values()), "cases": out,
+            "fixture": "tests/golden/g67_memory_evaluate.npz (reference HbirdEvaluation outputs)", "tolerance": 1e-4}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -253,6 +276,8 @@ def main():
             index.set_fp16(False)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(D, k, M)
+        if world == 1:
+            res["miou_parity"] = miou_parity(device)
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
