@@ -82,19 +82,21 @@ extern "C" int64_t hb_index_nlabels(const hb_index_t* ix) { return ix->nlabels; 
 extern "C" int hb_index_set_timing(hb_index_t* ix, int enable) { ix->time_kernels = enable; return 0; }
 extern "C" int hb_index_last_knn_ms(const hb_index_t* ix, double* ms) { *ms = ix->last_knn_ms; return 0; }
 extern "C" int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_tiles) {
+    if (!ix) return hb_fail("hb_index_set_tuning: NULL index handle");
     // workgroups < 0 selects a timing-only ablation variant (HB_ABLATION builds): bits = -workgroups
     if (workgroups < 0) { ix->ablate = -workgroups; workgroups = 0; } else ix->ablate = 0;
     ix->force_G = workgroups; ix->force_panel = panel_tiles; ix->sched = hb_schedule(); return 0;
 }
-// Host-only: build the kNN work list for a (query tiles x bank tiles) grid without touching a GPU, for inspection
-// and tests.  segs_out receives up to max_segs rows of {block, q_tile, b_tile0, n_tiles, slot, first}.
 extern "C" int hb_index_set_fp16(hb_index_t* ix, int enable) {
+    if (!ix) return hb_fail("hb_index_set_fp16: NULL index handle");
     ix->fp16 = enable ? 1 : 0;
     return 0;
 }
 
 extern "C" int hb_index_last_fp16_fallbacks(const hb_index_t* ix, int64_t* n) { *n = ix->last_fp16_fallbacks; return 0; }
 
+// Host-only: build the kNN work list for a (query tiles x bank tiles) grid without touching a GPU, for inspection
+// and tests.  segs_out receives up to max_segs rows of {block, q_tile, b_tile0, n_tiles, slot, first}.
 extern "C" int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, int* segs_out, int64_t max_segs,
                                 int64_t stats[8]) {
     if (nqt <= 0 || nbt <= 0 || workgroups <= 0 || d <= 0) return hb_fail("hb_schedule_plan: bad arguments");
@@ -118,11 +120,13 @@ extern "C" int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tile
 }
 
 extern "C" int hb_index_set_variant(hb_index_t* ix, int variant) {
+    if (!ix) return hb_fail("hb_index_set_variant: NULL index handle");
     if (variant < 0 || variant > 1) return hb_fail("hb_index_set_variant: unknown kernel variant");
     ix->variant = variant;
     return 0;
 }
 extern "C" int hb_index_schedule_info(const hb_index_t* ix, int64_t out[8]) {
+    if (!ix) return hb_fail("hb_index_schedule_info: NULL index handle");
     const hb_schedule& s = ix->sched;
     out[0] = s.G; out[1] = (int64_t)s.segs.size(); out[2] = s.n_slots; out[3] = s.panel; out[4] = s.max_slots_per_qt;
     out[5] = s.nqt; out[6] = s.nbt; out[7] = 0;
@@ -139,6 +143,7 @@ static int grow(void** p, size_t* have, size_t need) {
 }
 
 extern "C" int hb_index_reserve(hb_index_t* ix, int64_t n_rows) {
+    if (!ix) return hb_fail("hb_index_reserve: NULL index handle");
     HB_HIP(hipSetDevice(ix->device));
     int64_t cap = (n_rows + HB_BT - 1) / HB_BT * HB_BT;
     if (cap <= ix->cap_rows) return 0;
@@ -166,6 +171,7 @@ extern "C" int hb_index_reserve(hb_index_t* ix, int64_t n_rows) {
 }
 
 extern "C" int hb_index_reset(hb_index_t* ix) {
+    if (!ix) return hb_fail("hb_index_reset: NULL index handle");
     HB_HIP(hipSetDevice(ix->device));
     hipStream_t s = ix->stream;
     if (ix->cap_rows > 0) {
@@ -185,6 +191,7 @@ static int stage_in(hb_index* ix, const void* host, size_t bytes, size_t offset)
 }
 
 extern "C" int hb_index_add(hb_index_t* ix, const float* x, int64_t n, int x_on_device, int normalize) {
+    if (!ix) return hb_fail("hb_index_add: NULL index handle");
     if (n < 0) return hb_fail("hb_index_add: negative row count");
     if (n == 0) return 0;
     if (!x) return hb_fail("hb_index_add: x is NULL");
@@ -217,6 +224,7 @@ extern "C" int hb_index_add(hb_index_t* ix, const float* x, int64_t n, int x_on_
 }
 
 extern "C" int hb_index_add_labels(hb_index_t* ix, const float* labels, int64_t n, int c, int on_device) {
+    if (!ix) return hb_fail("hb_index_add_labels: NULL index handle");
     if (n < 0 || c <= 0) return hb_fail("hb_index_add_labels: bad shape");
     if (n == 0) return 0;
     HB_HIP(hipSetDevice(ix->device));
@@ -295,6 +303,7 @@ static int search_impl(hb_index* ix, const float* q, int64_t nq, int k, int64_t 
 
 extern "C" int hb_index_search(hb_index_t* ix, const float* q, int64_t nq, int k, int64_t id_base, int64_t* out_idx,
                                float* out_dist, int io_on_device) {
+    if (!ix) return hb_fail("hb_index_search: NULL index handle");
     if (nq > 0 && (!out_idx || !out_dist)) return hb_fail("hb_index_search: output pointers are NULL");
     return search_impl(ix, q, nq, k, id_base, 0.f, nullptr, out_idx, out_dist, io_on_device, false);
 }
@@ -302,6 +311,7 @@ extern "C" int hb_index_search(hb_index_t* ix, const float* q, int64_t nq, int k
 extern "C" int hb_index_search_aggregate(hb_index_t* ix, const float* q, int64_t nq, int k, int64_t id_base, float beta,
                                          float* out_label_hat, int64_t* out_idx_opt, float* out_dist_opt,
                                          int io_on_device) {
+    if (!ix) return hb_fail("hb_index_search_aggregate: NULL index handle");
     if (nq > 0 && !out_label_hat) return hb_fail("hb_index_search_aggregate: out_label_hat is NULL");
     if (!(beta > 0.f)) return hb_fail("hb_index_search_aggregate: beta must be positive");
     if (!ix->ext_labels && (!ix->labels || ix->nlabels < ix->ntotal)) return hb_fail("hb_index_search_aggregate: label rows missing (hb_index_add_labels)");
@@ -310,6 +320,7 @@ extern "C" int hb_index_search_aggregate(hb_index_t* ix, const float* q, int64_t
 
 extern "C" int hb_index_aggregate(hb_index_t* ix, const float* q, int64_t nq, const int64_t* idx, const float* dist,
                                   int k, int64_t id_base, float beta, float* out_label_hat, int io_on_device) {
+    if (!ix) return hb_fail("hb_index_aggregate: NULL index handle");
     if (nq == 0) return 0;
     if (!io_on_device) return hb_fail("hb_index_aggregate: host pointers are not supported, pass device memory");
     if (!(beta > 0.f)) return hb_fail("hb_index_aggregate: beta must be positive");
@@ -351,15 +362,18 @@ static int gather_impl(hb_index* ix, const int64_t* ids, int64_t n, int64_t id_b
 
 extern "C" int hb_index_reconstruct(hb_index_t* ix, const int64_t* ids, int64_t n, int64_t id_base, float* out,
                                     int io_on_device) {
+    if (!ix) return hb_fail("hb_index_reconstruct: NULL index handle");
     return gather_impl(ix, ids, n, id_base, out, io_on_device, false);
 }
 extern "C" int hb_index_gather_labels(hb_index_t* ix, const int64_t* ids, int64_t n, int64_t id_base, float* out,
                                       int io_on_device) {
+    if (!ix) return hb_fail("hb_index_gather_labels: NULL index handle");
     return gather_impl(ix, ids, n, id_base, out, io_on_device, true);
 }
 
 extern "C" int hb_index_set_label_table(hb_index_t* ix, const float* labels, const float* bnorm, int64_t n, int c,
                                         int64_t id_base) {
+    if (!ix) return hb_fail("hb_index_set_label_table: NULL index handle");
     if (labels && (!bnorm || n <= 0 || c <= 0)) return hb_fail("hb_index_set_label_table: bad arguments");
     ix->ext_labels = labels; ix->ext_bnorm = bnorm; ix->ext_n = labels ? n : 0; ix->ext_base = labels ? id_base : 0;
     if (labels) ix->c = c;
@@ -367,6 +381,7 @@ extern "C" int hb_index_set_label_table(hb_index_t* ix, const float* labels, con
 }
 
 extern "C" int hb_index_copy_norms(hb_index_t* ix, float* out, int on_device) {
+    if (!ix) return hb_fail("hb_index_copy_norms: NULL index handle");
     if (ix->ntotal == 0) return 0;
     HB_HIP(hipSetDevice(ix->device));
     HB_HIP(hipMemcpyAsync(out, ix->bnorm, (size_t)ix->ntotal * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ix->stream));
@@ -377,6 +392,7 @@ extern "C" int hb_index_copy_norms(hb_index_t* ix, float* out, int on_device) {
 extern "C" int hb_index_set_score_output(hb_index_t* ix, int enable) { ix->score_output = enable ? 1 : 0; return 0; }
 
 extern "C" int hb_index_distances_from_scores(hb_index_t* ix, const float* q, int64_t nq, int k, float* dist_inout) {
+    if (!ix) return hb_fail("hb_index_distances_from_scores: NULL index handle");
     if (nq == 0 || ix->metric != 1) return 0;            // inner product: the score is the distance
     if (!q || !dist_inout) return hb_fail("hb_index_distances_from_scores: NULL pointer");
     HB_HIP(hipSetDevice(ix->device));

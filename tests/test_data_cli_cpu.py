@@ -197,3 +197,13 @@ def test_voc_from_a_tar_archive_equals_the_folder(tmp_path):
         st.open("images/none.jpg")
     with pytest.raises(RuntimeError):
         get_dataset("voc", str(nested) + "!/data/other", 2, 0, 32)
+
+
+def test_c_abi_rejects_a_null_handle_without_a_gpu():
+    """Entry points validate the handle before touching the device (error code + hb_last_error, never a crash)."""
+    from hbird_mi import _lib
+    L = _lib.lib()
+    assert L.hb_index_add(None, None, 10, 0, 0) != 0
+    assert b"NULL index handle" in L.hb_last_error()
+    assert L.hb_index_search(None, None, 1, 1, 0, None, None, 0) != 0
+    assert L.hb_index_set_fp16(None, 1) != 0
