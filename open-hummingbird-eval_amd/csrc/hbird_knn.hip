@@ -29,7 +29,8 @@
 #define KN_MFMA(T, FR, B, S) acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(FR[(T) & 3][S], B[S], acc[T], 0, 0, 0);
 
 // ABL: timing-only ablation bits (results are garbage when != 0): 1 = no LDS-DMA in the steady state,
-// 2 = no fragment reads, 4 = no barrier / vmcnt wait, 8 = no epilogue.
+// 2 = no fragment reads, 4 = no barrier / vmcnt wait, 8 = no epilogue.  Bit 512 is NOT an ablation: it adds the
+// radix-select cold start of a slot's first tile (exact; used for searches with few tiles per workgroup).
 template <int ABL, bool WIDE>
 __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -170,7 +171,12 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
             if (++ks == g8) {
                 if constexpr (!(ABL & 8)) {
                     if constexpr (WIDE) tile_epilogue<true, true>(acc, thr, wl_s, wl_i, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
-                    else tile_epilogue<!(ABL & 16), false>(acc, thr, lst_s, lst_i, sc, w * 32, lane, k, (unsigned)bt);
+                    else {
+                        if constexpr (ABL & 512) {   // small searches: radix-select cold start (separate instantiation, see launcher)
+                            if (seg.first && bt == seg.b_tile0) thr = fmaxf(thr, cold_start_threshold(acc, k));
+                        }
+                        tile_epilogue<!(ABL & 16), false>(acc, thr, lst_s, lst_i, sc, w * 32, lane, k, (unsigned)bt);
+                    }
                 }
                 else {
 #pragma unroll
@@ -599,6 +605,15 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         attr_set = true;
     }
     knn_fn fn = variants[wide ? 1 : 0];
+    // Few stages per workgroup: the cold start of every slot (its first tile inserts all 256 rows of every query) is
+    // a visible share of the search -> the instantiation with the radix-select cold start (+14 % at 50 k x 384).  The
+    // big searches keep the plain instantiation: the extra code costs them 0.3 % (same-box A/B at 10 M x 768).
+    static const knn_fn cold_fn = knn_fused_kernel<512, false>;
+    static bool cold_attr = false;
+    if (!wide && (long long)nqt * nbt / std::max(1, sc.G) * ix->g8 < 150000) {
+        if (!cold_attr) { HB_HIP(hipFuncSetAttribute((const void*)cold_fn, hipFuncAttributeMaxDynamicSharedMemorySize, KN_LDS_TOTAL)); cold_attr = true; }
+        fn = cold_fn;
+    }
     if (!wide && ix->ablate)
         for (size_t i = 0; i < sizeof(variants) / sizeof(variants[0]); ++i) if (variant_bits[i] == ix->ablate) fn = variants[i];
     int threads = HB_THREADS;

@@ -250,6 +250,36 @@ __device__ __forceinline__ void pool_end(const knn_args_pool_view& pv, int slot,
     if (lane < 32) { pv.cnt[(size_t)slot * HB_QT + myq] = cnt[myq]; pv.thr[(size_t)slot * HB_QT + myq] = thr; }
 }
 
+// Cold start of a slot (LDS-list path): with no threshold yet, the first bank tile would insert all of its 256 rows into
+// every query's list one by one (8192 wave-cooperative insertions per wave).  Instead the k-th largest of the tile's
+// 256 scores of each query -- they sit in two lanes (lane, lane ^ 32) x 128 accumulator registers -- is found with a
+// 32-round radix select on the monotone keys, and everything below it is filtered like any other score: about k
+// insertions per query remain.  Returns the float just below that k-th score (ties with it must still pass), or -inf
+// when the tile has fewer than k real rows (padding rows score -inf).
+__device__ __forceinline__ float cold_start_threshold(const f32x16 (&acc)[8], int k) {
+    unsigned prefix = 0;
+    int kk = k;
+    for (int b = 31; b >= 0; --b) {
+        const unsigned himask = ~((1u << b) - 1u), cand = prefix | (1u << b);
+        int c = 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[t][r];
+                asm volatile("" : "+v"(v));   // keeps the 128 keys from being hoisted out of the bit loop (registers)
+                c += ((pool_key(v) & himask) == cand) ? 1 : 0;
+            }
+        c += __shfl_xor(c, 32);
+        if (c >= kk) prefix = cand; else kk -= c;
+    }
+    // prefix = key of the k-th largest score; one key below it (skipping -0.0) admits its ties
+    if (prefix <= 0x007FFFFFu) return -INFINITY;
+    unsigned g = prefix - 1u;
+    if (g == 0x7FFFFFFFu) g = 0x7FFFFFFEu;
+    return __builtin_bit_cast(float, (g & 0x80000000u) ? (g ^ 0x80000000u) : ~g);
+}
+
 // LDS map shared by the variants (bytes): a 4-slot ring of k8 stages, two row-init buffers, the lists, the scratch
 #define KN_SLOT_BYTES 16384                 // 8 KiB bank fragments + 8 KiB query fragments (32 rows x 8 k blocks)
 #define KN_RING 4
