@@ -113,7 +113,7 @@ def main():
     from hbird.utils.eval_metrics import PredsmIoU
     import torch.nn.functional as F
     _install_exact_backend()
-    out = os.path.join(ROOT, "tests", "golden")
+    out = os.environ.get("HBIRD_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")   # override: reproducibility check
     os.makedirs(out, exist_ok=True)
     HE = he.HbirdEvaluation
     blank = HE.__new__(HE)  # instance without running __init__, for the pure methods

@@ -2,6 +2,8 @@
 
 CPU only.  These tests are what makes the oracle trustworthy as the checker of the HIP path.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -216,3 +218,22 @@ def test_g8_predsmiou(golden_dir):
             assert tp == g[f"tp_{name}_{mode}"].tolist()
             assert fp == g[f"fp_{name}_{mode}"].tolist()
             assert fn == g[f"fn_{name}_{mode}"].tolist()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/hbird"), reason="the reference is only mounted in the build container")
+def test_fixtures_are_reproducible_from_the_reference(golden_dir, tmp_path):
+    """tests/golden/gen_golden.py, run again on the reference's own Python, reproduces the committed fixtures exactly:
+    the pins of the oracle are the reference's outputs, not hand-edited data.  (CPU only; skipped on the GPU box.)"""
+    import glob
+    import subprocess
+    import sys
+    env = dict(os.environ, HBIRD_GOLDEN_OUT=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
+    gen = os.path.join(golden_dir, "gen_golden.py")
+    subprocess.run([sys.executable, gen], check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    made = sorted(glob.glob(str(tmp_path / "*.npz")))
+    assert [os.path.basename(f) for f in made] == sorted(f for f in os.listdir(golden_dir) if f.endswith(".npz"))
+    for f in made:
+        a, b = np.load(f), np.load(os.path.join(golden_dir, os.path.basename(f)))
+        assert set(a.files) == set(b.files)
+        for key in a.files:
+            assert np.array_equal(a[key], b[key]), (os.path.basename(f), key)
