@@ -9,7 +9,8 @@ with the CPU oracle on the SAME bank:
     oracle (bit-exact),
   * label_hat vs the oracle's cross-attention (max abs difference),
   * mIoU vs the oracle's metric.
-Writes one JSON (default gpurun_out/parity_at_scale.json).  The oracle is used here as the checker only.
+Writes one JSON (default gpurun_out/parity_at_scale.json).  Test infrastructure (it lives under tests/ because it uses
+the oracle, as the checker): run as `python tests/parity_report.py`.
 """
 import argparse
 import json
@@ -17,7 +18,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repo root
 sys.path[:0] = [ROOT, os.path.join(ROOT, "open-hummingbird-eval_amd"), os.path.join(ROOT, "tests")]
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
