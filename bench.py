@@ -7,18 +7,28 @@ soft labels, and query batches of 16 images x 1369 patches = 21,904 un-normalise
 One step = one pass of the hot path over one query batch: query tiling -> exact brute-force kNN
 (fused fp32-MFMA top-k kernel) -> partial-list merge -> cosine-softmax label aggregation, all inputs
 already resident in HBM.  With N GPUs the bank is row-sharded (10M / N rows per rank, one process per
-GPU), every rank searches all queries on its shard, the per-rank top-k lists are exchanged with an RCCL
-all-gather and merged, and each rank aggregates the labels for its slice of the queries ("strong"
-scaling: total work is fixed).
+GPU), every rank searches all queries on its shard, the per-rank top-k lists are exchanged with ONE packed RCCL
+all-gather per step and merged, and each rank aggregates the labels for its slice of the queries ("strong"
+scaling: total work is fixed).  The exchange of step i (all-gather + merge + aggregation, on a side stream)
+runs under the kNN kernel of step i+1.
+
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks itself (a child
+`python -m torch.distributed.run --nproc-per-node N bench.py ...`, before this process touches a GPU); under
+torchrun (RANK / WORLD_SIZE set, the driver's form) it is one of the ranks.  WORLD_SIZE != --gpus is an error.
 
 Prints ONE JSON line on rank 0 (see README / the driver contract).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -34,7 +44,7 @@ PEAK_FP16_MFMA_TFLOPS = 2516.6   # 256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz (
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs (default: WORLD_SIZE under torchrun, else 1)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=10_000_000, help="total bank rows M")
@@ -47,7 +57,38 @@ def parse():
     ap.add_argument("--panel", type=int, default=0)
     ap.add_argument("--fp16", action="store_true", help="use_fp16: fp16 candidate pass + exact fp32 re-rank")
     ap.add_argument("--variant", type=int, default=0, help="kNN kernel variant (0: 8 waves, 1: 4 waves)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 --pmc passes behind roofline.traffic")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: run the exchange on the kNN stream (no side stream)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # one untimed step under rocprofv3 --pmc
     return ap.parse_args()
+
+
+def kernel_source_hash():
+    """sha256 over the HIP sources: a committed traffic figure is only quoted for the kernels it was measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "open-hummingbird-eval_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def launch_ranks(a):
+    """--gpus N > 1 without a torchrun environment: start the N ranks as a CHILD process tree.  Nothing in this
+    process has touched a GPU yet (torch.cuda.device_count() does not initialise one), and the parent only waits."""
+    one_gpu = os.environ.get("HBIRD_BENCH_ONE_GPU") == "1"
+    import torch
+    have = torch.cuda.device_count()
+    if not one_gpu and have < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {have} GPU(s) visible on this node")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    argv = [x for x in sys.argv[1:]]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def build_bank(index, rows_lo, rows_hi, D, C, device):
@@ -113,6 +154,8 @@ def cpu_baseline(D, k, M_total):
         "unit": "query-patches/s",
         "cores": oracle.num_threads(),
         "kind": "port",
+        "extrapolated": True,                       # value = measured sample rate x (sample rows / bank rows)
+        "measured_on_sample": {"value": qps_sample, "unit": "query-patches/s", "bank_rows": ms, "queries": nqs, "seconds": round(dt, 2)},
         "sample": f"oracle exact fp32 brute force on {nqs} queries x {ms} rows x {D} dims took {dt:.2f}s "
                   f"({qps_sample:.1f} q/s), scaled x{ms}/{M_total} to the full bank; ScaNN (the reference's default CPU "
                   f"backend) is not installed on this image",
@@ -146,30 +189,82 @@ def miou_parity(device):
             "fixture": "tests/golden/g67_memory_evaluate.npz (reference HbirdEvaluation outputs)", "tolerance": 1e-4}
 
 
+def measure_traffic(a, kernel):
+    """roofline.traffic measured LIVE: two `rocprofv3 --pmc` child passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one
+    pass, MI355X_MICROARCH.md "rocprofv3 PMC slots") of this script in --pmc-child mode (same bank, one untimed step;
+    the program itself follows `--`).  FETCH_SIZE is doubled (gfx950 tallies 128-B requests of wide streaming reads at
+    64 B).  Returns (bytes per launch, note) or (None, why)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    import csv
+    env = dict(os.environ); env["TMPDIR"] = "/tmp"
+    args = ["--rows", str(a.rows), "--dim", str(a.dim), "--classes", str(a.classes), "--nq", str(a.nq), "--k", str(a.k),
+            "--workgroups", str(a.workgroups), "--panel", str(a.panel), "--variant", str(a.variant)] + (["--fp16"] if a.fp16 else [])
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="hbird_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child"] + args
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            per_dispatch = {}
+            for root, _, files in os.walk(out):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        for row in csv.DictReader(open(os.path.join(root, f))):
+                            if kernel in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                                per_dispatch[row["Dispatch_Id"]] = per_dispatch.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if not per_dispatch:
+                return None, f"rocprofv3 --pmc {ctr}: no {kernel} rows (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}"
+            vals[ctr] = sum(per_dispatch.values()) / len(per_dispatch)     # KiB per launch
+        except Exception as e:     # the measurement is optional evidence, never a reason to lose the bench line
+            return None, f"rocprofv3 --pmc {ctr} failed: {e!r}"
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return 2.0 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024, \
+        f"live: rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE = {vals['FETCH_SIZE']:.0f} KiB x2 + {vals['WRITE_SIZE']:.0f} KiB"
+
+
 def main():
     a = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None:
+        if a.gpus is not None and a.gpus > 1:
+            launch_ranks(a)                       # never returns: exits with the child's status
+        world = 1
+    else:
+        world = int(env_world)
+        if a.gpus is not None and a.gpus != world:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # HBIRD_BENCH_ONE_GPU=1 (testing only): all ranks share cuda:0 and talk over gloo, since RCCL refuses two
-    # ranks on one device; the normal path is one rank per GPU over RCCL.
+    # ranks on one device; the normal path is one rank per GPU over RCCL.  HBIRD_BENCH_FORCE_DIST=1 (testing only) runs
+    # the N-rank code path -- process group, packed all-gather, merge -- with a single rank.
     one_gpu = os.environ.get("HBIRD_BENCH_ONE_GPU") == "1"
+    dist_on = world > 1 or os.environ.get("HBIRD_BENCH_FORCE_DIST") == "1"
     dev_index = 0 if one_gpu else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
-        if one_gpu:
-            torch.distributed.init_process_group("gloo")
+    td = torch.distributed
+    backend = None
+    if dist_on:
+        backend = "gloo" if one_gpu else "nccl"
+        kw = {} if one_gpu else {"device_id": device}
+        if env_world is None:
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+            td.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, **kw)
         else:
-            torch.distributed.init_process_group("nccl", device_id=device)
+            td.init_process_group(backend, **kw)
+        assert td.get_world_size() == world and td.get_rank() == rank
     from hbird_mi import dist as hdist
-    from hbird_mi.nn.search_hip import HipFlatIndex, merge_topk
+    from hbird_mi.nn.search_hip import HipFlatIndex, merge_topk_packed
 
     M, D, C, nq, k = a.rows, a.dim, a.classes, a.nq, a.k
-    per = (M + world - 1) // world
-    lo, hi = min(M, rank * per), min(M, (rank + 1) * per)
+    lo, hi = hdist.shard_range(M, rank, world)
     index = HipFlatIndex(D, 0, dev_index)
     index.set_num_classes(C)
     index.use_current_stream()
@@ -181,13 +276,16 @@ def main():
         index.set_fp16(True)
     t_build = time.time()
     build_bank(index, lo, hi, D, C, device)
-    if world > 1:
+    agg = index
+    if dist_on:
         # label rows and bank-row norms are small (6 GB / 40 MB at cfg-3): replicate them once so that any
-        # rank can aggregate the labels of any merged neighbour list
+        # rank can aggregate the labels of any merged neighbour list.  They hang off a second, row-less handle, whose
+        # workspace is independent of the searching index (the aggregation may run on a side stream).
         lab_all, counts = hdist.allgather_rows(index.gather_labels(torch.arange(hi - lo, device=device)))
         nrm_all, _ = hdist.allgather_rows(index.copy_norms())
-        index.set_label_table(torch.cat([lab_all[r, :counts[r]] for r in range(world)]),
-                              torch.cat([nrm_all[r, :counts[r]] for r in range(world)]), 0)
+        agg = HipFlatIndex(D, 0, dev_index)
+        agg.set_label_table(torch.cat([lab_all[r, :counts[r]] for r in range(world)]),
+                            torch.cat([nrm_all[r, :counts[r]] for r in range(world)]), 0)
         del lab_all, nrm_all
     torch.cuda.synchronize(device)
     t_build = time.time() - t_build
@@ -197,52 +295,81 @@ def main():
     q = 3.0 * torch.randn((nq, D), generator=g, device=device, dtype=torch.float32)
     qs_lo, qs_hi = (nq * rank) // world, (nq * (rank + 1)) // world
 
-    knn_ms = []
+    if a.pmc_child:     # one untimed step for the counter passes of measure_traffic()
+        index.search_aggregate(q, k, beta=0.02)
+        torch.cuda.synchronize(device)
+        return
 
-    def step():
-        if world == 1:
+    knn_ms, xchg_ms = [], []
+    main_s = torch.cuda.current_stream(device)
+    overlap = dist_on and not a.no_overlap and os.environ.get("HBIRD_BENCH_OVERLAP") == "1"
+    side = torch.cuda.Stream(device) if overlap else main_s
+    ex = [hdist.PackedTopK(nq, k, device, world) for _ in range(2)] if dist_on else None
+    ev_knn = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev_done = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    used = [False, False]
+    pending = []
+
+    def step(i):
+        if not dist_on:
             return index.search_aggregate(q, k, beta=0.02)
-        # every rank searches all queries on its shard; one all-gather of the per-rank top-k + local merge;
-        # each rank then aggregates the labels for its own slice of the queries
-        idx, dist = hdist.sharded_search(index.search_scores, merge_topk, q, k, lo, 0, finish=index.distances_from_scores)
-        return index.aggregate(q[qs_lo:qs_hi], idx[qs_lo:qs_hi], dist[qs_lo:qs_hi], beta=0.02)
+        # every rank searches all queries on its shard straight into its packed list; ONE all-gather of the packed
+        # lists; merge in place; each rank then aggregates the labels for its own slice of the queries
+        b = i & 1
+        if used[b]:
+            main_s.wait_event(ev_done[b])          # the packed buffers of step i-2 have been merged
+        index.use_current_stream()
+        index.search_scores(q, k, lo, out=(ex[b].idx, ex[b].dist))
+        ev_knn[b].record(main_s)
+        with torch.cuda.stream(side):
+            side.wait_event(ev_knn[b])
+            ex[b].gather()
+            mi, md = merge_topk_packed(ex[b].recv, ex[b].part_bytes, world, nq, k, 0)
+            agg.use_current_stream()
+            out = agg.aggregate(q[qs_lo:qs_hi], mi[qs_lo:qs_hi].contiguous(), md[qs_lo:qs_hi].contiguous(), beta=0.02)
+            ev_done[b].record(side)
+        used[b] = True
+        pending.append((ev_knn[b], ev_done[b]))
+        return out
 
     def sync():
         torch.cuda.synchronize(device)
-        if world > 1:
-            torch.distributed.barrier()
+        if dist_on:
+            td.barrier(**({} if one_gpu else {"device_ids": [dev_index]}))
             torch.cuda.synchronize(device)
 
-    for _ in range(a.warmup):
-        step()
+    for i in range(a.warmup):
+        step(i)
     sync()
     index.set_timing(True)
     t0 = time.time()
-    for _ in range(a.steps):
-        step()
-        knn_ms.append(index.last_knn_ms())
+    for i in range(a.steps):
+        step(i)
+        knn_ms.append(index.last_knn_ms())        # waits for this step's kNN kernel (HIP events on its stream)
+        if dist_on and not overlap:
+            ev_done[i & 1].synchronize()
+            xchg_ms.append(ev_knn[i & 1].elapsed_time(ev_done[i & 1]))
     sync()
     dt = time.time() - t0
     index.set_timing(False)
-    if world > 1:
+    per_rank = None
+    if dist_on:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = float(t.item())
+        mine = torch.tensor([float(np.mean(knn_ms)), float(np.mean(xchg_ms)) if xchg_ms else -1.0, float(hi - lo)],
+                            device=device, dtype=torch.float64)
+        allr = torch.empty(world * 3, device=device, dtype=torch.float64)
+        td.all_gather_into_tensor(allr, mine)
+        per_rank = allr.view(world, 3).cpu().tolist()
 
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "latest_knn_traffic.json")
-    if world == 1 and os.path.exists(tpath):
-        # PMC counters cannot be read from inside the bench; the committed rocprofv3 --pmc passes of this very
-        # command (tools/gpu_profile.sh) provide them when the workload matches
-        t = json.load(open(tpath))
-        if t.get("workload") == {"bank_rows": M, "dim": D, "k": k, "queries_per_step": nq}:
-            traffic = t["traffic_bytes_per_launch"]
     if rank == 0:
         kms = float(np.mean(knn_ms))
         flops = 2.0 * nq * (hi - lo) * D
         ach = flops / (kms * 1e-3) / 1e12
         # --fp16 prices the candidate kernel against the dense fp16 matrix peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s)
         peak = PEAK_FP16_MFMA_TFLOPS if a.fp16 else PEAK_FP32_MFMA_TFLOPS
+        kernel = "knn_f16_kernel" if a.fp16 else "knn_fused_kernel"
         res = {
             "metric": "query-patches/sec", "value": nq * a.steps / dt, "unit": "query-patches/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -255,32 +382,65 @@ def main():
                        "bank_build_s": round(t_build, 2), "schedule": index.schedule_info(),
                        "use_fp16": bool(a.fp16), "fp16_fallback_queries": index.last_fp16_fallbacks() if a.fp16 else None},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                         "frac": ach / peak, "traffic": traffic,
-                         "traffic_unit": "bytes/launch (L2-miss side, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
-                         "kernel": "knn_f16_kernel" if a.fp16 else "knn_fused_kernel", "avg_kernel_ms": kms,
-                         "algorithmic_flops_per_launch": flops},
+                         "frac": ach / peak, "traffic": None,
+                         "traffic_unit": "bytes/launch (L2-miss side, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE; Infinity-Cache hits included)",
+                         "kernel": kernel, "avg_kernel_ms": kms,
+                         "algorithmic_flops_per_launch": flops,
+                         "algorithmic_bytes_per_launch": 4.0 * (hi - lo) * D + 4.0 * nq * D + 12.0 * nq * k},
         }
-        if world == 1 and not a.fp16:
+        if dist_on:
+            res["multi_gpu"] = {
+                "backend": backend + (" (RCCL)" if backend == "nccl" else " (test mode, ranks share cuda:0)"),
+                "world_size": td.get_world_size(), "rows_per_rank": [int(r[2]) for r in per_rank],
+                "knn_ms_per_rank": [round(r[0], 3) for r in per_rank],
+                "exchange_ms_per_rank": None if overlap else [round(r[1], 3) for r in per_rank],
+                "exchange": "one packed all-gather of (id int64, score fp32) [nq,k] per rank + in-place k-way merge + "
+                            "label aggregation of this rank's query slice" + (", on a side stream under the next step's kNN kernel" if overlap else
+                            ", exposed after the kNN kernel (it owns every CU's registers, nothing can run beside it)"),
+                "packed_list_bytes_per_rank": ex[0].part_bytes,
+            }
+        if world == 1 and not dist_on and not a.fp16:
             # extra, not the headline: the same step in use_fp16 mode (fp16 candidate pass + certified exact fp32
-            # re-rank; returns the identical bits) -- bound by LDS staging, not by the fp32 MFMA roof
+            # re-rank; returns the identical bits)
             index.set_fp16(True)
             index.search_aggregate(q, k, beta=0.02); torch.cuda.synchronize(device)
+            index.set_timing(True)
             t1 = time.time()
-            for _ in range(2):
+            k16 = []
+            for _ in range(3):
                 index.search_aggregate(q, k, beta=0.02)
+                k16.append(index.last_knn_ms())
             torch.cuda.synchronize(device)
-            dt16 = (time.time() - t1) / 2
+            dt16 = (time.time() - t1) / 3
+            index.set_timing(False)
             res["use_fp16_mode"] = {"value": nq / dt16, "unit": "query-patches/s", "ms_per_step": dt16 * 1e3,
                                     "fallback_queries": index.last_fp16_fallbacks(),
+                                    "candidate_kernel_ms": float(np.mean(k16)),
+                                    "candidate_kernel_frac_of_fp16_mfma_peak": flops / (float(np.mean(k16)) * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
                                     "note": "certified-exact fast mode, same outputs as the fp32 search"}
             index.set_fp16(False)
-        if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and not dist_on:
+        # roofline.traffic: live counter passes (children of this process); else the committed figure of the same
+        # workload IF it was measured on these very kernel sources; else null
+        del index, agg
+        torch.cuda.empty_cache()
+        traffic, note = (None, "skipped (--no-traffic)") if a.no_traffic else measure_traffic(a, kernel)
+        if traffic is None:
+            tpath = os.path.join(ROOT, "profiles", "latest_knn_traffic.json")
+            if os.path.exists(tpath):
+                t = json.load(open(tpath))
+                if t.get("workload") == {"bank_rows": M, "dim": D, "k": k, "queries_per_step": nq} and not a.fp16 \
+                        and t.get("kernel_source_hash") == kernel_source_hash():
+                    traffic, note = t["traffic_bytes_per_launch"], note + "; committed profiles/latest_knn_traffic.json (same kernel sources)"
+        res["roofline"]["traffic"] = traffic
+        res["roofline"]["traffic_source"] = note
+        if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(D, k, M)
-        if world == 1:
-            res["miou_parity"] = miou_parity(device)
+        res["miou_parity"] = miou_parity(device)
+    if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    if dist_on:
+        td.destroy_process_group()
 
 
 if __name__ == "__main__":

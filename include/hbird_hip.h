@@ -91,12 +91,21 @@ int hb_index_distances_from_scores(hb_index_t* ix, const float* q, int64_t nq, i
  * 53-63; here fed by an RCCL all-gather).  Device pointers. */
 int hb_merge_topk(const float* dist_parts, const int64_t* idx_parts, int parts, int64_t nq, int k, int metric,
                   int64_t* out_idx, float* out_dist, void* hip_stream);
+/* The same merge on PACKED per-shard lists, so that one rank's result travels in ONE all-gather message: a packed
+ * list is hb_packed_list_bytes(nq, k) bytes = [nq*k int64 ids][nq*k fp32 scores] (+ padding to 16 B); a search writes
+ * it when out_idx = buf and out_dist = (float*)((char*)buf + nq*k*8).  packed_parts holds `parts` such lists
+ * part_bytes apart (the all-gather's output). */
+int64_t hb_packed_list_bytes(int64_t nq, int k);
+int hb_merge_topk_packed(const void* packed_parts, int64_t part_bytes, int parts, int64_t nq, int k, int metric,
+                         int64_t* out_idx, float* out_dist, void* hip_stream);
 
 /* ---- bank build (device pointers, enqueued on hip_stream) -------------------------------------- */
 /* features / torch.norm(features, dim=-1, keepdim=True), hbird_eval.py:324, 335. */
 int hb_normalize_rows(const float* x, int64_t n, int d, float* out, void* hip_stream);
 /* _patchify_gt + one_hot(...).float().mean(dim=3), hbird_eval.py:555-573, 319-320; y[B,1,H,W] int64 ->
- * out[B, H/ps, W/ps, C]; map255 = 1 applies `y[y == 255] = 0` (hbird_eval.py:310) on the fly. */
+ * out[B, H/ps, W/ps, C]; map255 = 1 applies `y[y == 255] = 0` (hbird_eval.py:310) on the fly.  A class value outside
+ * [0, C) fails the call (F.one_hot raises for it, hbird_eval.py:319): the error flag is read back after the kernel, so
+ * this entry synchronises hip_stream. */
 int hb_patch_label_hist(const int64_t* y, int64_t B, int H, int W, int ps, int C, int map255, float* out,
                         void* hip_stream);
 /* _sample_features scores, hbird_eval.py:471-493 (presence read from the soft labels). */

@@ -41,8 +41,18 @@ int hb_launch_patch_label_hist(const int64_t* y, int64_t B, int H, int W, int ps
     const int64_t np = B * (H / ps) * (W / ps);
     if (np == 0) return 0;
     if ((size_t)C * 16 > 60000) return hb_fail("hb_patch_label_hist: too many classes");
-    patch_label_hist_kernel<<<dim3((unsigned)((np + 3) / 4)), dim3(256), (size_t)C * 16, s>>>(y, np, H, W, ps, C, map255, out, nullptr);
+    // out-of-range classes: F.one_hot of the reference raises (hbird_eval.py:319), and so does this call -- the flag is
+    // read back after the kernel (one stream synchronisation per training batch, as one_hot's own range check costs)
+    int* err = nullptr;
+    HB_HIP(hipMallocAsync((void**)&err, 4, s));
+    HB_HIP(hipMemsetAsync(err, 0, 4, s));
+    patch_label_hist_kernel<<<dim3((unsigned)((np + 3) / 4)), dim3(256), (size_t)C * 16, s>>>(y, np, H, W, ps, C, map255, out, err);
     HB_HIP(hipGetLastError());
+    int bad = 0;
+    HB_HIP(hipMemcpyAsync(&bad, err, 4, hipMemcpyDeviceToHost, s));
+    HB_HIP(hipStreamSynchronize(s));
+    HB_HIP(hipFreeAsync(err, s));
+    if (bad) return hb_fail("hb_patch_label_hist: class values must be in [0, " + std::to_string(C) + ") (out-of-range class in the mask)");
     return 0;
 }
 

@@ -4,6 +4,9 @@
 #include <cmath>
 #include <cstring>
 #include <dlfcn.h>
+#include <mutex>
+#include <set>
+#include <utility>
 
 static thread_local std::string g_err;
 void hb_set_error(const std::string& msg) { g_err = msg; }
@@ -29,9 +32,22 @@ const roctx_api& roctx() { static const roctx_api api; return api; }
 hb_range::hb_range(const char* name) { if (roctx().push) roctx().push(name); }
 hb_range::~hb_range() { if (roctx().pop) roctx().pop(); }
 
+int hb_ensure_dyn_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    HB_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({kernel, dev})) return 0;
+    HB_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({kernel, dev});
+    return 0;
+}
+
 extern "C" const char* hb_last_error(void) { return g_err.c_str(); }
 
 extern "C" int hb_device_count(int* n) {
+    if (!n) return hb_fail("hb_device_count: n is NULL");
     int c = 0;
     hipError_t e = hipGetDeviceCount(&c);
     if (e != hipSuccess) { c = 0; (void)hipGetLastError(); }
@@ -76,11 +92,30 @@ extern "C" int hb_index_free(hb_index_t* ix) {
     return 0;
 }
 
-extern "C" int hb_index_set_stream(hb_index_t* ix, void* s) { ix->stream = (hipStream_t)s; return 0; }
-extern "C" int64_t hb_index_ntotal(const hb_index_t* ix) { return ix->ntotal; }
-extern "C" int64_t hb_index_nlabels(const hb_index_t* ix) { return ix->nlabels; }
-extern "C" int hb_index_set_timing(hb_index_t* ix, int enable) { ix->time_kernels = enable; return 0; }
-extern "C" int hb_index_last_knn_ms(const hb_index_t* ix, double* ms) { *ms = ix->last_knn_ms; return 0; }
+extern "C" int hb_index_set_stream(hb_index_t* ix, void* s) {
+    if (!ix) return hb_fail("hb_index_set_stream: NULL index handle");
+    ix->stream = (hipStream_t)s;
+    return 0;
+}
+// the two counters have no status channel: a NULL handle reads as -1 rows (and sets hb_last_error)
+extern "C" int64_t hb_index_ntotal(const hb_index_t* ix) {
+    if (!ix) { hb_set_error("hb_index_ntotal: NULL index handle"); return -1; }
+    return ix->ntotal;
+}
+extern "C" int64_t hb_index_nlabels(const hb_index_t* ix) {
+    if (!ix) { hb_set_error("hb_index_nlabels: NULL index handle"); return -1; }
+    return ix->nlabels;
+}
+extern "C" int hb_index_set_timing(hb_index_t* ix, int enable) {
+    if (!ix) return hb_fail("hb_index_set_timing: NULL index handle");
+    ix->time_kernels = enable;
+    return 0;
+}
+extern "C" int hb_index_last_knn_ms(const hb_index_t* ix, double* ms) {
+    if (!ix || !ms) return hb_fail("hb_index_last_knn_ms: NULL pointer");
+    *ms = ix->last_knn_ms;
+    return 0;
+}
 extern "C" int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_tiles) {
     if (!ix) return hb_fail("hb_index_set_tuning: NULL index handle");
     // workgroups < 0 selects a timing-only ablation variant (HB_ABLATION builds): bits = -workgroups
@@ -93,7 +128,11 @@ extern "C" int hb_index_set_fp16(hb_index_t* ix, int enable) {
     return 0;
 }
 
-extern "C" int hb_index_last_fp16_fallbacks(const hb_index_t* ix, int64_t* n) { *n = ix->last_fp16_fallbacks; return 0; }
+extern "C" int hb_index_last_fp16_fallbacks(const hb_index_t* ix, int64_t* n) {
+    if (!ix || !n) return hb_fail("hb_index_last_fp16_fallbacks: NULL pointer");
+    *n = ix->last_fp16_fallbacks;
+    return 0;
+}
 
 // Host-only: build the kNN work list for a (query tiles x bank tiles) grid without touching a GPU, for inspection
 // and tests.  segs_out receives up to max_segs rows of {block, q_tile, b_tile0, n_tiles, slot, first}.
@@ -389,7 +428,11 @@ extern "C" int hb_index_copy_norms(hb_index_t* ix, float* out, int on_device) {
     return 0;
 }
 
-extern "C" int hb_index_set_score_output(hb_index_t* ix, int enable) { ix->score_output = enable ? 1 : 0; return 0; }
+extern "C" int hb_index_set_score_output(hb_index_t* ix, int enable) {
+    if (!ix) return hb_fail("hb_index_set_score_output: NULL index handle");
+    ix->score_output = enable ? 1 : 0;
+    return 0;
+}
 
 extern "C" int hb_index_distances_from_scores(hb_index_t* ix, const float* q, int64_t nq, int k, float* dist_inout) {
     if (!ix) return hb_fail("hb_index_distances_from_scores: NULL index handle");
@@ -405,7 +448,27 @@ extern "C" int hb_merge_topk(const float* dist_parts, const int64_t* idx_parts, 
                              int64_t* out_idx, float* out_dist, void* stream) {
     hb_range range("hbird:merge_topk");
     if (parts < 1 || k < 1) return hb_fail("hb_merge_topk: bad shape");
-    return hb_launch_merge_parts(dist_parts, idx_parts, parts, nq, k, metric, out_idx, out_dist, (hipStream_t)stream);
+    if (nq > 0 && (!dist_parts || !idx_parts || !out_idx || !out_dist)) return hb_fail("hb_merge_topk: NULL pointer");
+    return hb_launch_merge_parts(dist_parts, idx_parts, parts, nq, k, metric, nq * (int64_t)k, nq * (int64_t)k, out_idx, out_dist,
+                                 (hipStream_t)stream);
+}
+
+extern "C" int64_t hb_packed_list_bytes(int64_t nq, int k) {
+    const int64_t n = nq * (int64_t)k;
+    return (n * 12 + 15) / 16 * 16;
+}
+
+extern "C" int hb_merge_topk_packed(const void* packed_parts, int64_t part_bytes, int parts, int64_t nq, int k, int metric,
+                                    int64_t* out_idx, float* out_dist, void* stream) {
+    hb_range range("hbird:merge_topk");
+    if (parts < 1 || k < 1) return hb_fail("hb_merge_topk_packed: bad shape");
+    if (nq == 0) return 0;
+    if (!packed_parts || !out_idx || !out_dist) return hb_fail("hb_merge_topk_packed: NULL pointer");
+    if (part_bytes < nq * (int64_t)k * 12 || part_bytes % 8 != 0)
+        return hb_fail("hb_merge_topk_packed: part_bytes must be a multiple of 8 and hold nq*k ids (int64) + nq*k scores (fp32)");
+    const char* base = reinterpret_cast<const char*>(packed_parts);
+    return hb_launch_merge_parts(reinterpret_cast<const float*>(base + nq * (int64_t)k * 8), reinterpret_cast<const int64_t*>(base),
+                                 parts, nq, k, metric, part_bytes / 4, part_bytes / 8, out_idx, out_dist, (hipStream_t)stream);
 }
 
 extern "C" int hb_normalize_rows(const float* x, int64_t n, int d, float* out, void* stream) {

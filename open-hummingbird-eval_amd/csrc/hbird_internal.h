@@ -100,6 +100,10 @@ int hb_fail(const std::string& msg);
             return hb_fail(std::string(#call) + ": " + hipGetErrorString(_e));               \
     } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) acts on the CURRENT device only: remembers the (kernel, device)
+// pairs already configured (thread-safe), so an index on a second GPU of the same process gets its own call.
+int hb_ensure_dyn_lds(const void* kernel, int bytes);
+
 // kernels/launchers (each returns 0 or a negative status after hb_set_error)
 int hb_launch_rows_to_tiles(const float* src, int64_t n_rows, int d, int dp, int64_t row0, float* tiles,
                             float* binit, float* bnorm, int metric, int normalize, int is_bank, hipStream_t s);
@@ -121,7 +125,7 @@ int hb_knn_f16_launch(const knn16_args& args, int grid, hipStream_t s);
 int hb_launch_aggregate(const hb_index* ix, const float* qnorm, const int64_t* idx, const float* dist, int64_t nq,
                         int k, int64_t id_base, float beta, float* out, hipStream_t s);
 int hb_launch_merge_parts(const float* dist_parts, const int64_t* idx_parts, int parts, int64_t nq, int k, int metric,
-                          int64_t* out_idx, float* out_dist, hipStream_t s);
+                          int64_t dist_stride, int64_t idx_stride, int64_t* out_idx, float* out_dist, hipStream_t s);
 int hb_launch_patch_label_hist(const int64_t* y, int64_t B, int H, int W, int ps, int C, int map255, float* out,
                                hipStream_t s);
 int hb_launch_normalize_rows(const float* x, int64_t n, int d, float* out, hipStream_t s);

@@ -312,10 +312,12 @@ static int launch_merge(hb_index* ix, const float* state_s, const unsigned* stat
 
 // ---- merge of per-shard results [parts][nq][k] (multi-GPU: after the all-gather) -------------------
 // IP: larger is better; L2: smaller squared distance is better.  Ties -> lower global id.
+// A part's lists start at dist_parts + p * dist_stride / idx_parts + p * idx_stride (elements): [parts][nq][k] arrays
+// (stride nq*k) or the packed per-rank buffers of one all-gather (hb_merge_topk_packed).
 __global__ __launch_bounds__(64) void merge_parts_kernel(const float* __restrict__ dist_parts,
                                                          const int64_t* __restrict__ idx_parts, int parts, int64_t nq,
-                                                         int k, int metric, int64_t* __restrict__ out_idx,
-                                                         float* __restrict__ out_dist) {
+                                                         int k, int metric, int64_t dist_stride, int64_t idx_stride,
+                                                         int64_t* __restrict__ out_idx, float* __restrict__ out_dist) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int64_t q = blockIdx.x;
     const int n = parts * k;
@@ -323,10 +325,10 @@ __global__ __launch_bounds__(64) void merge_parts_kernel(const float* __restrict
     int64_t* ci = reinterpret_cast<int64_t*>(smem + ((n * 4 + 15) / 16) * 16);
     const int lane = threadIdx.x;
     for (int c = lane; c < n; c += 64) {
-        const size_t off = ((size_t)(c / k) * nq + q) * k + (c % k);
-        float d = dist_parts[off];
+        const size_t off = (size_t)q * k + (c % k);
+        float d = dist_parts[(size_t)(c / k) * dist_stride + off];
         cs[c] = metric == 1 ? -d : d;
-        ci[c] = idx_parts[off];
+        ci[c] = idx_parts[(size_t)(c / k) * idx_stride + off];
     }
     __syncthreads();
     for (int c = lane; c < n; c += 64) {
@@ -351,12 +353,13 @@ __global__ __launch_bounds__(64) void merge_parts_kernel(const float* __restrict
 }
 
 int hb_launch_merge_parts(const float* dist_parts, const int64_t* idx_parts, int parts, int64_t nq, int k, int metric,
-                          int64_t* out_idx, float* out_dist, hipStream_t s) {
+                          int64_t dist_stride, int64_t idx_stride, int64_t* out_idx, float* out_dist, hipStream_t s) {
     if (nq == 0) return 0;
     const size_t n = (size_t)parts * k;
     const size_t sh = ((n * 4 + 15) / 16) * 16 + n * 8;
     if (sh > 60000) return hb_fail("hb_merge_topk: parts*k too large for the merge kernel");
-    merge_parts_kernel<<<dim3((unsigned)nq), dim3(64), sh, s>>>(dist_parts, idx_parts, parts, nq, k, metric, out_idx, out_dist);
+    merge_parts_kernel<<<dim3((unsigned)nq), dim3(64), sh, s>>>(dist_parts, idx_parts, parts, nq, k, metric, dist_stride, idx_stride,
+                                                                 out_idx, out_dist);
     HB_HIP(hipGetLastError());
     return 0;
 }
@@ -599,33 +602,20 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
 #endif
     };
     static const int variant_bits[] = {0, -1, 1, 2, 4, 8, 15, 16, 13, 14, 11, 7, 3, 5, 6, 9, 10, 12, 32, 64, 96, 128, 256, 384};
-    static bool attr_set = false;
-    if (!attr_set) {
-        for (knn_fn f : variants) HB_HIP(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, KN_LDS_TOTAL));
-        attr_set = true;
-    }
     knn_fn fn = variants[wide ? 1 : 0];
     // Few stages per workgroup: the cold start of every slot (its first tile inserts all 256 rows of every query) is
     // a visible share of the search -> the instantiation with the radix-select cold start (+14 % at 50 k x 384).  The
     // big searches keep the plain instantiation: the extra code costs them 0.3 % (same-box A/B at 10 M x 768).
     static const knn_fn cold_fn = knn_fused_kernel<512, false>;
-    static bool cold_attr = false;
-    if (!wide && (long long)nqt * nbt / std::max(1, sc.G) * ix->g8 < 150000) {
-        if (!cold_attr) { HB_HIP(hipFuncSetAttribute((const void*)cold_fn, hipFuncAttributeMaxDynamicSharedMemorySize, KN_LDS_TOTAL)); cold_attr = true; }
-        fn = cold_fn;
-    }
+    if (!wide && (long long)nqt * nbt / std::max(1, sc.G) * ix->g8 < 150000) fn = cold_fn;
     if (!wide && ix->ablate)
         for (size_t i = 0; i < sizeof(variants) / sizeof(variants[0]); ++i) if (variant_bits[i] == ix->ablate) fn = variants[i];
     int threads = HB_THREADS;
     if (ix->variant == 1 && !wide) {   // the experimental 4-wave variant only has the LDS-list path
         fn = hb_knn_w4_kernel(false);
         threads = 256;
-        static bool w4_attr[1] = {false};
-        if (!w4_attr[0]) {
-            HB_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, KN_LDS_TOTAL));
-            w4_attr[0] = true;
-        }
     }
+    if (hb_ensure_dyn_lds((const void*)fn, KN_LDS_TOTAL)) return -1;   // per (kernel, device)
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev0, s));
     fn<<<dim3((unsigned)sc.G), dim3(threads), KN_LDS_TOTAL, s>>>(a);
     HB_HIP(hipGetLastError());

@@ -297,8 +297,7 @@ int hb_launch_rerank(const float* tiles, const float* binit, int g8, int d, cons
 }
 
 int hb_knn_f16_launch(const knn16_args& args, int grid, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) { HB_HIP(hipFuncSetAttribute((const void*)knn_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F16_LDS_TOTAL)); attr = true; }
+    if (hb_ensure_dyn_lds((const void*)knn_f16_kernel, F16_LDS_TOTAL)) return -1;
     knn_f16_kernel<<<dim3((unsigned)grid), dim3(HB_THREADS), F16_LDS_TOTAL, s>>>(args);
     HB_HIP(hipGetLastError());
     return 0;

@@ -150,11 +150,7 @@ int hb_launch_confusion(const int64_t* gt, const int64_t* pred, int64_t n, int n
     const size_t bins = (size_t)num_gt * num_pred;
     const int use_lds = bins * 4 <= 120 * 1024;
     const size_t sh = use_lds ? bins * 4 : 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HB_HIP(hipFuncSetAttribute((const void*)confusion_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-        attr_set = true;
-    }
+    if (hb_ensure_dyn_lds((const void*)confusion_kernel, 120 * 1024)) return -1;   // per (kernel, device)
     int64_t blocks = std::min<int64_t>((n + 255) / 256, 2048);
     confusion_kernel<<<dim3((unsigned)blocks), dim3(256), sh, s>>>(gt, pred, n, num_gt, num_pred, ignore, has_ignore, use_lds, conf);
     HB_HIP(hipGetLastError());

@@ -40,6 +40,8 @@ SIGNATURES = {
     "hb_index_set_score_output": (c_int, [c_void_p, c_int]),
     "hb_index_distances_from_scores": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "hb_merge_topk": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "hb_packed_list_bytes": (c_int64, [c_int64, c_int]),
+    "hb_merge_topk_packed": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "hb_normalize_rows": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "hb_patch_label_hist": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "hb_patch_scores": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -64,6 +66,10 @@ SIGNATURES = {
 
 class HbirdHipError(RuntimeError):
     pass
+
+
+class HbirdClassRangeError(HbirdHipError, ValueError):
+    """A mask holds a class id outside [0, num_classes): F.one_hot of the reference raises for it (hbird_eval.py:319)."""
 
 
 def lib() -> ctypes.CDLL:

@@ -4,7 +4,8 @@ hbird/nn/search_faiss.py:53-63: contiguous row ranges, successive ids) and has O
 an all-gather of the per-rank top-k lists followed by a local k-way merge.
 
 Message sizes at cfg-3 (21,904 queries, k = 30): 21,904 x 30 x (8 + 4) B = 7.9 MB per rank -- latency-bound on
-7 x 153 GB/s xGMI links, so a single flat all-gather per tensor is used (no bucketing, no ring pipelining).
+7 x 153 GB/s xGMI links, so ids and scores travel PACKED in one flat all-gather per search (`PackedTopK`: no
+bucketing, no ring pipelining, one message per rank) and the merge kernel reads the gathered buffer in place.
 """
 from __future__ import annotations
 
@@ -51,8 +52,39 @@ def allgather_rows(x: torch.Tensor) -> Tuple[torch.Tensor, List[int]]:
     return out.view((world,) + tuple(pad.shape)), counts
 
 
+class PackedTopK:
+    """One rank's top-k lists as ONE message: [nq*k int64 ids][nq*k fp32 scores] (+ padding to 16 B; the layout of
+    hb_packed_list_bytes / hb_merge_topk_packed), and the receive buffer of the all-gather ([world] such lists).
+    `idx` / `dist` are [nq, k] views into the send buffer: a search may write them directly."""
+
+    def __init__(self, nq: int, k: int, device, world: int):
+        n = nq * k
+        self.nq, self.k, self.world = nq, k, world
+        self.part_bytes = (n * 12 + 15) // 16 * 16
+        self.send = torch.zeros(self.part_bytes, dtype=torch.uint8, device=device)
+        self.recv = torch.zeros(world * self.part_bytes, dtype=torch.uint8, device=device)
+        self.idx = self.send[:n * 8].view(torch.int64).view(nq, k)
+        self.dist = self.send[n * 8:n * 12].view(torch.float32).view(nq, k)
+
+    def gather(self, async_op: bool = False):
+        """The exchange step: one all-gather of the packed lists (RCCL on the GPU box)."""
+        if self.world == 1:
+            self.recv.copy_(self.send)
+            return None
+        return td.all_gather_into_tensor(self.recv, self.send, async_op=async_op)
+
+    def parts(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(dist_parts [world, nq, k], idx_parts [world, nq, k]) copies of the gathered lists (generic merges)."""
+        n = self.nq * self.k
+        r = self.recv.view(self.world, self.part_bytes)
+        pi = r[:, :n * 8].contiguous().view(torch.int64).view(self.world, self.nq, self.k)
+        pd = r[:, n * 8:n * 12].contiguous().view(torch.float32).view(self.world, self.nq, self.k)
+        return pd, pi
+
+
 def sharded_search(local_search: Callable, merge: Callable, q: torch.Tensor, k: int, id_base: int, metric: int,
-                   finish: Optional[Callable] = None):
+                   finish: Optional[Callable] = None, merge_packed: Optional[Callable] = None,
+                   exchange: Optional[PackedTopK] = None):
     """Every rank searches ALL queries on its shard, the per-rank lists are all-gathered and merged.
 
     local_search(q, k, id_base) -> (idx int64 [nq,k] global ids, dist fp32 [nq,k]);
@@ -60,15 +92,23 @@ def sharded_search(local_search: Callable, merge: Callable, q: torch.Tensor, k: 
     With `finish`, local_search returns ORDERING scores (larger is better) instead of distances, the merge runs on them
     (metric 0 ordering) and finish(q, scores) -> distances converts the merged list: squared L2 distances round away
     score differences that the single-index search still orders by, so only this reproduces it bit for bit.
+    merge_packed(recv, part_bytes, world, nq, k, metric) -> (idx, dist), when given, merges the gathered PackedTopK
+    buffer in place (hb_merge_topk_packed); `exchange` re-uses a PackedTopK across calls of one shape.
     Every rank ends up with the same merged result (faiss.IndexShards semantics)."""
     rank, world = rank_world()
     idx, dist = local_search(q, k, id_base)
     if world == 1:
         return idx, (finish(q, dist) if finish else dist)
     nq = idx.shape[0]
-    pi = torch.empty((world * nq, k), dtype=idx.dtype, device=idx.device)
-    pd = torch.empty((world * nq, k), dtype=dist.dtype, device=dist.device)
-    td.all_gather_into_tensor(pi, idx.contiguous())
-    td.all_gather_into_tensor(pd, dist.contiguous())
-    mi, md = merge(pd.view(world, nq, k), pi.view(world, nq, k), 0 if finish else metric)
+    ex = exchange if exchange is not None and (exchange.nq, exchange.k, exchange.world) == (nq, k, world) \
+        else PackedTopK(nq, k, idx.device, world)
+    ex.idx.copy_(idx)
+    ex.dist.copy_(dist)
+    ex.gather()
+    m = 0 if finish else metric
+    if merge_packed is not None:
+        mi, md = merge_packed(ex.recv, ex.part_bytes, world, nq, k, m)
+    else:
+        pd, pi = ex.parts()
+        mi, md = merge(pd, pi, m)
     return mi, (finish(q, md) if finish else md)

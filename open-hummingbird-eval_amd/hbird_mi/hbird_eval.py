@@ -26,7 +26,7 @@ from hbird_mi import dist as hdist
 from hbird_mi import ops
 from hbird_mi import tiling
 from hbird_mi.models import FeatureExtractor, FeatureExtractorSimple
-from hbird_mi.nn.search_hip import HipFlatIndex, MAX_K, merge_topk, _METRICS
+from hbird_mi.nn.search_hip import HipFlatIndex, MAX_K, merge_topk, merge_topk_packed, _METRICS
 from hbird_mi.utils.eval_metrics import PredsmIoU
 
 try:
@@ -96,10 +96,22 @@ class HbirdEvaluation:
             for g in gpu_ids:
                 if g >= n or g < 0:
                     raise ValueError(f"Invalid GPU ID: {g}. Available GPUs: 0-{n - 1}")    # search_faiss.py:25
+            if len(set(gpu_ids)) > 1 and self.world == 1:
+                logger.warning("nn_params['gpu_ids']=%s lists %d GPUs, but the device-resident evaluator keeps the bank on "
+                               "ONE GPU per process (%s): run one rank per GPU (torchrun) with nn_params['idx_shard']=True "
+                               "to use them all, or hbird_mi.nn.search_hip.NearestNeighborSearchHIP for a multi-GPU "
+                               "index in one process", list(gpu_ids), len(set(gpu_ids)), self.gpu_device)
         if not 1 <= n_neighbours <= MAX_K:
             raise ValueError(f"n_neighbours={n_neighbours} outside the supported range [1, {MAX_K}]")
-        # a sharded bank needs >1 rank; idx_shard=False with several ranks keeps full replicas per rank
-        self.sharded = self.world > 1 and bool(nn_params.get("idx_shard", True))
+        # idx_shard keeps the reference's default (False, search_faiss.py:7): with several ranks that means a full bank
+        # replica per rank and data-parallel validation batches (faiss.IndexReplicas, 65-74); idx_shard=True row-shards
+        # the bank over the ranks (faiss.IndexShards, 53-63) -- the mode for banks that should not be built N times
+        self.sharded = self.world > 1 and bool(nn_params.get("idx_shard", False))
+        if self.world > 1:
+            logger.warning("torch.distributed world of %d ranks: bank %s (nn_params['idx_shard']=%s)", self.world,
+                           "row-sharded over the ranks" if self.sharded else "replicated on every rank", self.sharded)
+            if self.sharded:
+                self._align_cpu_rng()
 
         eval_spatial_resolution = self.feature_extractor.eval_spatial_resolution
         logger.info("Initializing memory: nn_method=%s, memory_size=%s, augmentation_epoch=%s", self.nn_method,
@@ -123,6 +135,13 @@ class HbirdEvaluation:
         self._save_memory()
         self._finalize_shards()
 
+    def _align_cpu_rng(self) -> None:
+        """Sharded bank build: every rank replays the reference's single CPU random stream (the sampling noise of
+        hbird_eval.py:500 is drawn for EVERY batch, owned or not), so all ranks must start from rank 0's state."""
+        st = torch.get_rng_state().to(self.gpu_device)
+        torch.distributed.broadcast(st, 0)
+        torch.set_rng_state(st.cpu())
+
     # ------------------------------------------------------------------------------------------------
     # bank build (reference _create_memory, hbird_eval.py:283-369)
     # ------------------------------------------------------------------------------------------------
@@ -143,6 +162,7 @@ class HbirdEvaluation:
             self.index.reserve(max(1, self.memory_size // max(1, self.world if self.sharded else 1)))
         rows_before_me = 0
         flat = 0
+        presized = self.memory_size is not None
         with torch.no_grad():
             for _ in tqdm(range(self.augmentation_epoch), desc="Augmentation loop"):
                 for x, y in tqdm(train_loader, desc="Memory Creation loop"):
@@ -160,6 +180,12 @@ class HbirdEvaluation:
                     # K2: `y[y == 255] = 0` (310) + patchify (317) + one-hot mean (319-320)
                     label = ops.patch_label_hist(y, patch_size, num_classes, map255=True)   # [bs,S,S,C]
                     if self.memory_size is None:
+                        if not presized and total_flat is not None:
+                            # the unbounded bank's size is known up front (batches x images x patches; a short last
+                            # batch only over-reserves): one allocation instead of geometric growth copies
+                            own_batches = (min(own_hi, total_flat) - own_lo) if self.sharded else total_flat
+                            self.index.reserve(max(1, int(own_batches) * bs * S * S))
+                            presized = True
                         feats = self._tokens(x)                            # [bs, S*S, D] on the GPU
                         self.index.use_current_stream()
                         self.index.add(feats.reshape(-1, feats.shape[-1]), normalize=True)   # K1 (324-329)
@@ -234,25 +260,60 @@ class HbirdEvaluation:
             return torch.zeros((0, self.num_classes))
         return self.index.gather_labels(torch.arange(n, device=self.gpu_device)).cpu()
 
+    def _gather_to_rank0(self, local: torch.Tensor) -> Optional[torch.Tensor]:
+        """Sharded mode: the shards' rows [M_r, W] (CPU) concatenated in rank order on rank 0 (None elsewhere).  Rows
+        travel GPU to GPU in chunks (send / recv work on both RCCL and gloo), so no rank stages more than a chunk."""
+        td = torch.distributed
+        counts = torch.zeros(self.world, dtype=torch.int64, device=self.gpu_device)
+        counts[self.rank] = local.shape[0]
+        td.all_reduce(counts)
+        counts = counts.cpu().tolist()
+        width = local.shape[1]
+        chunk = max(1, (256 << 20) // (4 * max(1, width)))
+        if self.rank == 0:
+            out = torch.empty((sum(counts), width), dtype=torch.float32)
+            out[:counts[0]] = local
+            base = counts[0]
+            for r in range(1, self.world):
+                for lo in range(0, counts[r], chunk):
+                    n = min(chunk, counts[r] - lo)
+                    buf = torch.empty((n, width), dtype=torch.float32, device=self.gpu_device)
+                    td.recv(buf, src=r)
+                    out[base + lo: base + lo + n] = buf.cpu()
+                base += counts[r]
+            return out
+        for lo in range(0, counts[self.rank], chunk):
+            td.send(local[lo: lo + chunk].to(self.gpu_device).contiguous(), dst=0)
+        return None
+
     def _save_memory(self) -> None:
-        sfx = f".rank{self.rank}" if self.sharded else ""
-        if self.f_mem_p is not None:
-            torch.save(self.feature_memory, self.f_mem_p + sfx)
-            logger.info("Saved feature memory to: %s", self.f_mem_p + sfx)
-        if self.l_mem_p is not None:
-            torch.save(self.label_memory, self.l_mem_p + sfx)
-            logger.info("Saved label memory to: %s", self.l_mem_p + sfx)
+        """`torch.save` of the two plain tensors, as the reference (hbird_eval.py:371-380).  Also under a row-sharded
+        bank the files hold the WHOLE bank in the reference's row order (rank 0 writes them), so a bank saved by N
+        ranks loads into one process, into the reference, or into any other number of ranks."""
+        for path, name in ((self.f_mem_p, "feature"), (self.l_mem_p, "label")):
+            if path is None:
+                continue
+            t = self.feature_memory if name == "feature" else self.label_memory
+            if self.sharded:
+                t = self._gather_to_rank0(t)
+            if t is not None:
+                torch.save(t, path)
+                logger.info("Saved %s memory to: %s", name, path)
+        if self.sharded and (self.f_mem_p is not None or self.l_mem_p is not None):
+            torch.distributed.barrier()
 
     def load_memory(self) -> bool:
-        """Load a bank saved by `_save_memory` (or by the reference) and rebuild the index from it."""
-        sfx = f".rank{self.rank}" if self.sharded else ""
-        if (self.f_mem_p is not None and self.l_mem_p is not None and os.path.isfile(self.f_mem_p + sfx)
-                and os.path.isfile(self.l_mem_p + sfx)):
-            fm = torch.load(self.f_mem_p + sfx)
-            lm = torch.load(self.l_mem_p + sfx)
+        """Load a bank saved by `_save_memory` (or by the reference) and rebuild the index from it; under a
+        row-sharded bank every rank takes its contiguous row range of the one file."""
+        if (self.f_mem_p is not None and self.l_mem_p is not None and os.path.isfile(self.f_mem_p)
+                and os.path.isfile(self.l_mem_p)):
+            fm = torch.load(self.f_mem_p, mmap=True)
+            lm = torch.load(self.l_mem_p, mmap=True)
+            lo, hi = hdist.shard_range(fm.shape[0], self.rank, self.world) if self.sharded else (0, fm.shape[0])
             self.index.reset()
-            self.index.add(fm.to(self.gpu_device), normalize=False)
-            self.index.add_labels(lm.to(self.gpu_device))
+            self.index.reserve(max(1, hi - lo))
+            self.index.add(fm[lo:hi].to(self.gpu_device), normalize=False)
+            self.index.add_labels(lm[lo:hi].to(self.gpu_device))
             self._finalize_shards()
             logger.info("Loaded memory from disk.")
             return True
@@ -269,7 +330,7 @@ class HbirdEvaluation:
         if not self.sharded:
             return self.index.search(q_flat, k, id_base=self.id_base)
         return hdist.sharded_search(self.index.search_scores, merge_topk, q_flat, k, self.id_base, self.metric,
-                                    finish=self.index.distances_from_scores)
+                                    finish=self.index.distances_from_scores, merge_packed=merge_topk_packed)
 
     def _label_hat(self, feats: torch.Tensor, want_details: bool):
         """feats [B,N,D] -> label_hat [B,N,C] (+ neighbours when details are requested)."""

@@ -92,13 +92,13 @@ class HipFlatIndex:
             return False, x
         return False, np.ascontiguousarray(x, dtype=np.float32)
 
-    def search_scores(self, q, k: int, id_base: int = 0):
+    def search_scores(self, q, k: int, id_base: int = 0, out=None):
         """Like `search`, but the second output holds the ORDERING scores (larger is better; L2: q.b - |b|^2/2), the
         input of a cross-shard merge (hb_index_set_score_output); convert with `distances_from_scores`."""
         lib = _lib.lib()
         _lib.check(lib.hb_index_set_score_output(self._h, 1))
         try:
-            return self.search(q, k, id_base)
+            return self.search(q, k, id_base, out=out)
         finally:
             _lib.check(lib.hb_index_set_score_output(self._h, 0))
 
@@ -109,11 +109,16 @@ class HipFlatIndex:
         _lib.check(_lib.lib().hb_index_distances_from_scores(self._h, _ptr(q), q.shape[0], scores.shape[1], _ptr(scores)))
         return scores
 
-    def search(self, q, k: int, id_base: int = 0):
-        """-> (idx int64 [nq,k], dist float32 [nq,k]); torch CUDA tensors for CUDA queries, numpy otherwise."""
+    def search(self, q, k: int, id_base: int = 0, out=None):
+        """-> (idx int64 [nq,k], dist float32 [nq,k]); torch CUDA tensors for CUDA queries, numpy otherwise.
+        out = (idx, dist): contiguous CUDA tensors to write into (e.g. the views of a dist.PackedTopK)."""
         on_dev, q = self._as_f32(q)
         nq = q.shape[0]
-        if on_dev:
+        if out is not None:
+            idx, dist = out
+            assert on_dev and idx.is_cuda and dist.is_cuda and idx.is_contiguous() and dist.is_contiguous()
+            assert idx.dtype == torch.int64 and dist.dtype == torch.float32 and tuple(idx.shape) == tuple(dist.shape) == (nq, k)
+        elif on_dev:
             idx = torch.empty((nq, k), dtype=torch.int64, device=q.device)
             dist = torch.empty((nq, k), dtype=torch.float32, device=q.device)
         else:
@@ -245,6 +250,18 @@ def merge_topk(dist_parts: torch.Tensor, idx_parts: torch.Tensor, metric: int):
     return idx, dist
 
 
+def merge_topk_packed(recv: torch.Tensor, part_bytes: int, parts: int, nq: int, k: int, metric: int):
+    """The gathered buffer of a dist.PackedTopK (CUDA, `parts` packed lists part_bytes apart) -> merged (idx, dist);
+    hb_merge_topk_packed reads it in place."""
+    assert recv.is_cuda and recv.is_contiguous() and recv.numel() * recv.element_size() >= parts * part_bytes
+    idx = torch.empty((nq, k), dtype=torch.int64, device=recv.device)
+    dist = torch.empty((nq, k), dtype=torch.float32, device=recv.device)
+    s = torch.cuda.current_stream(recv.device).cuda_stream
+    _lib.check(_lib.lib().hb_merge_topk_packed(_ptr(recv), int(part_bytes), int(parts), int(nq), int(k), int(metric), _ptr(idx),
+                                               _ptr(dist), ctypes.c_void_p(s)))
+    return idx, dist
+
+
 class NearestNeighborSearchHIP(NearestNeighborSearchBase):
     """Exact flat search on MI355X behind the reference's plugin interface.
 
@@ -252,7 +269,16 @@ class NearestNeighborSearchHIP(NearestNeighborSearchBase):
     `idx_shard`, `use_fp16` (fp16 candidate pass + exact fp32 re-rank: same answers as fp32, several times
     faster), `gpu_ids`.
     Unknown keywords are swallowed like the reference's **kwargs.  Like the Faiss class it does not call
-    the base constructor (search_faiss.py:7-32) and copies the bank to the GPU at construction (78-81).
+    the base constructor (search_faiss.py:7-32) and copies the bank to the GPU(s) at construction (78-81).
+
+    GPUs.  In ONE process (the reference's call shape) the plugin drives every GPU of `gpu_ids` (default: all, as
+    search_faiss.py:19-20) with one `hb_index_t` per entry and one host thread per index (faiss `threaded=True`, 57):
+    `idx_shard=True` cuts the bank into contiguous row ranges with successive ids (faiss.IndexShards, 53-63) -- every
+    GPU searches all queries on its range, the [nq, k] lists are copied to the first GPU (peer copy over xGMI) and
+    merged there by hb_merge_topk on the ordering scores, which reproduces the single-index result bit for bit;
+    `idx_shard=False` puts a full replica on every GPU and splits the queries (faiss.IndexReplicas, 65-74).
+    Under torch.distributed (one process per GPU) each rank drives its own GPU only and `idx_shard=True` shards over
+    the RANKS instead (RCCL all-gather of the packed lists + merge).
     """
 
     def __init__(self, feature_memory, n_neighbors=30, distance_measure="dot_product", idx_shard=False,
@@ -272,25 +298,33 @@ class NearestNeighborSearchHIP(NearestNeighborSearchBase):
             for gpu_id in gpu_ids:                                                 # search_faiss.py:22-25
                 if gpu_id >= self.n_gpus or gpu_id < 0:
                     raise ValueError(f"Invalid GPU ID: {gpu_id}. Available GPUs: 0-{self.n_gpus - 1}")
-        self.gpu_ids = gpu_ids
+        self.gpu_ids = list(gpu_ids)
 
-        # one process per GPU: this rank's GPU is the current torch device when it is listed, else the
-        # first listed id
-        cur = torch.cuda.current_device() if torch.cuda.is_available() else gpu_ids[0]
-        self.gpu = cur if cur in gpu_ids else gpu_ids[0]
         self.rank, self.world = 0, 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.rank, self.world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+        cur = torch.cuda.current_device() if torch.cuda.is_available() else self.gpu_ids[0]
+        if self.world > 1:
+            # one process per GPU: this rank's GPU is the current torch device when it is listed, else the first listed
+            self.local_gpus = [cur if cur in self.gpu_ids else self.gpu_ids[0]]
+        else:
+            self.local_gpus = list(self.gpu_ids)
+        self.gpu = self.local_gpus[0]
         self.id_base = 0
-        self.index = self._initialize_index()
+        self.indexes = self._initialize_index()
+        self.index = self.indexes[0]           # the first shard / replica (the only one with a single GPU)
+        self._pool = None
         self._add_features_to_index(feature_memory)
 
     def _initialize_index(self):
         if self.distance_measure not in _METRICS:
             raise ValueError(f"Unsupported distance measure: {self.distance_measure}")   # search_faiss.py:48
-        index = HipFlatIndex(self.embed_d, _METRICS[self.distance_measure], self.gpu)
-        index.set_fp16(bool(self.use_fp16))                                             # search_faiss.py:40
-        return index
+        out = []
+        for g in self.local_gpus:
+            index = HipFlatIndex(self.embed_d, _METRICS[self.distance_measure], g)
+            index.set_fp16(bool(self.use_fp16))                                         # search_faiss.py:40
+            out.append(index)
+        return out
 
     def _add_features_to_index(self, feature_memory):
         M = feature_memory.size(0)
@@ -300,8 +334,23 @@ class NearestNeighborSearchHIP(NearestNeighborSearchBase):
             per = (M + self.world - 1) // self.world
             lo, hi = min(M, self.rank * per), min(M, (self.rank + 1) * per)
         self.id_base = lo
-        self.index.reserve(max(hi - lo, 1))
-        self.index.add(feature_memory[lo:hi])
+        n = len(self.indexes)
+        self.shard_bases = []
+        for i, index in enumerate(self.indexes):
+            if self.idx_shard and n > 1:
+                per = (hi - lo + n - 1) // n
+                a, b = min(hi, lo + i * per), min(hi, lo + (i + 1) * per)
+            else:
+                a, b = lo, hi                                   # replicas (or a single index): all local rows
+            self.shard_bases.append(a)
+            index.reserve(max(b - a, 1))
+            index.add(feature_memory[a:b])
+
+    def _threads(self):
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=len(self.indexes), thread_name_prefix="hbird-gpu")
+        return self._pool
 
     def find_nearest_neighbors(self, q, k=None):
         if k is None:
@@ -312,16 +361,52 @@ class NearestNeighborSearchHIP(NearestNeighborSearchBase):
             idx, dist = self._search_device(q, k)
             return idx, dist
         q_np = q.cpu().numpy() if isinstance(q, torch.Tensor) else np.asarray(q)   # search_faiss.py:88
-        if self.idx_shard and self.world > 1:
-            idx, dist = self._search_device(torch.from_numpy(np.ascontiguousarray(q_np)).cuda(self.gpu), k)
+        if (self.idx_shard and self.world > 1) or len(self.indexes) > 1:
+            idx, dist = self._search_device(torch.from_numpy(np.ascontiguousarray(q_np, dtype=np.float32)).cuda(self.gpu), k)
             return idx.cpu().numpy(), dist.cpu().numpy()
         indices, distances = self.index.search(q_np, k, self.id_base)
         return indices, distances                                                  # (I, D) order: search_faiss.py:89-90
 
+    def _search_local(self, q: torch.Tensor, k: int, id_base_unused: int = 0, scores: bool = False):
+        """All local GPUs on q (a CUDA tensor on the first one) -> (idx, dist | ordering scores) on the first GPU."""
+        n = len(self.indexes)
+        if n == 1:
+            self.index.use_current_stream()
+            return (self.index.search_scores if scores else self.index.search)(q, k, self.shard_bases[0])
+        dev0 = torch.device("cuda", self.local_gpus[0])
+        torch.cuda.current_stream(dev0).synchronize()            # q is complete before other devices' streams read it
+        nq = q.shape[0]
+
+        def run(i):
+            index, g = self.indexes[i], self.local_gpus[i]
+            dev = torch.device("cuda", g)
+            with torch.cuda.device(dev):
+                if self.idx_shard:
+                    qi = q if dev == q.device else q.to(dev)
+                else:
+                    a, b = (nq * i) // n, (nq * (i + 1)) // n       # replicas: a slice of the queries each
+                    qi = q[a:b] if dev == q.device else q[a:b].to(dev)
+                index.use_current_stream()
+                # shards always return ordering scores: the merge must see what the single index orders by
+                idx, d = (index.search_scores if (self.idx_shard or scores) else index.search)(qi.contiguous(), k, self.shard_bases[i])
+                torch.cuda.current_stream(dev).synchronize()
+                return idx.to(dev0), d.to(dev0)                    # peer copy of the [nq, k] lists (xGMI)
+
+        parts = list(self._threads().map(run, range(n)))
+        with torch.cuda.device(dev0):
+            if not self.idx_shard:
+                return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+            idx, sc = merge_topk(torch.stack([p[1] for p in parts]), torch.stack([p[0] for p in parts]), 0)
+            if scores:
+                return idx, sc
+            self.index.use_current_stream()
+            return idx, self.index.distances_from_scores(q if q.device == dev0 else q.to(dev0), sc.contiguous())
+
     def _search_device(self, q: torch.Tensor, k: int):
-        self.index.use_current_stream()
         if self.idx_shard and self.world > 1:
             from hbird_mi import dist as hdist
-            return hdist.sharded_search(self.index.search_scores, merge_topk, q, k, self.id_base,
-                                        _METRICS[self.distance_measure], finish=self.index.distances_from_scores)
-        return self.index.search(q, k, self.id_base)
+            self.index.use_current_stream()
+            return hdist.sharded_search(lambda qq, kk, base: self._search_local(qq, kk, base, scores=True), merge_topk, q, k,
+                                        self.id_base, _METRICS[self.distance_measure],
+                                        finish=self.index.distances_from_scores, merge_packed=merge_topk_packed)
+        return self._search_local(q, k)

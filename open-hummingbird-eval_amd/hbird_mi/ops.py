@@ -43,8 +43,10 @@ def patch_label_hist(y: torch.Tensor, patch_size: int, num_classes: int, map255:
     y = y.contiguous().to(torch.int64)
     B, _, H, W = y.shape
     out = torch.empty((B, H // patch_size, W // patch_size, num_classes), dtype=torch.float32, device=y.device)
-    _lib.check(_lib.lib().hb_patch_label_hist(_p(y), B, H, W, int(patch_size), int(num_classes), int(map255), _p(out),
-                                              _stream(y)))
+    rc = _lib.lib().hb_patch_label_hist(_p(y), B, H, W, int(patch_size), int(num_classes), int(map255), _p(out), _stream(y))
+    if rc != 0 and "out-of-range class" in _lib.last_error():
+        raise _lib.HbirdClassRangeError(_lib.last_error())     # F.one_hot raises here (hbird_eval.py:319)
+    _lib.check(rc)
     return out
 
 

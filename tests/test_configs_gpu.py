@@ -1,0 +1,181 @@
+"""Parity at the shapes BASELINE.json's configs name: every config's D / k / bank size goes
+through the HIP path and is checked against the CPU oracle (oracle.knn_chain_f32: bit-exact indices and distance bits)
+where the oracle finishes in seconds, and through size-independent properties at the full sizes.
+
+  cfg-1  50,176 x 384, 12,544 queries, k = 30      full oracle (the cold-start instantiation of the kernel)
+  cfg-2  2,074,072 x 384, 12,544 queries, k = 30   full-size bank, oracle on a 512-query sample
+  cfg-3  10 M x 768, k = 30                        tests/test_knn_gpu.py::test_headline_size_10m_x_768
+  cfg-4  20,345,364 x 1024 (83 GB), k = 30         D = 1024 vs the oracle at 30 k rows + full-size property test
+  cfg-5  768-d bank, k = 90                        D = 768 / k = 90 vs the oracle + 10 M-row property test (pool path)
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+import oracle
+from hbird_mi.nn.search_hip import HipFlatIndex, NearestNeighborSearchHIP, merge_topk
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_exact(idx, dist, q, bank, k, metric, id_base=0):
+    ridx, rdist = oracle.knn_chain_f32(q, bank, k, metric, id_base)
+    idx = idx.cpu().numpy() if isinstance(idx, torch.Tensor) else idx
+    dist = dist.cpu().numpy() if isinstance(dist, torch.Tensor) else dist
+    bad = np.argwhere(idx != ridx)
+    assert bad.size == 0, f"{len(bad)} index mismatches, first {bad[:5].tolist()}"
+    assert np.array_equal(dist.view(np.uint32), rdist.view(np.uint32)), "distance bits differ"
+
+
+# ---- cfg-4's width: D = 1024 ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("metric,fp16,k", [("dot_product", False, 30), ("l2", False, 30), ("dot_product", True, 30),
+                                           ("l2", True, 30), ("dot_product", False, 90)])
+def test_cfg4_width_1024_vs_oracle(cuda_device, metric, fp16, k):
+    M, D, nq = 30_000, 1024, 700
+    bank = gi.unit_bank(M, D, seed=41)
+    bank[20_000] = bank[17]                                  # an exact tie
+    q = gi.vit_like_queries(nq, D, seed=42)
+    nn = NearestNeighborSearchHIP(torch.from_numpy(bank), n_neighbors=k, distance_measure=metric, use_fp16=fp16, gpu_ids=[0])
+    idx, dist = nn.find_nearest_neighbors(torch.from_numpy(q))
+    _check_exact(idx, dist, q, bank, k, metric)
+    nn.index.set_tuning(7, 3)                                # several slots per query tile
+    idx, dist = nn.index.search(torch.from_numpy(q).cuda(), k)
+    _check_exact(idx, dist, q, bank, k, metric)
+
+
+# ---- cfg-5's k = 90 at the real width -----------------------------------------------------------------------------
+@pytest.mark.parametrize("metric,fp16", [("dot_product", False), ("l2", False), ("dot_product", True)])
+def test_cfg5_k90_width_768_vs_oracle(cuda_device, metric, fp16):
+    M, D, nq, k = 40_000, 768, 520, 90
+    bank = gi.unit_bank(M, D, seed=51)
+    bank[39_000:39_003] = bank[5]
+    q = gi.vit_like_queries(nq, D, seed=52)
+    ix = HipFlatIndex(D, 0 if metric == "dot_product" else 1, 0)
+    ix.add(torch.from_numpy(bank).cuda())
+    ix.set_fp16(fp16)
+    idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
+    _check_exact(idx, dist, q, bank, k, metric)
+    ix.set_tuning(64, 4)
+    idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
+    _check_exact(idx, dist, q, bank, k, metric)
+
+
+# ---- cfg-1: the exact shape, full oracle ------------------------------------------------------------------------------
+def test_cfg1_exact_shape_vs_full_oracle(cuda_device):
+    """256 images x 196 patches = 50,176 bank rows of 384 dims against a 64 x 196 = 12,544-query batch: the search with few
+    bank tiles per workgroup (radix-select cold start of every slot)."""
+    M, D, nq, k = 50_176, 384, 12_544, 30
+    bank = gi.unit_bank(M, D, seed=11)
+    q = gi.vit_like_queries(nq, D, seed=12)
+    ix = HipFlatIndex(D, 0, 0)
+    ix.add(torch.from_numpy(bank).cuda())
+    idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
+    info = ix.schedule_info()
+    assert info["query_tiles"] == 49 and info["bank_tiles"] == 196
+    _check_exact(idx, dist, q, bank, k, "dot_product")
+    ix.set_fp16(True)
+    idx16, dist16 = ix.search(torch.from_numpy(q).cuda(), k)
+    assert torch.equal(idx16, idx) and torch.equal(dist16, dist)
+
+
+def _device_bank(M, D, seed, dev, targets, chunk=500_000):
+    """Rows N(0,1)/|.| generated on the device in chunks and appended to every index in `targets` whose [lo, hi) range
+    they fall into: (index, lo, hi) triples."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    for r in range(0, M, chunk):
+        n = min(chunk, M - r)
+        rows = torch.randn((n, D), generator=g, device=dev)
+        rows = rows / rows.norm(dim=1, keepdim=True)
+        for ix, lo, hi in targets:
+            a, b = max(lo, r), min(hi, r + n)
+            if a < b:
+                ix.add(rows[a - r:b - r])
+    return g
+
+
+def _float64_topk(ix, q_sel, M, k, dev, chunk=1_000_000):
+    best_s = torch.full((q_sel.shape[0], k), -float("inf"), dtype=torch.float64, device=dev)
+    best_i = torch.full((q_sel.shape[0], k), -1, dtype=torch.int64, device=dev)
+    qs = q_sel.double()
+    for r in range(0, M, chunk):
+        ids = torch.arange(r, min(M, r + chunk), device=dev)
+        sc = qs @ ix.reconstruct(ids).double().T
+        cs = torch.cat([best_s, sc], dim=1); ci = torch.cat([best_i, ids[None].expand(q_sel.shape[0], -1)], dim=1)
+        top = cs.topk(k, dim=1)
+        best_s, best_i = top.values, ci.gather(1, top.indices)
+    return best_i, best_s
+
+
+def _full_size_properties(M, D, nq, ks, dev, seed, n_plant=128):
+    """Planted neighbours, sortedness, distinct ids, determinism, 2-shard merge == single index, use_fp16 == fp32 bits,
+    and a float64 check of 16 queries against ALL rows -- for every k in `ks` on one bank."""
+    ix = HipFlatIndex(D, 0, 0); ix.reserve(M)
+    half = M // 2
+    a, b = HipFlatIndex(D, 0, 0), HipFlatIndex(D, 0, 0)
+    a.reserve(half); b.reserve(M - half)
+    g = _device_bank(M, D, seed, dev, [(ix, 0, M), (a, 0, half), (b, half, M)])
+    assert ix.ntotal == M and a.ntotal == half and b.ntotal == M - half
+    q = 3.0 * torch.randn((nq, D), generator=g, device=dev)
+    planted = torch.arange(n_plant, device=dev) * (M // n_plant) + 11
+    q[:n_plant] = 2.5 * ix.reconstruct(planted)
+    sel = torch.linspace(0, nq - 1, 16, device=dev).long()
+    out = {}
+    for k in ks:
+        idx, dist = ix.search(q, k)
+        assert (idx[:n_plant, 0] == planted).all()
+        assert (dist[:, :-1] >= dist[:, 1:]).all() and (idx >= 0).all() and (idx < M).all()
+        srt = idx.sort(dim=1).values
+        assert (srt[:, 1:] != srt[:, :-1]).all()
+        idx2, dist2 = ix.search(q, k)
+        assert torch.equal(idx, idx2) and torch.equal(dist, dist2)
+        ia, da = a.search(q, k, id_base=0)
+        ib, db = b.search(q, k, id_base=half)
+        im, dm = merge_topk(torch.stack([da, db]), torch.stack([ia, ib]), 0)
+        assert torch.equal(im, idx) and torch.equal(dm, dist)
+        out[k] = (idx, dist)
+    del a, b
+    torch.cuda.empty_cache()
+    ix.set_fp16(True)
+    for k in ks:
+        idx16, dist16 = ix.search(q, k)
+        assert torch.equal(idx16, out[k][0]) and torch.equal(dist16, out[k][1])
+        assert ix.last_fp16_fallbacks() < max(1, nq // 100)
+    ix.set_fp16(False)
+    kmax = max(ks)
+    best_i, best_s = _float64_topk(ix, q[sel], M, kmax, dev)
+    for k in ks:
+        got = out[k][0][sel].cpu().numpy(); ref = best_i[:, :k].cpu().numpy()
+        # a D-term fp32 chain at |q| ~ 3 sqrt(D) is off by a few 1e-5: positions may swap where the float64 scores are
+        # closer than that (64 fp32 ulps of the score), nowhere else
+        rep = oracle.near_tie_report(got, ref, best_s[:, :k].cpu().numpy(), ulps=64.0)
+        assert rep["excused_rate"] == 1.0 and rep["set_rate"] >= 0.8, (k, rep)
+        assert np.abs(out[k][1][sel].cpu().numpy() - best_s[:, :k].cpu().numpy()).max() < 2e-4
+
+
+def test_cfg4_full_size_20m_x_1024(cuda_device):
+    """BASELINE cfg-4: 20,345,364 x 1024 (an 83 GB bank; with the two half-size shards 166 GB of the 288 GB)."""
+    _full_size_properties(20_345_364, 1024, 16 * 1369, [30], torch.device("cuda:0"), seed=44)
+
+
+def test_cfg5_k90_full_size_10m_x_768(cuda_device):
+    """BASELINE cfg-5's retrieval shape: k = 90 over a 10 M x 768 bank (candidate pools in HBM, radix-select compaction)."""
+    _full_size_properties(10_000_000, 768, 16 * 1369, [90], torch.device("cuda:0"), seed=55)
+
+
+def test_cfg2_full_size_bank_oracle_on_a_query_sample(cuda_device):
+    """BASELINE cfg-2: the full 2,074,072 x 384 bank and the 12,544-query batch; the oracle checks a 512-query sample bit
+    for bit (the full oracle takes minutes), every query's list is checked for order and distinct ids."""
+    M, D, nq, k = 2_074_072, 384, 12_544, 30
+    dev = torch.device("cuda:0")
+    ix = HipFlatIndex(D, 0, 0); ix.reserve(M)
+    g = _device_bank(M, D, 22, dev, [(ix, 0, M)])
+    q = 3.0 * torch.randn((nq, D), generator=g, device=dev)
+    idx, dist = ix.search(q, k)
+    assert (dist[:, :-1] >= dist[:, 1:]).all() and (idx >= 0).all() and (idx < M).all()
+    sel = torch.randperm(nq, generator=torch.Generator().manual_seed(3))[:512].to(dev)
+    bank = ix.reconstruct(torch.arange(M, device=dev)).cpu().numpy()
+    _check_exact(idx[sel], dist[sel], q[sel].cpu().numpy(), bank, k, "dot_product")
+    ix.set_fp16(True)
+    idx16, dist16 = ix.search(q, k)
+    assert torch.equal(idx16, idx) and torch.equal(dist16, dist)

@@ -1,7 +1,9 @@
 """Host-side pieces that need no GPU: folder datasets (on a generated miniature VOC tree), transforms, CLI parsing,
 and the C-ABI surface (the library must load and export every symbol declared in include/hbird_hip.h)."""
+import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -110,6 +112,9 @@ def test_feature_extractor_backends_cpu():
         def get_intermediate_layers(self, x):
             return [tok]
 
+        def get_last_selfattention(self, x):
+            return None
+
     class DinoV2(torch.nn.Module):
         def forward_features(self, x):
             return {"x_norm_clstoken": tok[:, 0], "x_norm_patchtokens": tok[:, 1:]}
@@ -118,11 +123,41 @@ def test_feature_extractor_backends_cpu():
         def forward(self, x):
             return tok
 
+    class TimmLike(torch.nn.Module):
+        """timm >= 0.9 VisionTransformer: has get_intermediate_layers too, but it skips the final norm (norm=False);
+        the reference takes forward_features(imgs)[:, 1:] for this family (hbird/models.py:208-216, 344-345)."""
+
+        def __init__(self):
+            super().__init__()
+            blk = torch.nn.Module(); blk.attn = torch.nn.Identity()
+            self.blocks = torch.nn.ModuleList([blk])
+
+        def get_intermediate_layers(self, x):
+            return [tok]                              # un-normed tokens: must NOT be used
+
+        def forward_features(self, x):
+            return 2.0 * tok + 1.0                    # "after the final norm"
+
+    class HfLike(torch.nn.Module):
+        class config:
+            model_type = "vit"
+
+        def forward(self, x, output_attentions=False, return_dict=True):
+            att = torch.rand(B, 3, S * S + 1, S * S + 1)
+            return type("Out", (), {"last_hidden_state": tok, "attentions": (att,)})()
+
     x = torch.zeros(B, 3, 8, 8)
-    for m in (Dino(), DinoV2(), Plain()):
+    Dino.get_last_selfattention = lambda self, x: torch.rand(B, 2, S * S + 1, S * S + 1)
+    for m, backend, want in ((Dino(), "dino", tok[:, 1:]), (DinoV2(), "dinov2", tok[:, 1:]), (Plain(), "generic", tok[:, 1:]),
+                             (TimmLike(), "timm", 2.0 * tok[:, 1:] + 1.0), (HfLike(), "hf", tok[:, 1:])):
         fe = FeatureExtractor(m, eval_spatial_resolution=S, d_model=D)
+        assert fe.backend == backend
         out, attn = fe.forward_features(x)
-        assert attn is None and out.shape == (B, S * S, D) and torch.equal(out, tok[:, 1:])
+        assert out.shape == (B, S * S, D) and torch.equal(out, want)
+        if backend in ("dino", "hf"):
+            assert attn.shape == (B, S * S) and float(attn.min()) == 0.0 and float(attn.max()) == 1.0
+        else:
+            assert attn is None
         assert fe.eval_spatial_resolution == S and fe.d_model == D
     fs = FeatureExtractorSimple(Plain(), lambda model, imgs: model(imgs)[:, 1:], eval_spatial_resolution=S, d_model=D)
     out, attn = fs.forward_features(x)
@@ -207,3 +242,81 @@ def test_c_abi_rejects_a_null_handle_without_a_gpu():
     assert b"NULL index handle" in L.hb_last_error()
     assert L.hb_index_search(None, None, 1, 1, 0, None, None, 0) != 0
     assert L.hb_index_set_fp16(None, 1) != 0
+    # EVERY entry that takes an index handle: a NULL handle is an error (or -1 rows), never a dereference
+    import ctypes
+    ms, n64, info = ctypes.c_double(0), ctypes.c_int64(0), (ctypes.c_int64 * 8)()
+    calls = {
+        "hb_index_set_stream": (None, None), "hb_index_reserve": (None, 10), "hb_index_add_labels": (None, None, 1, 3, 0),
+        "hb_index_reset": (None,), "hb_index_search_aggregate": (None, None, 1, 1, 0, 0.02, None, None, None, 0),
+        "hb_index_aggregate": (None, None, 1, None, None, 1, 0, 0.02, None, 1),
+        "hb_index_reconstruct": (None, None, 1, 0, None, 0), "hb_index_gather_labels": (None, None, 1, 0, None, 0),
+        "hb_index_set_label_table": (None, None, None, 0, 0, 0), "hb_index_copy_norms": (None, None, 0),
+        "hb_index_set_score_output": (None, 1), "hb_index_distances_from_scores": (None, None, 1, 1, None),
+        "hb_index_set_timing": (None, 1), "hb_index_last_knn_ms": (None, ctypes.byref(ms)),
+        "hb_index_set_tuning": (None, 0, 0), "hb_index_last_fp16_fallbacks": (None, ctypes.byref(n64)),
+        "hb_index_set_variant": (None, 0), "hb_index_schedule_info": (None, info),
+    }
+    for name, args in calls.items():
+        assert getattr(L, name)(*args) != 0, name
+        assert b"NULL" in L.hb_last_error(), (name, L.hb_last_error())
+    assert L.hb_index_ntotal(None) == -1 and L.hb_index_nlabels(None) == -1
+    assert L.hb_index_free(None) == 0                       # free(NULL) is a no-op, like free()
+    taking_ix = {n for n, (_, a) in _lib.SIGNATURES.items() if n.startswith("hb_index_") and n != "hb_index_create"}
+    assert taking_ix == set(calls) | {"hb_index_add", "hb_index_search", "hb_index_set_fp16", "hb_index_ntotal",
+                                      "hb_index_nlabels", "hb_index_free"}, "an hb_index_* entry is not covered above"
+    # the packed-list helpers validate their arguments too
+    assert L.hb_packed_list_bytes(21904, 30) == (21904 * 30 * 12 + 15) // 16 * 16
+    assert L.hb_merge_topk_packed(None, 64, 2, 4, 1, 0, None, None, None) != 0
+    assert L.hb_merge_topk(None, None, 2, 4, 1, 0, None, None, None) != 0
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_gpus_n_starts_n_ranks_before_touching_a_gpu(monkeypatch):
+    """`python bench.py --gpus 2` without a torchrun environment must start 2 ranks itself (child process tree running
+    torch.distributed.run), not print a 1-GPU line; under torchrun a --gpus / WORLD_SIZE mismatch is an error."""
+    bench = _load_bench()
+    calls = {}
+
+    def fake_call(cmd, env=None):
+        calls["cmd"], calls["env"] = cmd, env
+        return 7
+
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(v, raising=False)
+    monkeypatch.setenv("HBIRD_BENCH_ONE_GPU", "1")          # no GPU count check (this container has none)
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(bench.torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("GPU touched before the launch")))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7                                  # the children's status is the parent's
+    cmd = calls["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # more ranks than GPUs is refused (normal mode)
+    monkeypatch.delenv("HBIRD_BENCH_ONE_GPU")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "GPU(s) visible" in str(e.value.code)
+    # under a launcher: WORLD_SIZE must agree with --gpus
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=4" in str(e.value.code)
+
+
+def test_bench_kernel_source_hash_tracks_the_hip_sources():
+    bench = _load_bench()
+    h = bench.kernel_source_hash()
+    assert len(h) == 16 and h == bench.kernel_source_hash()
+    t = json.load(open(os.path.join(ROOT, "profiles", "latest_knn_traffic.json")))
+    assert "traffic_bytes_per_launch" in t and "workload" in t

@@ -55,6 +55,22 @@ def _worker(rank, world, port, metric_name, M, D, nq, k, ret):
     idx, dist = hdist.sharded_search(local_search, _np_merge, torch.from_numpy(q), k, lo, metric)
     ridx, rdist = oracle.knn_chain_f32(q, bank, k, metric_name)
     ok = np.array_equal(idx.numpy(), ridx) and np.array_equal(dist.numpy(), rdist)
+    # the same search through the in-place merge hook: ONE packed all-gather message per rank, whose byte layout
+    # ([nq*k int64 ids][nq*k fp32 scores], padded to 16 B) is what hb_merge_topk_packed reads on the GPU
+    seen = {}
+
+    def merge_packed(recv, part_bytes, parts, nq_, k_, m):
+        raw = recv.numpy().reshape(parts, part_bytes)
+        n = nq_ * k_
+        pi = np.stack([raw[p, :n * 8].copy().view(np.int64).reshape(nq_, k_) for p in range(parts)])
+        pd = np.stack([raw[p, n * 8:n * 12].copy().view(np.float32).reshape(nq_, k_) for p in range(parts)])
+        seen["bytes"] = (part_bytes, recv.numel())
+        return _np_merge(torch.from_numpy(pd), torch.from_numpy(pi), m)
+
+    ex = hdist.PackedTopK(nq, k, "cpu", world)
+    idx2, dist2 = hdist.sharded_search(local_search, None, torch.from_numpy(q), k, lo, metric, merge_packed=merge_packed, exchange=ex)
+    ok = ok and np.array_equal(idx2.numpy(), ridx) and np.array_equal(dist2.numpy(), rdist)
+    ok = ok and seen["bytes"] == ((nq * k * 12 + 15) // 16 * 16, world * ((nq * k * 12 + 15) // 16 * 16))
     # ragged all-gather
     rows = torch.full((3 + 2 * rank, 4), float(rank))
     allr, counts = hdist.allgather_rows(rows)

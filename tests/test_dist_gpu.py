@@ -30,6 +30,8 @@ def _worker(rank, world, port, golden_dir, name, ret):
     g = np.load(f"{golden_dir}/g67_memory_evaluate.npz")
     c = golden_case_indexed(g, name)
     torch.set_rng_state(torch.from_numpy(g[f"rng_state_{name}"]))
+    if rank == 1:
+        torch.rand(17)       # a rank whose CPU generator has drifted: the sharded build re-aligns it with rank 0's
     ev = HbirdEvaluation(IndexedReplayExtractor(c["tokens_by_key"], c["S"], c["D"]), c["train"], num_classes=c["C"],
                          n_neighbours=c["k"], augmentation_epoch=c["aug"], device="cuda:0", nn_method="faiss",
                          nn_params={"idx_shard": True}, memory_size=c["mem"], dataset_size=c["nb"] * c["B"])
@@ -141,3 +143,52 @@ def test_two_rank_l2_plugin_search_is_bit_identical_to_single_process(cuda_devic
         assert np.array_equal(i1, i2) and np.array_equal(d1.view(np.uint32), d2.view(np.uint32))
     ridx, rdist = oracle.knn_chain_f32(gi.vit_like_queries(500, 48, seed=6), gi.unit_bank(60_000, 48, seed=5), 30, "l2")
     assert np.array_equal(i1, ridx) and np.array_equal(d1.view(np.uint32), rdist.view(np.uint32))
+
+
+def _persist_worker(rank, world, port, golden_dir, tmp, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "open-hummingbird-eval_amd"), os.path.join(root, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from helpers import IndexedReplayExtractor, golden_case_indexed
+    from hbird_mi.hbird_eval import HbirdEvaluation
+    g = np.load(f"{golden_dir}/g67_memory_evaluate.npz")
+    c = golden_case_indexed(g, "unb")
+    fp, lp = os.path.join(tmp, "fm.pt"), os.path.join(tmp, "lm.pt")
+    ev = HbirdEvaluation(IndexedReplayExtractor(c["tokens_by_key"], c["S"], c["D"]), c["train"], num_classes=c["C"],
+                         n_neighbours=c["k"], augmentation_epoch=c["aug"], device="cuda:0", nn_method="hip",
+                         nn_params={"idx_shard": True}, f_mem_p=fp, l_mem_p=lp)
+    jac = ev.evaluate(c["val"], c["S"], ignore_index=c["ign"])
+    # ONE file pair in the reference's format (whole bank, reference row order), written by rank 0
+    fm, lm = torch.load(fp), torch.load(lp)
+    ok = not os.path.exists(fp + ".rank0") and fm.shape == g["feature_memory_unb"].shape
+    ok = ok and np.abs(fm.numpy() - g["feature_memory_unb"]).max() <= 2.5e-7 and np.array_equal(lm.numpy(), g["label_memory_unb"])
+    rows_before = ev.index.ntotal
+    ev.index.reset()
+    ok = ok and ev.load_memory() and ev.index.ntotal == rows_before and ev.total_rows == fm.shape[0]
+    jac2 = ev.evaluate(c["val"], c["S"], ignore_index=c["ign"])
+    ret[rank] = (bool(ok), float(jac), float(jac2), float(g["jac_unb"]))
+    td.destroy_process_group()
+
+
+def test_two_rank_sharded_bank_saves_one_reference_format_file_pair(cuda_device, golden_dir, tmp_path):
+    """f_mem_p / l_mem_p under a row-sharded bank: the shards are gathered to rank 0 and saved as the reference's two
+    plain tensors (hbird_eval.py:371-380), so the files load into one process, the reference, or any rank count."""
+    ret = mp.Manager().dict()
+    mp.spawn(_persist_worker, args=(2, _free_port(), golden_dir, str(tmp_path), ret), nprocs=2, join=True)
+    for r in (0, 1):
+        ok, jac, jac2, ref = ret[r]
+        assert ok and abs(jac - ref) < 1e-4 and abs(jac2 - ref) < 1e-4, dict(ret)
+    # the same files in ONE process
+    from helpers import IndexedReplayExtractor, golden_case_indexed
+    from hbird_mi.hbird_eval import HbirdEvaluation
+    g = np.load(f"{golden_dir}/g67_memory_evaluate.npz")
+    c = golden_case_indexed(g, "unb")
+    ev = HbirdEvaluation(IndexedReplayExtractor(c["tokens_by_key"], c["S"], c["D"]), c["train"][:1], num_classes=c["C"],
+                         n_neighbours=c["k"], device="cuda:0", nn_method="hip")
+    ev.f_mem_p, ev.l_mem_p = str(tmp_path / "fm.pt"), str(tmp_path / "lm.pt")
+    assert ev.load_memory() and ev.index.ntotal == g["feature_memory_unb"].shape[0]
+    assert abs(ev.evaluate(c["val"], c["S"], ignore_index=c["ign"]) - float(g["jac_unb"])) < 1e-4

@@ -217,7 +217,7 @@ def _random_cases(n, seed):
     cases = []
     for i in range(n):
         M = int(rng.choice([1, 31, 255, 256, 257, 1000, 4097, 20000]))
-        D = int(rng.choice([1, 7, 8, 17, 64, 100, 384, 768]))
+        D = int(rng.choice([1, 7, 8, 17, 64, 100, 384, 768, 1024]))
         nq = int(rng.choice([1, 32, 255, 256, 257, 700]))
         k = int(rng.choice([1, 2, 29, 32, 33, 64, 65, 130, 256]))
         metric = str(rng.choice(["dot_product", "l2"]))
