@@ -153,14 +153,25 @@ int hb_index_last_fp16_fallbacks(const hb_index_t* ix, int64_t* n);
  * accumulator registers per lane).  Same results; for tuning. */
 int hb_index_set_variant(hb_index_t* ix, int variant);
 /* Work-list statistics of the last search: out[0]=workgroups, [1]=segments, [2]=slots, [3]=panel tiles,
- * [4]=max slots per query tile, [5]=query tiles, [6]=bank tiles. */
+ * [4]=max slots per query tile, [5]=query tiles, [6]=bank tiles, [7]=cluster shape (query ways * 16 + bank ways). */
 int hb_index_schedule_info(const hb_index_t* ix, int64_t out[8]);
+/* L2-sharing clusters of the kNN work list (speed only; results never depend on it): cluster_q x cluster_b workgroups
+ * of one XCD walk (cluster_q query tiles) x (cluster_b interleaved bank tiles) in lockstep, so that one L2 fill serves
+ * several workgroups.  0 x 0 or 1 x 1 = off (the default: neither kernel is bound by the fabric); q x b
+ * with q * b <= 8 otherwise (2 x 2 recommended).  sync_lag: stages a member may run ahead of the slowest one before it
+ * waits (-1 = 16, 0 = never wait). */
+int hb_index_set_cluster(hb_index_t* ix, int cluster_q, int cluster_b, int sync_lag);
+/* Soft-sync statistics of the last clustered search (synchronises the stream): out[0] = progress checks, [1] = waits
+ * (re-polls while a member was behind), [2] = members that gave up waiting (bounded spin); zeros without clusters. */
+int hb_index_cluster_stats(hb_index_t* ix, int64_t out[4]);
 
 /* Host-only (no GPU needed): the work list the kNN kernel would run for nqt query tiles (256 rows) x nbt bank tiles
- * (256 rows) on `workgroups` workgroups; panel_tiles = 0 selects the automatic panel.  segs_out (may be NULL) receives
- * up to max_segs rows {block, q_tile, b_tile0, n_tiles, slot, first}; stats as hb_index_schedule_info. */
-int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, int* segs_out, int64_t max_segs,
-                     int64_t stats[8]);
+ * (256 rows) on `workgroups` workgroups; panel_tiles = 0 selects the automatic panel; cluster_q / cluster_b as in
+ * hb_index_set_cluster (negative = automatic).  segs_out (may be NULL) receives up to max_segs rows {block, q_tile,
+ * b_tile0, n_tiles, slot, first, tile stride, cluster clock at the first tile, cluster clock of the block's next segment,
+ * progress word of the block (-1: no cluster)}; stats as hb_index_schedule_info. */
+int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b, int* segs_out,
+                     int64_t max_segs, int64_t stats[8]);
 
 #ifdef __cplusplus
 }

@@ -136,25 +136,50 @@ extern "C" int hb_index_last_fp16_fallbacks(const hb_index_t* ix, int64_t* n) {
 
 // Host-only: build the kNN work list for a (query tiles x bank tiles) grid without touching a GPU, for inspection
 // and tests.  segs_out receives up to max_segs rows of {block, q_tile, b_tile0, n_tiles, slot, first}.
-extern "C" int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, int* segs_out, int64_t max_segs,
-                                int64_t stats[8]) {
+extern "C" int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b,
+                                int* segs_out, int64_t max_segs, int64_t stats[8]) {
+    if (!stats) return hb_fail("hb_schedule_plan: stats is NULL");
     if (nqt <= 0 || nbt <= 0 || workgroups <= 0 || d <= 0) return hb_fail("hb_schedule_plan: bad arguments");
     const int dp = (d + HB_KC - 1) / HB_KC * HB_KC;
     const int G = (int)std::min<long long>(workgroups, (long long)nqt * nbt);
-    const int panel = panel_tiles > 0 ? panel_tiles : hb_default_panel(nqt, G, (size_t)HB_BT * dp * 4);
+    int cq = cluster_q, cb = cluster_b;
+    if (cq < 0 || cb < 0) hb_default_cluster(nqt, nbt, G, &cq, &cb);           // negative: the automatic shape
+    if (cq < 1 || cb < 1 || (long long)nqt * nbt < workgroups || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
+    const int panel = panel_tiles > 0 ? panel_tiles : hb_default_panel(nqt, G, (size_t)HB_BT * dp * 4, cq, cb);
     hb_schedule sc;
-    hb_build_schedule(nqt, nbt, workgroups, panel, sc);
+    hb_build_schedule(nqt, nbt, workgroups, panel, sc, cq, cb);
     stats[0] = sc.G; stats[1] = (int64_t)sc.segs.size(); stats[2] = sc.n_slots; stats[3] = sc.panel;
-    stats[4] = sc.max_slots_per_qt; stats[5] = sc.nqt; stats[6] = sc.nbt; stats[7] = 0;
+    stats[4] = sc.max_slots_per_qt; stats[5] = sc.nqt; stats[6] = sc.nbt; stats[7] = sc.cq * 16 + sc.cb;
     if (segs_out) {
         int64_t n = 0;
         for (int b = 0; b < sc.G; ++b)
             for (int i = sc.wg_off[b]; i < sc.wg_off[b + 1] && n < max_segs; ++i, ++n) {
                 const hb_seg& g = sc.segs[i];
-                int* o = segs_out + n * 6;
+                int* o = segs_out + n * 10;
                 o[0] = b; o[1] = g.q_tile; o[2] = g.b_tile0; o[3] = g.n_tiles; o[4] = g.slot; o[5] = g.first;
+                o[6] = g.stride; o[7] = g.tile0; o[8] = g.next_tile0; o[9] = sc.wg_member[b];
             }
     }
+    return 0;
+}
+
+extern "C" int hb_index_cluster_stats(hb_index_t* ix, int64_t out[4]) {
+    if (!ix || !out) return hb_fail("hb_index_cluster_stats: NULL pointer");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!ix->cl_stats_dev) return 0;
+    HB_HIP(hipSetDevice(ix->device));
+    int h[3] = {0, 0, 0};
+    HB_HIP(hipMemcpyAsync(h, ix->cl_stats_dev, sizeof(h), hipMemcpyDeviceToHost, ix->stream));
+    HB_HIP(hipStreamSynchronize(ix->stream));
+    out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
+    return 0;
+}
+
+extern "C" int hb_index_set_cluster(hb_index_t* ix, int cluster_q, int cluster_b, int sync_lag) {
+    if (!ix) return hb_fail("hb_index_set_cluster: NULL index handle");
+    if (cluster_q < 0 || cluster_b < 0 || cluster_q * cluster_b > HB_CLUSTER_MAX)
+        return hb_fail("hb_index_set_cluster: cluster shape must be 0 x 0 (automatic) or q x b with q * b <= " + std::to_string(HB_CLUSTER_MAX));
+    ix->force_cq = cluster_q; ix->force_cb = cluster_b; ix->sync_lag = sync_lag; ix->sched = hb_schedule();
     return 0;
 }
 
@@ -168,7 +193,7 @@ extern "C" int hb_index_schedule_info(const hb_index_t* ix, int64_t out[8]) {
     if (!ix) return hb_fail("hb_index_schedule_info: NULL index handle");
     const hb_schedule& s = ix->sched;
     out[0] = s.G; out[1] = (int64_t)s.segs.size(); out[2] = s.n_slots; out[3] = s.panel; out[4] = s.max_slots_per_qt;
-    out[5] = s.nqt; out[6] = s.nbt; out[7] = 0;
+    out[5] = s.nqt; out[6] = s.nbt; out[7] = s.cq * 16 + s.cb;
     return 0;
 }
 

@@ -35,23 +35,34 @@ struct hb_range {
 struct hb_seg {
     int q_tile;    // query tile index (HB_QT rows)
     int b_tile0;   // first bank tile (HB_BT rows)
-    int n_tiles;   // consecutive bank tiles
+    int n_tiles;   // bank tiles b_tile0, b_tile0 + stride, ... (ascending)
     int slot;      // partial-list slot this segment accumulates into
     int first;     // 1: slot starts empty, 0: continue from the stored lists
+    int stride;    // bank-tile stride (1, or the cluster's bank ways: the members interleave the tiles of a range)
+    int tile0;     // cluster clock (tiles) at the segment's first tile; next_tile0 at its end (INT_MAX: no more work)
+    int next_tile0;
 };
+
+#define HB_CLUSTER_MAX 8      // workgroups per L2-sharing cluster
+#define HB_CLUSTER_LINE 32    // ints per cluster in the progress array (one 128-B line)
 
 struct hb_schedule {
     int nqt = 0, nbt = 0, G = 0, panel = 0;
+    int cq = 1, cb = 1;              // cluster shape: cq query tiles x cb interleaved bank tiles (1 x 1: no clusters)
     std::vector<hb_seg> segs;        // grouped by workgroup
     std::vector<int> wg_off;         // G+1 offsets into segs
+    std::vector<int> wg_member;      // per block: cluster * HB_CLUSTER_LINE + member (progress word of the block)
     std::vector<int> qt_off;         // nqt+1 offsets into qt_slots
     std::vector<int> qt_slots;       // slots that hold partial lists of each query tile
     int n_slots = 0;
     int max_slots_per_qt = 0;
+    int n_clusters = 0;
 };
 
-void hb_build_schedule(int nqt, int nbt, int G, int panel_tiles, hb_schedule& out);
-int hb_default_panel(int nqt, int G, size_t tile_bytes);
+void hb_build_schedule(int nqt, int nbt, int G, int panel_tiles, hb_schedule& out, int cq = 1, int cb = 1);
+int hb_default_panel(int nqt, int G, size_t tile_bytes, int cq = 1, int cb = 1);
+// automatic cluster shape for a search (1 x 1 when clusters do not apply)
+void hb_default_cluster(int nqt, int nbt, int G, int* cq, int* cb);
 
 struct hb_index {
     int d = 0, dp = 0, g8 = 0, metric = 0, device = 0;
@@ -74,6 +85,9 @@ struct hb_index {
     char* tmp = nullptr; size_t tmp_bytes = 0;           // staging for host<->device convenience paths
     hb_schedule sched;                                   // cached for (nqt, nbt)
     int force_G = 0, force_panel = 0;                    // test/tuning overrides
+    int force_cq = 0, force_cb = 0;                      // cluster shape override (0 = automatic)
+    int sync_lag = -1;                                   // soft-sync lag in stages (-1 = automatic, 0 = no sync)
+    const int* cl_stats_dev = nullptr;                   // {checks, spins, timeouts} of the last clustered launch (in `state`)
     // fp16 candidate mode (use_fp16): fp16 copies of the bank / query fragment tiles, candidate buffers
     int fp16 = 0, dp16 = 0;
     void* tiles16 = nullptr; int64_t f16_cap_rows = 0, f16_rows = 0;

@@ -44,11 +44,13 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
     int* pcnt = reinterpret_cast<int*>(smem + KN_LISTS);
     const int g8 = a.g8, k = a.k;   // g8 = stages per bank tile
     const int myq = w * 32 + (lane & 31);
+    cl_sync cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + KN_CLWORDS);
 
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
     for (int si = seg_begin; si < seg_end; ++si) {
         const hb_seg seg = a.segs[si];
         const int klw = a.klw;   // list row stride (HB_KL on the LDS path)
+        const int bstride = seg.stride, clock0 = seg.tile0 * g8;
         float* wl_s = a.state_s + (size_t)seg.slot * HB_QT * klw;      // this slot's lists in global memory
         unsigned* wl_i = a.state_i + (size_t)seg.slot * HB_QT * klw;
         float thr;
@@ -69,6 +71,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
         f32x16 acc[8];
         f32x4 fa[4], fy[4], fb, fbk;   // X-half / Y-half bank fragments, query fragment (current, kept for Y)
 
+        int fpar = 0, cpar = 0;   // row-init double buffer: parity of the tile being fetched / computed
         // wave w stages bank row-tile w and query row-tile w of one k8 group (1 KiB each)
         // Only waves 0-3 issue the LDS-DMA copies (4 per stage each: bank row-tiles w, w+4 and query row-tiles
         // w, w+4).  Waves w and w+4 share a SIMD: when both stalled on a copy's issue at the same point of the
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
                     glds16(src + (size_t)4 * g8 * HB_BLK, smem + slot * KN_SLOT_BYTES + 8192 + (w + 4) * 1024);
                 }
             }
-            if (ks == 0 && w == 0) glds16(a.binit + (size_t)bt * HB_BT + lane * 4, smem + KN_BINIT + (bt & 1) * 1024);
+            if (ks == 0 && w == 0) glds16(a.binit + (size_t)bt * HB_BT + lane * 4, smem + KN_BINIT + fpar * 1024);
         };
 
         int bt = seg.b_tile0, ks = 0;          // stage being computed
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
         // stage: the steady-state loop has no data-dependent branches around its LDS traffic, so the compiler
         // counts its lgkmcnt waits instead of draining.
         auto advance_fetch = [&]() {
-            if (--left > 0) { if (++fks == g8) { fks = 0; ++fbt; } }
+            if (--left > 0) { if (++fks == g8) { fks = 0; fbt += bstride; fpar ^= 1; } }
             if (++slot_f == KN_RING) slot_f = 0;
         };
         // vmcnt is counted by hand (the compiler does not wait for LDS-DMA at a barrier): an issuing wave has
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
             const f32x4* Ac = reinterpret_cast<const f32x4*>(smem + slot_c * KN_SLOT_BYTES) + lane;
             const f32x4* An = reinterpret_cast<const f32x4*>(smem + slot_n * KN_SLOT_BYTES) + lane;
             if (ks == 0) {
-                const f32x4* bi = reinterpret_cast<const f32x4*>(smem + KN_BINIT + (bt & 1) * 1024);
+                const f32x4* bi = reinterpret_cast<const f32x4*>(smem + KN_BINIT + cpar * 1024);
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -148,6 +151,9 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
             KN_FENCE KN_MFMA(2, fa, fb, 0) KN_FENCE if constexpr (!(ABL & 2)) fy[2] = Ac[6 * 64];
             KN_FENCE KN_MFMA(3, fa, fb, 0) KN_FENCE if constexpr (!(ABL & 2)) fy[3] = Ac[7 * 64];
             KN_FENCE KN_MFMA(0, fa, fb, 1) KN_MFMA(1, fa, fb, 1) KN_FENCE
+            // cluster soft sync: wave 0 pays the issue of one more vector-memory instruction now and then (its SIMD partner
+            // covers it like it covers the copies); issued AHEAD of the stage's copies, so the hand-counted vmcnt still holds
+            if (w == 0) cl_tick(cs, clock0 + st, lane);
             if constexpr (!(ABL & 1)) issue_a(fbt, fks, slot_f);
             KN_FENCE KN_MFMA(2, fa, fb, 1) KN_MFMA(3, fa, fb, 1) KN_MFMA(0, fa, fb, 2) KN_MFMA(1, fa, fb, 2) KN_FENCE
             if constexpr (!(ABL & 1)) issue_b(fbt, fks, slot_f);
@@ -183,9 +189,10 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
                     for (int t = 0; t < 8; ++t) asm volatile("" :: "v"(acc[t]));
                 }
                 ks = 0;
-                ++bt;
+                bt += bstride; cpar ^= 1;
             }
         }
+        if (w == 0) cl_publish(cs, seg.next_tile0 == 0x7FFFFFFF ? 0x7FFFFFFF : seg.next_tile0 * g8, lane);   // covers idle units
         if constexpr (!WIDE) {   // store the partial lists of this segment
             for (int e = lane; e < 1024; e += 64) { wl_s[w * 1024 + e] = lst_s[w * 1024 + e]; wl_i[w * 1024 + e] = lst_i[w * 1024 + e]; }
         } else {
@@ -195,6 +202,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (unused) run-ahead copies
         __syncthreads();   // the ring is reused by the next segment's prologue
     }
+    cl_finish(cs, a.cl_stats, w == 0, lane);
 }
 
 // ---- merge of the partial lists of one query: rank by counting over <= slots*k candidates --------
@@ -377,23 +385,115 @@ int hb_launch_merge_parts(const float* dist_parts, const int64_t* idx_parts, int
 // sharing works (L2 hit rate 26 % -> 68 %, fabric reads -58 %, profiles/r01/README.md) but buys nothing: the fp32
 // kernel is bound by the matrix pipe (2438 vs 2413 ms) and the fp16 candidate kernel by the latency of a stage's slowest
 // line, which a 68 % hit rate does not shorten, while 3.4x more partial-list slots cost more (454 vs 413 ms).
-int hb_default_panel(int nqt, int G, size_t tile_bytes) {
-    auto gcd = [](int x, int y) { while (y) { int t = x % y; x = y; y = t; } return x; };
-    int p0 = G / gcd(nqt, G);   // smallest panel for which nqt*panel divides evenly over G workgroups
+static int hb_gcd(int x, int y) { while (y) { int t = x % y; x = y; y = t; } return x; }
+
+int hb_default_panel(int nqt, int G, size_t tile_bytes, int cq, int cb) {
+    // smallest panel for which the work of a panel divides evenly: nqt * panel pairs over G workgroups, or, with
+    // clusters, ceil(nqt / cq) * (panel / cb) units over G / (cq cb) clusters
+    int p0;
+    if (cq * cb > 1) {
+        const int NC = std::max(1, G / (cq * cb)), NQG = (nqt + cq - 1) / cq;
+        p0 = cb * (NC / hb_gcd(NQG, NC));
+    } else p0 = G / hb_gcd(nqt, G);
     size_t budget = (size_t)96 << 20;
     int j = (int)std::max<size_t>(1, budget / (tile_bytes * (size_t)p0));
     return p0 * j;
 }
 
-void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out) {
+// L2-sharing clusters: cq x cb workgroups of ONE XCD walk the same unit list in lockstep -- a unit is (cq query tiles)
+// x (cb consecutive bank tiles), member (ia, ib) takes the pair (query tile ia, bank tile ib) -- so that at any time the
+// cq members with the same ib stream the same bank tile and the cb members with the same ia the same query tile: one L2
+// fill serves cq (bank) or cb (query) consumers, fabric traffic per pair drops from Q + B to Q / cb + B / cq.  The
+// members hold each other within a few stages through the progress words (soft sync in the kernels); placement and
+// lockstep are speed only, any schedule gives the same result.
+void hb_default_cluster(int nqt, int nbt, int G, int* cq, int* cb) {
+    *cq = 1; *cb = 1;
+    if (G % 32 != 0 || (long long)nqt * nbt < 64LL * G) return;   // 2 x 2 clusters, 8 XCDs; enough work to share
+    if (nqt < 2 || (nqt % 2 != 0 && nqt < 32)) return;           // an odd query-tile count idles 1 / (nqt + 1) of the pairs
+    *cq = 2; *cb = 2;
+}
+
+static void hb_finish_schedule(hb_schedule& out, std::vector<std::vector<hb_seg>>& per_wg, const std::vector<int>& logical_of_block,
+                               const std::vector<std::vector<int>>& slots_of_qt) {
+    const int G = out.G;
+    for (auto& v : per_wg)
+        for (size_t i = 0; i < v.size(); ++i) v[i].next_tile0 = i + 1 < v.size() ? v[i + 1].tile0 : 0x7FFFFFFF;
+    out.wg_off.assign(G + 1, 0);
+    for (int b = 0; b < G; ++b) {
+        const int w = logical_of_block[b];
+        out.wg_off[b + 1] = out.wg_off[b] + (int)per_wg[w].size();
+        out.segs.insert(out.segs.end(), per_wg[w].begin(), per_wg[w].end());
+    }
+    out.qt_off.assign(out.nqt + 1, 0);
+    for (int q = 0; q < out.nqt; ++q) {
+        out.qt_off[q + 1] = out.qt_off[q] + (int)slots_of_qt[q].size();
+        out.qt_slots.insert(out.qt_slots.end(), slots_of_qt[q].begin(), slots_of_qt[q].end());
+        out.max_slots_per_qt = std::max(out.max_slots_per_qt, (int)slots_of_qt[q].size());
+    }
+}
+
+static void hb_build_clustered(int nqt, int nbt, int G, int panel, int cq, int cb, hb_schedule& out) {
+    const int CS = cq * cb, NC = G / CS, NQG = (nqt + cq - 1) / cq;
+    out.cq = cq; out.cb = cb; out.n_clusters = NC;
+    std::vector<std::vector<hb_seg>> per_wg(G);   // logical workgroup = cluster * CS + member
+    std::map<std::pair<int, int>, int> slot_of;   // (logical wg, q_tile) -> slot
+    std::vector<std::vector<int>> slots_of_qt(nqt);
+    std::vector<int> clock(NC, 0);                // cluster clock: tiles each member has been dealt (idle ones included)
+    for (int b0 = 0; b0 < nbt; b0 += panel) {
+        const int pp = std::min(panel, nbt - b0);
+        const int UB = (pp + cb - 1) / cb;        // bank groups of the panel (the last one may be partial)
+        const long long U = (long long)NQG * UB;
+        for (int c = 0; c < NC; ++c) {
+            long long e0 = (U * c) / NC, e1 = (U * (c + 1)) / NC;
+            while (e0 < e1) {
+                const int qg = (int)(e0 / UB), j0 = (int)(e0 % UB);
+                const int cnt = (int)std::min<long long>(UB - j0, e1 - e0);
+                for (int m = 0; m < CS; ++m) {
+                    const int ia = m / cb, ib = m % cb, q = qg * cq + ia, w = c * CS + m;
+                    int n = cnt;
+                    if ((j0 + cnt - 1) * cb + ib >= pp) --n;      // the partial last group has no tile for this member
+                    if (q >= nqt || n <= 0) continue;             // idle for these units (its clock still advances)
+                    hb_seg sg;
+                    sg.q_tile = q; sg.b_tile0 = b0 + j0 * cb + ib; sg.n_tiles = n; sg.stride = cb; sg.tile0 = clock[c]; sg.next_tile0 = 0;
+                    auto key = std::make_pair(w, q);
+                    auto it = slot_of.find(key);
+                    if (it == slot_of.end()) {
+                        sg.slot = out.n_slots++; sg.first = 1;
+                        slot_of[key] = sg.slot;
+                        slots_of_qt[q].push_back(sg.slot);
+                    } else { sg.slot = it->second; sg.first = 0; }
+                    per_wg[w].push_back(sg);
+                }
+                clock[c] += cnt;
+                e0 += cnt;
+            }
+        }
+    }
+    // placement (speed only): blocks b, b + 8, ... share an XCD; every XCD gets NC / 8 consecutive clusters, whole
+    std::vector<int> logical_of_block(G);
+    out.wg_member.assign(G, -1);
+    const int per_xcd = NC / 8;
+    for (int c = 0; c < NC; ++c)
+        for (int m = 0; m < CS; ++m) {
+            const int block = c / per_xcd + 8 * ((c % per_xcd) * CS + m);
+            logical_of_block[block] = c * CS + m;
+            out.wg_member[block] = c * HB_CLUSTER_LINE + m;
+        }
+    hb_finish_schedule(out, per_wg, logical_of_block, slots_of_qt);
+}
+
+void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out, int cq, int cb) {
     out = hb_schedule();
     out.nqt = nqt; out.nbt = nbt; out.panel = panel;
     const long long total_pairs = (long long)nqt * nbt;
     if (total_pairs < G) G = (int)std::max<long long>(1, total_pairs);
     out.G = G;
+    if (cq < 1 || cb < 1 || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
+    if (cq * cb > 1) { hb_build_clustered(nqt, nbt, G, panel, cq, cb, out); return; }
     std::vector<std::vector<hb_seg>> per_wg(G);
     std::map<std::pair<int, int>, int> slot_of;   // (wg, q_tile) -> slot
     std::vector<std::vector<int>> slots_of_qt(nqt);
+    std::vector<int> clock(G, 0);
     for (int b0 = 0; b0 < nbt; b0 += panel) {
         const int pp = std::min(panel, nbt - b0);
         const long long W = (long long)nqt * pp;
@@ -405,7 +505,8 @@ void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out) {
                 auto key = std::make_pair(w, q);
                 auto it = slot_of.find(key);
                 hb_seg sg;
-                sg.q_tile = q; sg.b_tile0 = b0 + b; sg.n_tiles = cnt;
+                sg.q_tile = q; sg.b_tile0 = b0 + b; sg.n_tiles = cnt; sg.stride = 1; sg.tile0 = clock[w]; sg.next_tile0 = 0;
+                clock[w] += cnt;
                 if (it == slot_of.end()) {
                     sg.slot = out.n_slots++; sg.first = 1;
                     slot_of[key] = sg.slot;
@@ -433,18 +534,8 @@ void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out) {
             logical_of_block[b] = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
         }
     }
-    out.wg_off.assign(G + 1, 0);
-    for (int b = 0; b < G; ++b) {
-        const int w = logical_of_block[b];
-        out.wg_off[b + 1] = out.wg_off[b] + (int)per_wg[w].size();
-        out.segs.insert(out.segs.end(), per_wg[w].begin(), per_wg[w].end());
-    }
-    out.qt_off.assign(nqt + 1, 0);
-    for (int q = 0; q < nqt; ++q) {
-        out.qt_off[q + 1] = out.qt_off[q] + (int)slots_of_qt[q].size();
-        out.qt_slots.insert(out.qt_slots.end(), slots_of_qt[q].begin(), slots_of_qt[q].end());
-        out.max_slots_per_qt = std::max(out.max_slots_per_qt, (int)slots_of_qt[q].size());
-    }
+    out.wg_member.assign(G, -1);
+    hb_finish_schedule(out, per_wg, logical_of_block, slots_of_qt);
 }
 
 
@@ -474,15 +565,24 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     }
     const int G = ix->force_G > 0 ? ix->force_G : ix->num_cu;
     const size_t tile_bytes = (size_t)HB_BT * ix->dp * 4;
-    const int panel = ix->force_panel > 0 ? ix->force_panel : hb_default_panel(nqt, std::min<long long>(G, (long long)nqt * nbt), tile_bytes);
+    // L2-sharing clusters are opt-in (hb_index_set_cluster): measured on 10 M x 768 they raise the L2 hit rate from 12 %
+    // to 20 % (2 x 2, any lag the cheap sync can hold) for +0.3 % kernel time, and to 53 % / -46 % fabric reads only with a
+    // per-stage exchange that costs 1.5-5 % -- the fp32 kernel is bound by the matrix pipe and the fp16 candidate kernel by
+    // its LDS traffic, neither by the fabric (profiles/r02).  The 4-wave variant does not know strided segments.
+    int cq = 1, cb = 1;
+    if (ix->force_cq > 0 && ix->force_cb > 0) { cq = ix->force_cq; cb = ix->force_cb; }
+    if (ix->variant == 1 || (long long)nqt * nbt < G || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
+    const int panel = ix->force_panel > 0 ? ix->force_panel
+                                          : hb_default_panel(nqt, std::min<long long>(G, (long long)nqt * nbt), tile_bytes, cq, cb);
     hb_schedule& sc = ix->sched;
-    const bool rebuilt = !(sc.nqt == nqt && sc.nbt == nbt && sc.panel == panel && (sc.G == G || (long long)nqt * nbt < G));
-    if (rebuilt) hb_build_schedule(nqt, nbt, G, panel, sc);
-    // device copy of the work list: [segs][wg_off][qt_off][qt_slots]
+    const bool rebuilt = !(sc.nqt == nqt && sc.nbt == nbt && sc.panel == panel && sc.cq == cq && sc.cb == cb &&
+                           (sc.G == G || (long long)nqt * nbt < G));
+    if (rebuilt) hb_build_schedule(nqt, nbt, G, panel, sc, cq, cb);
+    // device copy of the work list: [segs][wg_off][qt_off][qt_slots][wg_member]
     const size_t b_segs = sc.segs.size() * sizeof(hb_seg), b_wg = sc.wg_off.size() * 4, b_qo = sc.qt_off.size() * 4,
-                 b_qs = sc.qt_slots.size() * 4;
+                 b_qs = sc.qt_slots.size() * 4, b_wm = sc.wg_member.size() * 4;
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-    const size_t o_wg = al(b_segs), o_qo = o_wg + al(b_wg), o_qs = o_qo + al(b_qo), tot = o_qs + al(b_qs);
+    const size_t o_wg = al(b_segs), o_qo = o_wg + al(b_wg), o_qs = o_qo + al(b_qo), o_wm = o_qs + al(b_qs), tot = o_wm + al(b_wm);
     const bool need_upload = rebuilt || ix->sched_bytes < tot;
     if (ensure_bytes(&ix->sched_dev, &ix->sched_bytes, tot)) return -1;
     if (need_upload) {
@@ -490,12 +590,14 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         HB_HIP(hipMemcpyAsync(ix->sched_dev + o_wg, sc.wg_off.data(), b_wg, hipMemcpyHostToDevice, s));
         HB_HIP(hipMemcpyAsync(ix->sched_dev + o_qo, sc.qt_off.data(), b_qo, hipMemcpyHostToDevice, s));
         HB_HIP(hipMemcpyAsync(ix->sched_dev + o_qs, sc.qt_slots.data(), b_qs, hipMemcpyHostToDevice, s));
+        HB_HIP(hipMemcpyAsync(ix->sched_dev + o_wm, sc.wg_member.data(), b_wm, hipMemcpyHostToDevice, s));
         HB_HIP(hipStreamSynchronize(s));   // host vectors may be rebuilt by the next call
     }
     const size_t state_half = (size_t)sc.n_slots * HB_QT * klw * 4;
     const size_t state_aux = wide ? (size_t)sc.n_slots * HB_QT * 4 : 0;   // pools: fill counts + thresholds
     const size_t floor_bytes = (size_t)nqt * HB_QT * 4;                   // shared threshold floors, one per query
-    if (ensure_bytes(&ix->state, &ix->state_bytes, 2 * state_half + 2 * state_aux + floor_bytes)) return -1;
+    const size_t prog_bytes = ((size_t)std::max(1, sc.n_clusters) * HB_CLUSTER_MAX + 1) * HB_CLUSTER_LINE * 4;   // progress words, a line each, + statistics
+    if (ensure_bytes(&ix->state, &ix->state_bytes, 2 * state_half + 2 * state_aux + floor_bytes + prog_bytes)) return -1;
 
     knn_args a;
     a.bank_tiles = ix->tiles; a.binit = ix->binit; a.q_tiles = ix->q_tiles;
@@ -509,6 +611,15 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     const int* pool_cnt = wide ? a.state_cnt : nullptr;
     a.gthr = reinterpret_cast<unsigned*>(ix->state + 2 * state_half + 2 * state_aux);
     HB_HIP(hipMemsetD32Async((hipDeviceptr_t)a.gthr, 0x007FFFFF, (size_t)nqt * HB_QT, s));   // key(-inf)
+    a.wg_member = reinterpret_cast<const int*>(ix->sched_dev + o_wm);
+    a.prog = reinterpret_cast<int*>(ix->state + 2 * state_half + 2 * state_aux + floor_bytes);
+    a.cl = sc.cq * sc.cb;
+    // soft-sync lag in stages: the members stay inside the L2's reach (4 MiB per XCD: tens of fp32 k8 stages); 0 disables
+    // the sync (the members then share only while they happen to run together: 36 % instead of 53 % L2 hits)
+    a.lag = a.cl > 1 ? (ix->sync_lag >= 0 ? ix->sync_lag : 16) : 0;
+    a.cl_stats = a.prog + (size_t)std::max(1, sc.n_clusters) * HB_CLUSTER_MAX * HB_CLUSTER_LINE;
+    ix->cl_stats_dev = a.cl > 1 ? a.cl_stats : nullptr;
+    if (a.cl > 1) HB_HIP(hipMemsetAsync(a.prog, 0, prog_bytes, s));
     if (f16) {
         // bring the fp16 copies of the bank / query fragment tiles up to date
         const int64_t need_rt = (ix->ntotal + 31) / 32;
@@ -534,6 +645,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         h.bank16 = reinterpret_cast<const _Float16*>(ix->tiles16); h.binit = ix->binit; h.q16 = reinterpret_cast<const _Float16*>(ix->q16); h.segs = a.segs; h.wg_off = a.wg_off;
         h.state_s = a.state_s; h.state_i = a.state_i; h.g16 = ix->dp16 / 16; h.k = kc; h.klw = klw;
         h.state_cnt = a.state_cnt; h.state_thr = a.state_thr; h.gthr = a.gthr;
+        h.wg_member = a.wg_member; h.prog = a.prog; h.cl = a.cl; h.lag = a.lag; h.cl_stats = a.cl_stats;
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev0, s));
         if (hb_knn_f16_launch(h, sc.G, s)) return -1;
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));

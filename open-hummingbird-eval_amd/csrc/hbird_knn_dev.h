@@ -23,6 +23,11 @@ struct knn_args {
     int* state_cnt;     // pools only: fill count and threshold per (slot, query), kept between segments
     float* state_thr;
     unsigned* gthr;     // [query]: shared threshold floor (monotone key of a score that k rows are known to reach)
+    const int* wg_member;   // per block: progress word of the block in `prog` (cluster * HB_CLUSTER_LINE + member)
+    int* prog;              // cluster progress words (stage clocks), zeroed before the launch
+    int cl;                 // workgroups per cluster (1: no clusters)
+    int lag;                // soft sync: a member waits while another one is more than `lag` stages behind (0: never)
+    int* cl_stats;          // {checks, spins, timeouts} of the launch
 };
 
 // arguments of the fp16 candidate kernel (hbird_knn_f16.hip); the fields shared with knn_args mean the same
@@ -40,7 +45,92 @@ struct knn16_args {
     int* state_cnt;
     float* state_thr;
     unsigned* gthr;
+    const int* wg_member;
+    int* prog;
+    int cl;
+    int lag;
+    int* cl_stats;
 };
+
+// ---- soft sync of an L2-sharing cluster (hb_build_clustered) ---------------------------------------------------------
+// The members of a cluster run the same stage sequence; one L2 fill serves several of them only while they stay within
+// a few stages of each other (an XCD's 4 MiB L2 turns over in tens of stages).  They mostly do by themselves (same start,
+// same work); what drifts them apart is slow (epilogue insertions, memory jitter).  So every member publishes its stage
+// clock every 4 stages (one fire-and-forget store to a 128-B line of its own), looks at the others once per HB_CL_PERIOD
+// stages (one LDS-DMA load of the members' words into a few words of LDS, read a few stages later so that its latency is
+// never waited for), and holds back only while the slowest member is more than `lag` stages behind.  No data is handed
+// over, so nothing depends on it: the spin is bounded, and a member that times out stops syncing for the rest of the
+// launch.
+// What it costs was measured on the fp32 kernel (10 M x 768, one box, kernel ms; plain list 2360-2380):
+//  * loads / stores the compiler tracks: it waits for them at the next control-flow merge -- a write-through round trip
+//    per exchange, +3..5 %.  Hence an inline-asm store and an LDS-DMA load (both invisible to the wait-count pass).
+//  * issued by wave 4..7 (the waves without copies): +3.4 % at one store per 4 stages, wherever it sits in the stage --
+//    a vector-memory instruction queues behind the CU's LDS-DMA copies, the wave stalls on its issue, and a wave and
+//    its SIMD partner stalled together idle the matrix pipe.  Issued by wave 0, which already pays that price for its
+//    copies and whose partner covers it, AHEAD of the stage's copies (so that the hand-counted vmcnt still holds):
+//    +1.9 % without any sharing, +0.3 % net with it.
+#define HB_CL_PERIOD 32
+struct cl_sync {
+    int* line;      // progress words of the cluster, one 128-B line per member
+    int* lds;       // HB_CLUSTER_MAX words of LDS: landing zone of the poll
+    int me, cl, lag;
+    int n_checks, n_spins, n_timeouts;   // statistics of this workgroup (hb_index_cluster_stats)
+    bool on;
+};
+__device__ __forceinline__ void cl_store(int* p, int v) {
+    asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void cl_poll(const cl_sync& cs, int lane) {
+    // lanes < cl: member `lane`'s progress word -> lds[lane] (LDS-DMA: wave-uniform LDS base + 4 * lane; sc1 = past the L1)
+    if (lane < cs.cl) __builtin_amdgcn_global_load_lds((gbl_cvoid*)(cs.line + lane * HB_CLUSTER_LINE), (lds_void*)cs.lds, 4, 0, 16);
+}
+__device__ __forceinline__ int cl_min_landed(const cl_sync& cs, int lane, bool wait) {
+    if (wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int m = lane < cs.cl ? cs.lds[lane] : 0x7FFFFFFF;
+#pragma unroll
+    for (int o = 1; o < HB_CLUSTER_MAX; o <<= 1) m = min(m, __shfl_xor(m, o));
+    return __builtin_amdgcn_readfirstlane(m);
+}
+// Called by wave 0, once per stage (acts every 4th), ahead of the stage's copies.
+__device__ __forceinline__ void cl_tick(cl_sync& cs, int now, int lane) {
+    if (!cs.on || (now & 3) != 0) return;
+    if (lane == 0) cl_store(cs.line + cs.me * HB_CLUSTER_LINE, now);
+    const int ph = now & (HB_CL_PERIOD - 1);
+    if (ph == 4) cl_poll(cs, lane);
+    else if (ph == 12) {
+        // the poll was issued two exchanges ago, ahead of that stage's copies: the per-stage vmcnt wait has covered it
+        bool wait = false;
+        int spins = 0;
+        ++cs.n_checks;
+        while (cl_min_landed(cs, lane, wait) < now - cs.lag) {
+            wait = true;
+            ++cs.n_spins;
+            if (++spins > 4000) { cs.on = false; ++cs.n_timeouts; break; }      // a member is not running (yet): never wait for it again
+            __builtin_amdgcn_s_sleep(8);
+            cl_poll(cs, lane);
+        }
+    }
+}
+__device__ __forceinline__ void cl_publish(const cl_sync& cs, int clock, int lane) {
+    if (cs.cl > 1 && lane == 0) cl_store(cs.line + cs.me * HB_CLUSTER_LINE, clock);
+}
+__device__ __forceinline__ cl_sync cl_init(const int* wg_member, int* prog, int cl, int lag, int block, bool poller, char* lds_words) {
+    cl_sync cs;
+    const int mem = cl > 1 ? wg_member[block] : -1;
+    cs.line = prog + (mem < 0 ? 0 : (mem & ~(HB_CLUSTER_LINE - 1)) * HB_CLUSTER_MAX);   // a 128-B line per MEMBER
+    cs.lds = reinterpret_cast<int*>(lds_words);
+    cs.me = mem < 0 ? 0 : mem & (HB_CLUSTER_LINE - 1);
+    cs.cl = cl; cs.lag = lag;
+    cs.n_checks = cs.n_spins = cs.n_timeouts = 0;
+    cs.on = mem >= 0 && lag > 0 && poller;
+    return cs;
+}
+// end of the kernel: add this workgroup's statistics to the launch's (three words behind the progress lines)
+__device__ __forceinline__ void cl_finish(const cl_sync& cs, int* stats, bool poller, int lane) {
+    if (cs.cl > 1 && poller && lane == 0 && cs.n_checks) {
+        atomicAdd(stats, cs.n_checks); atomicAdd(stats + 1, cs.n_spins); atomicAdd(stats + 2, cs.n_timeouts);
+    }
+}
 
 __device__ __forceinline__ void glds16(const float* gsrc, char* lds_base) {
     // 64 lanes x 16 B: per-lane global source, LDS destination = wave-uniform base + 16*lane
@@ -286,7 +376,8 @@ __device__ __forceinline__ float cold_start_threshold(const f32x16 (&acc)[8], in
 #define KN_BINIT (KN_RING * KN_SLOT_BYTES)  // 2 x 1 KiB
 #define KN_LISTS (KN_BINIT + 2048)
 #define KN_SCRATCH (KN_LISTS + 2 * HB_QT * HB_KL * 4)
-#define KN_LDS_TOTAL (KN_SCRATCH + 8192)      // scratch: 1 KiB per wave (8 waves) / 2 KiB per wave (4 waves)
+#define KN_CLWORDS (KN_SCRATCH + 8192)        // scratch: 1 KiB per wave (8 waves) / 2 KiB per wave (4 waves)
+#define KN_LDS_TOTAL (KN_CLWORDS + 64)        // landing zone of the cluster progress poll
 #define KN_FENCE __builtin_amdgcn_sched_barrier(0);
 
 typedef void (*hb_knn_fn)(knn_args);

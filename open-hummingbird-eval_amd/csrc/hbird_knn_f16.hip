@@ -23,7 +23,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define F16_BINIT (F16_RING * F16_SLOT_BYTES)
 #define F16_SCRATCH (F16_BINIT + 2048)
 #define F16_PCNT (F16_SCRATCH + 8192)                  // pool fill counts of the 256 queries
-#define F16_LDS_TOTAL (F16_PCNT + 1024)
+#define F16_CLWORDS (F16_PCNT + 1024)                  // landing zone of the cluster progress poll
+#define F16_LDS_TOTAL (F16_CLWORDS + 64)
 static_assert(F16_LDS_TOTAL <= 160 * 1024, "LDS budget");
 
 // fp32 fragment tiles -> fp16 fragment tiles.  fp16 block(rt, g16) = 32 rows x 16 k = 1 KiB, element (i, kk) at half
@@ -81,10 +82,13 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
     const int g16 = a.g16, k = a.k, klw = a.klw;
     const int NS = g16 / F16_GROUPS;   // k32 stages per bank tile
     const int myq = w * 32 + (lane & 31);
+    cl_sync cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + F16_CLWORDS);
 
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
     for (int si = seg_begin; si < seg_end; ++si) {
         const hb_seg seg = a.segs[si];
+        const int bstride = seg.stride;
+        int fpar = 0, cpar = 0;   // row-init double buffer: parity of the tile being fetched / computed
         float* wl_s = a.state_s + (size_t)seg.slot * HB_QT * klw;
         unsigned* wl_i = a.state_i + (size_t)seg.slot * HB_QT * klw;
         const knn_args_pool_view pv{a.state_cnt, a.state_thr};
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
             }
         };
         auto issue_binit = [&](int bt, int ks) {
-            if (ks == 0 && w == 0) glds16(a.binit + (size_t)bt * HB_BT + lane * 4, smem + F16_BINIT + (bt & 1) * 1024);
+            if (ks == 0 && w == 0) glds16(a.binit + (size_t)bt * HB_BT + lane * 4, smem + F16_BINIT + fpar * 1024);
         };
 
         // vmcnt is counted by hand as in the fp32 kernel: an issuing wave has 8 copies per stage in flight (wave 0 a ninth,
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
         int slot_c = 0, slot_f = 0;
         int left = total;
         auto advance_fetch = [&]() {
-            if (--left > 0) { if (++fks == NS) { fks = 0; ++fbt; } }
+            if (--left > 0) { if (++fks == NS) { fks = 0; fbt += bstride; fpar ^= 1; } }
             if (++slot_f == F16_RING) slot_f = 0;
         };
         for (int p = 0; p < F16_RING; ++p) {
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
         __syncthreads();
         f16x8 fa[8], ga[8], fb, gb;                         // fragments of the current / the next k16 group
 #define F16_MM(T, FA, FB) acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[T], FB, acc[T], 0, 0, 0);
-        for (int tl = 0; tl < seg.n_tiles; ++tl, ++bt) {
+        for (int tl = 0; tl < seg.n_tiles; ++tl, bt += bstride, cpar ^= 1) {
             {   // first fragments of the tile (read again rather than kept live across the epilogue: fewer registers)
                 const f16x8* A = reinterpret_cast<const f16x8*>(smem + slot_c * F16_SLOT_BYTES) + lane;
 #pragma unroll
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
                 fb = A[F16_HALF / 16 + (w * F16_GROUPS) * 64];
             }
             {   // accumulators start from the bank rows' init values (landed with the tile's first stage)
-                const f32x4* bi = reinterpret_cast<const f32x4*>(smem + F16_BINIT + (bt & 1) * 1024);
+                const f32x4* bi = reinterpret_cast<const f32x4*>(smem + F16_BINIT + cpar * 1024);
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -179,6 +183,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
                 __syncthreads();                                      // ... everyone's have, and this stage's slot has been read
                 // ---- group 1; fillers: the first fragments of the next stage and the copies of the stage four ahead ----
                 KN_FENCE F16_MM(0, ga, gb) KN_FENCE fa[0] = An[(0 * F16_GROUPS) * 64]; fb = An[F16_HALF / 16 + (w * F16_GROUPS) * 64];
+                if (w == 0) cl_tick(cs, (seg.tile0 + tl) * NS + ks, lane);   // cluster soft sync, ahead of the stage's copies (vmcnt)
                 issue_one(0, fbt, fks, slot_f);
                 KN_FENCE F16_MM(1, ga, gb) KN_FENCE fa[1] = An[(1 * F16_GROUPS) * 64]; issue_one(1, fbt, fks, slot_f);
                 KN_FENCE F16_MM(2, ga, gb) KN_FENCE fa[2] = An[(2 * F16_GROUPS) * 64]; issue_one(2, fbt, fks, slot_f);
@@ -200,11 +205,13 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
 #endif
         }
 #undef F16_MM
+        if (w == 0) cl_publish(cs, seg.next_tile0 == 0x7FFFFFFF ? 0x7FFFFFFF : seg.next_tile0 * NS, lane);   // covers idle units
         pool_end(pv, seg.slot, pcnt, thr, myq, lane);
         if (lane < 32) floor_publish(a.gthr, seg.q_tile * HB_QT + myq, thr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    cl_finish(cs, a.cl_stats, w == 0, lane);
 }
 
 // Exact re-rank: one wave per query; lane j scores candidates j, j+64, ... with the fp32 chain arithmetic of the fp32

@@ -231,11 +231,22 @@ class HipFlatIndex:
     def set_variant(self, variant: int):
         _lib.check(_lib.lib().hb_index_set_variant(self._h, int(variant)))
 
+    def set_cluster(self, cluster_q: int = 0, cluster_b: int = 0, sync_lag: int = -1):
+        """L2-sharing clusters of the work list (speed only, opt-in): 0 x 0 / 1 x 1 off, e.g. 2 x 2; sync_lag in stages."""
+        _lib.check(_lib.lib().hb_index_set_cluster(self._h, int(cluster_q), int(cluster_b), int(sync_lag)))
+
+    def cluster_stats(self) -> dict:
+        out = (ctypes.c_int64 * 4)()
+        _lib.check(_lib.lib().hb_index_cluster_stats(self._h, out))
+        return {"checks": int(out[0]), "waits": int(out[1]), "timeouts": int(out[2])}
+
     def schedule_info(self) -> dict:
         out = (ctypes.c_int64 * 8)()
         _lib.check(_lib.lib().hb_index_schedule_info(self._h, out))
         keys = ["workgroups", "segments", "slots", "panel_tiles", "max_slots_per_qtile", "query_tiles", "bank_tiles"]
-        return dict(zip(keys, list(out)[:7]))
+        d = dict(zip(keys, list(out)[:7]))
+        d["cluster"] = [int(out[7]) // 16, int(out[7]) % 16]
+        return d
 
 
 def merge_topk(dist_parts: torch.Tensor, idx_parts: torch.Tensor, metric: int):

@@ -254,7 +254,8 @@ def test_c_abi_rejects_a_null_handle_without_a_gpu():
         "hb_index_set_score_output": (None, 1), "hb_index_distances_from_scores": (None, None, 1, 1, None),
         "hb_index_set_timing": (None, 1), "hb_index_last_knn_ms": (None, ctypes.byref(ms)),
         "hb_index_set_tuning": (None, 0, 0), "hb_index_last_fp16_fallbacks": (None, ctypes.byref(n64)),
-        "hb_index_set_variant": (None, 0), "hb_index_schedule_info": (None, info),
+        "hb_index_set_variant": (None, 0), "hb_index_schedule_info": (None, info), "hb_index_set_cluster": (None, 2, 2, 16),
+        "hb_index_cluster_stats": (None, info),
     }
     for name, args in calls.items():
         assert getattr(L, name)(*args) != 0, name

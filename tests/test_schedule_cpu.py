@@ -10,14 +10,17 @@ import pytest
 from hbird_mi import _lib
 
 
-def plan(nqt, nbt, G, panel, d=768):
+def plan(nqt, nbt, G, panel, d=768, cluster=(1, 1)):
+    """-> (rows {block, q_tile, b_tile0, n_tiles, slot, first, stride, tile0, next_tile0, progress word}, stats)."""
     stats = (ctypes.c_int64 * 8)()
-    _lib.check(_lib.lib().hb_schedule_plan(nqt, nbt, G, panel, d, None, 0, stats))
+    _lib.check(_lib.lib().hb_schedule_plan(nqt, nbt, G, panel, d, cluster[0], cluster[1], None, 0, stats))
     nseg = stats[1]
-    buf = np.zeros((nseg, 6), dtype=np.int32)
-    _lib.check(_lib.lib().hb_schedule_plan(nqt, nbt, G, panel, d, buf.ctypes.data_as(ctypes.c_void_p), nseg, stats))
+    buf = np.zeros((nseg, 10), dtype=np.int32)
+    _lib.check(_lib.lib().hb_schedule_plan(nqt, nbt, G, panel, d, cluster[0], cluster[1], buf.ctypes.data_as(ctypes.c_void_p), nseg, stats))
     keys = ["workgroups", "segments", "slots", "panel_tiles", "max_slots_per_qtile", "query_tiles", "bank_tiles"]
-    return buf, dict(zip(keys, list(stats)[:7]))
+    st = dict(zip(keys, list(stats)[:7]))
+    st["cluster"] = (int(stats[7]) // 16, int(stats[7]) % 16)
+    return buf, st
 
 
 @pytest.mark.parametrize("nqt,nbt,G,panel", [
@@ -34,7 +37,8 @@ def test_work_list_invariants(nqt, nbt, G, panel):
     slot_q, slot_blk, slot_last, slot_first_seen = {}, {}, {}, set()
     per_block = np.zeros(st["workgroups"], dtype=np.int64)
     last_block = -1
-    for blk, q, b0, n, slot, first in segs.tolist():
+    for blk, q, b0, n, slot, first, stride, tile0, next_tile0, member in segs.tolist():
+        assert stride == 1 and member == -1
         assert 0 <= q < nqt and 0 <= b0 and n > 0 and b0 + n <= nbt
         assert blk >= last_block; last_block = blk              # segments are grouped by block
         cover[q, b0:b0 + n] += 1
@@ -59,3 +63,82 @@ def test_work_list_invariants(nqt, nbt, G, panel):
 def test_headline_plan_numbers():
     _, st = plan(86, 39063, 256, 0)
     assert st["panel_tiles"] == 128 and st["slots"] == 340 and st["max_slots_per_qtile"] == 4
+
+
+@pytest.mark.parametrize("nqt,nbt,G,panel,cq,cb", [
+    (86, 39063, 256, 0, 2, 2),      # headline, the automatic shape
+    (86, 39063, 256, 0, -1, -1),    # ... selected automatically
+    (86, 39063, 256, 0, 4, 2), (86, 39063, 256, 0, 2, 4), (86, 39063, 256, 0, 1, 4), (86, 39063, 256, 0, 8, 1),
+    (49, 8102, 256, 0, 2, 2),       # cfg-2: odd query-tile count (one member pair idles for the last query group)
+    (86, 4883, 256, 0, 2, 2),       # one of 8 shards
+    (7, 1001, 64, 0, 2, 2), (5, 333, 32, 7, 2, 2), (86, 500, 256, 33, 2, 2), (3, 4, 256, 0, 2, 2), (86, 300, 104, 0, 2, 2),
+])
+def test_clustered_work_list_invariants(nqt, nbt, G, panel, cq, cb):
+    """L2-sharing clusters: cq x cb workgroups walk (cq query tiles) x (cb interleaved bank tiles) units on a common
+    clock.  Same correctness invariants as the plain list, plus: members of a cluster sit on one XCD (blocks equal
+    mod 8), and at every clock tick the members that are busy hold pairs of ONE unit -- same bank-tile group for all,
+    the same bank tile for equal bank way, the same query tile for equal query way."""
+    segs, st = plan(nqt, nbt, G, panel, cluster=(cq, cb))
+    a, b = st["cluster"]
+    if cq < 0:
+        assert (a, b) == ((2, 2) if nqt * nbt >= 64 * G and G % 32 == 0 else (1, 1))
+    elif G % (8 * cq * cb) != 0 or nqt * nbt < G:
+        assert (a, b) == (1, 1)                                  # falls back to the plain list
+    else:
+        assert (a, b) == (cq, cb)
+    assert st["workgroups"] == min(G, nqt * nbt)
+    cover = np.zeros((nqt, nbt), dtype=np.int32)
+    slot_q, slot_blk, slot_last, started = {}, {}, {}, set()
+    per_block = np.zeros(st["workgroups"], dtype=np.int64)
+    at = {}                       # (cluster, clock) -> list of (member, q, bank tile)
+    blk_clock = {}
+    last_block = -1
+    for blk, q, b0, n, slot, first, stride, tile0, next_tile0, member in segs.tolist():
+        assert blk >= last_block; last_block = blk
+        assert stride == (b if a * b > 1 else 1) and n > 0
+        tiles = b0 + stride * np.arange(n)
+        assert 0 <= q < nqt and tiles[0] >= 0 and tiles[-1] < nbt
+        cover[q, tiles] += 1
+        per_block[blk] += n
+        if first:
+            assert slot not in started
+            started.add(slot); slot_q[slot] = q; slot_blk[slot] = blk
+        assert slot in started and slot_q[slot] == q and slot_blk[slot] == blk
+        assert b0 > slot_last.get(slot, -1), "bank tiles of a slot must ascend"
+        slot_last[slot] = int(tiles[-1])
+        assert tile0 >= blk_clock.get(blk, 0), "a block's clock never runs backwards"
+        blk_clock[blk] = tile0 + n
+        assert next_tile0 >= tile0 + n                          # 0x7fffffff after the block's last segment
+        if a * b > 1:
+            cl, m = member // 32, member % 32
+            assert 0 <= m < a * b and blk % 8 == (cl // (st["workgroups"] // (a * b) // 8))   # whole clusters per XCD
+            if nqt * nbt <= 600_000 or cl % 16 == 3:            # per-tick check: all clusters of the small cases, a sample of the big
+                for j in range(n):
+                    at.setdefault((cl, tile0 + j), []).append((m, q, int(tiles[j])))
+        else:
+            assert member == -1
+    assert (cover == 1).all(), "every (query tile, bank tile) pair exactly once"
+    assert len(started) == st["slots"]
+    for (cl, t), mem in at.items():
+        assert len({m for m, _, _ in mem}) == len(mem) <= a * b
+        P = st["panel_tiles"]
+        assert len({(bt // P, (bt % P) // b) for _, _, bt in mem}) == 1, "members of a tick work on one bank-tile group"
+        for m, q, bt in mem:
+            for m2, q2, bt2 in mem:
+                if m % b == m2 % b:
+                    assert bt == bt2                             # equal bank way: the SAME bank tile (shared through L2)
+                if m // b == m2 // b:
+                    assert q == q2                               # equal query way: the SAME query tile
+    if a * b > 1:
+        # balance: whole units are dealt, so blocks differ by at most one tile per panel (plus idle members of a ragged
+        # last query group / bank group)
+        npanels = -(-nbt // st["panel_tiles"])
+        busy = per_block[per_block > 0]
+        assert busy.max() - np.median(busy) <= npanels + 1
+        if nqt % a == 0:
+            assert busy.max() - busy.min() <= 2 * npanels + 1
+
+
+def test_headline_clustered_plan_numbers():
+    _, st = plan(86, 39063, 256, 0, cluster=(2, 2))
+    assert st["cluster"] == (2, 2) and st["panel_tiles"] == 128 and st["slots"] <= 440 and st["max_slots_per_qtile"] <= 8
