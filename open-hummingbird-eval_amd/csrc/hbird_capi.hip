@@ -67,7 +67,7 @@ extern "C" int hb_index_create(int d, int metric, int device, hb_index_t** out) 
         return hb_fail("hb_index_create: invalid GPU id " + std::to_string(device) + ", available 0-" + std::to_string(ndev - 1));
     HB_HIP(hipSetDevice(device));
     hb_index* ix = new hb_index();
-    ix->d = d; ix->dp = (d + HB_KC - 1) / HB_KC * HB_KC; ix->g8 = ix->dp / 8; ix->dp16 = (d + 63) / 64 * 64; ix->metric = metric; ix->device = device;
+    ix->d = d; ix->dp = (d + HB_KC - 1) / HB_KC * HB_KC; ix->g8 = ix->dp / 8; ix->dp16 = (d + 127) / 128 * 128; ix->metric = metric; ix->device = device;
     hipDeviceProp_t prop;
     HB_HIP(hipGetDeviceProperties(&prop, device));
     ix->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -75,6 +75,7 @@ extern "C" int hb_index_create(int d, int metric, int device, hb_index_t** out) 
     HB_HIP(hipMemset(ix->bmax, 0, 4));
     HB_HIP(hipEventCreate(&ix->ev0));
     HB_HIP(hipEventCreate(&ix->ev1));
+    if (const char* v = getenv("HBIRD_KNN_VARIANT")) ix->variant = atoi(v) >= 0 && atoi(v) <= 2 ? atoi(v) : 0;   // A/B of kernel variants
     *out = ix;
     return 0;
 }
@@ -185,7 +186,7 @@ extern "C" int hb_index_set_cluster(hb_index_t* ix, int cluster_q, int cluster_b
 
 extern "C" int hb_index_set_variant(hb_index_t* ix, int variant) {
     if (!ix) return hb_fail("hb_index_set_variant: NULL index handle");
-    if (variant < 0 || variant > 1) return hb_fail("hb_index_set_variant: unknown kernel variant");
+    if (variant < 0 || variant > 2) return hb_fail("hb_index_set_variant: unknown kernel variant");
     ix->variant = variant;
     return 0;
 }

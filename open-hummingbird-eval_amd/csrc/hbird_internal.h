@@ -135,7 +135,7 @@ int hb_launch_bnorm_max(const float* bnorm, int64_t n, float* bmax, hipStream_t 
 int hb_launch_scatter_rows(const int64_t* rows, int64_t n, int k, const int64_t* src_idx, const float* src_dist,
                            int64_t* out_idx, float* out_dist, hipStream_t s);
 struct knn16_args;
-int hb_knn_f16_launch(const knn16_args& args, int grid, hipStream_t s);
+int hb_knn_f16_launch(const knn16_args& args, int grid, int design, hipStream_t s);
 int hb_launch_aggregate(const hb_index* ix, const float* qnorm, const int64_t* idx, const float* dist, int64_t nq,
                         int k, int64_t id_base, float beta, float* out, hipStream_t s);
 int hb_launch_merge_parts(const float* dist_parts, const int64_t* idx_parts, int parts, int64_t nq, int k, int metric,

@@ -571,7 +571,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // its LDS traffic, neither by the fabric (profiles/r02).  The 4-wave variant does not know strided segments.
     int cq = 1, cb = 1;
     if (ix->force_cq > 0 && ix->force_cb > 0) { cq = ix->force_cq; cb = ix->force_cb; }
-    if (ix->variant == 1 || (long long)nqt * nbt < G || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
+    if (ix->variant != 0 || (long long)nqt * nbt < G || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
     const int panel = ix->force_panel > 0 ? ix->force_panel
                                           : hb_default_panel(nqt, std::min<long long>(G, (long long)nqt * nbt), tile_bytes, cq, cb);
     hb_schedule& sc = ix->sched;
@@ -647,7 +647,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         h.state_cnt = a.state_cnt; h.state_thr = a.state_thr; h.gthr = a.gthr;
         h.wg_member = a.wg_member; h.prog = a.prog; h.cl = a.cl; h.lag = a.lag; h.cl_stats = a.cl_stats;
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev0, s));
-        if (hb_knn_f16_launch(h, sc.G, s)) return -1;
+        if (hb_knn_f16_launch(h, sc.G, ix->variant == 2 ? 2 : 1, s)) return -1;
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
         if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
                          reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, kc, klw, 0, 0, nullptr,

@@ -186,9 +186,9 @@ __device__ __forceinline__ unsigned pool_kth(const unsigned (&key)[EMAX], bool (
     return prefix;
 }
 
-// Compact the full pool (cap entries) at (gs, gi) to its best k in entries [0, k); returns the k-th best score.
+// Compact the full pool (cap entries, cap <= 64 EMAX) at (gs, gi) to its best k in entries [0, k); returns the k-th best score.
+template <int EMAX = HB_POOL_MAX / 64>
 __device__ __forceinline__ float pool_compact(float* gs, unsigned* gi, int cap, int k, int lane) {
-    constexpr int EMAX = HB_POOL_MAX / 64;
     const int E = cap >> 6;
     float es[EMAX];
     unsigned ei[EMAX], key[EMAX];
@@ -244,7 +244,7 @@ __device__ __forceinline__ float pool_compact(float* gs, unsigned* gi, int cap, 
 // qb = first of the 32 queries (of the workgroup's 256) that `acc` holds.
 // WIDE = false: lst_s / lst_i are the sorted LDS lists.  WIDE = true: they are the slot's pools in global memory
 // (row stride klw = capacity) and `cnt` holds the fill counts of the workgroup's 256 queries in LDS.
-template <bool SLOW = true, bool WIDE = false>
+template <bool SLOW = true, bool WIDE = false, int EMAX = HB_POOL_MAX / 64>
 __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, float* lst_s, unsigned* lst_i, float* sc,
                                               int qb, int lane, int k, unsigned bt, int klw = HB_KL, int* cnt = nullptr) {
     unsigned qmask = 0;   // bit 4t+q: quarter q (8 bank rows) of row tile t holds a score above its query's threshold
@@ -285,7 +285,7 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, floa
                         const int n = __builtin_ctzll(full) & 31;
                         full &= full - 1;
                         const size_t off = (size_t)(qb + n) * klw;
-                        const float kth = pool_compact(lst_s + off, lst_i + off, klw, k, lane);
+                        const float kth = pool_compact<EMAX>(lst_s + off, lst_i + off, klw, k, lane);
                         if (lane == 0) cnt[qb + n] = k;
                         if ((lane & 31) == n) thr = fmaxf(thr, kth);
                     }

@@ -214,6 +214,161 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
     cl_finish(cs, a.cl_stats, w == 0, lane);
 }
 
+// ---- second design of the candidate kernel -----------------------------------------------------------------------------
+// What bounds the kernel above was measured in round 2 (profiles/r02): NOT the fabric -- the L2's average read latency
+// at the memory side is ~610 cycles under this kernel's load (TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ), and 41 % fewer
+// fabric reads (L2-sharing clusters) bought 1.7 % -- but the LDS: per k16 group the workgroup reads 72 KiB of fragments
+// (>= 288 cycles) and takes in 16 KiB of LDS-DMA copies (281 cycles: an LDS-DMA byte costs the LDS about four times a
+// read byte) against 512 cycles of matrix work per SIMD, and the two streams serialise.
+// A wave's query fragment (32 queries x k16 = 1 KiB per group) is read by that wave ONLY: staging it through LDS buys no
+// reuse.  Here it goes straight from global memory into registers (inline-asm global_load_dwordx4, four k32 stages ahead,
+// counted by hand with the copies), which halves the LDS-DMA traffic and drops the ninth fragment read of every group;
+// the ring then holds bank fragments only (8 slots x 16 KiB) and the bank fragments need ONE register set: fragment t is
+// re-loaded right after MFMA t has issued, 8 MFMAs before its next use.  Per group: 64 KiB of reads + 8 KiB of copies.
+// Stages are unrolled by four so that the register buffers of the query fragments have static indices.
+#define F2_RING 8
+#define F2_SLOT 16384                                  // bank fragments of one k32 stage: [row tile 0..7][group 0..1][1 KiB]
+#define F2_BINIT (F2_RING * F2_SLOT)
+#define F2_SCRATCH (F2_BINIT + 2048)
+#define F2_PCNT (F2_SCRATCH + 8192)
+#define F2_LDS_TOTAL (F2_PCNT + 1024)
+static_assert(F2_LDS_TOTAL <= 160 * 1024, "LDS budget");
+
+template <int EMAX>   // pool capacity / 64 that the instantiation can compact (registers of the rare compaction path)
+__global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    float* sc = reinterpret_cast<float*>(smem + F2_SCRATCH) + w * 256;
+    int* pcnt = reinterpret_cast<int*>(smem + F2_PCNT);
+    const int g16 = a.g16, k = a.k, klw = a.klw;
+    const int NS = g16 / 2;   // k32 stages per bank tile, a multiple of 4 (dp16 is a multiple of 128)
+    const int myq = w * 32 + (lane & 31);
+    const unsigned lane_off = (unsigned)lane * 16u;
+
+    const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
+    for (int si = seg_begin; si < seg_end; ++si) {
+        const hb_seg seg = a.segs[si];
+        const int bstride = seg.stride;
+        float* wl_s = a.state_s + (size_t)seg.slot * HB_QT * klw;
+        unsigned* wl_i = a.state_i + (size_t)seg.slot * HB_QT * klw;
+        const knn_args_pool_view pv{a.state_cnt, a.state_thr};
+        float thr = pool_begin(pv, seg.slot, seg.first, pcnt, myq, lane);
+        thr = fmaxf(thr, floor_load(a.gthr, seg.q_tile * HB_QT + myq));
+        const int total = seg.n_tiles * NS;
+        f32x16 acc[8];
+        f16x8 fa[8];        // bank fragments of the current group (one set)
+        f16x8 bq[4][2];     // query fragments of four stages, two k16 groups each
+
+        // A batch = what one wave requests for one stage: its two 1 KiB bank pieces (row tile w, both groups; LDS-DMA) and
+        // its own two query fragments (registers).  Wave 0 adds the row-init values with the first stage of a tile.
+        const char* bank_w = reinterpret_cast<const char*>(a.bank16) + (size_t)w * g16 * 1024;
+        const char* query_w = reinterpret_cast<const char*>(a.q16) + (size_t)(seg.q_tile * 8 + w) * g16 * 1024;
+        int fbt = seg.b_tile0, fks = 0, slot_f = 0, left = total, fpar = 0;
+#define F2_BATCH(B0, B1)                                                                                                     \
+        {                                                                                                                    \
+            const char* bsrc = bank_w + ((size_t)fbt * 8 * g16 + (size_t)fks * 2) * 1024 + lane_off;                        \
+            char* bdst = smem + slot_f * F2_SLOT + w * 2048;                                                                 \
+            __builtin_amdgcn_global_load_lds((gbl_cvoid*)bsrc, (lds_void*)bdst, 16, 0, 0);                                   \
+            __builtin_amdgcn_global_load_lds((gbl_cvoid*)(bsrc + 1024), (lds_void*)(bdst + 1024), 16, 0, 0);                 \
+            const char* qsrc = query_w + (size_t)fks * 2048;                                                                 \
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(B0) : "v"(lane_off), "s"(qsrc) : "memory");                 \
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(B1) : "v"(lane_off), "s"(qsrc) : "memory");     \
+            if (fks == 0 && w == 0) glds16(a.binit + (size_t)fbt * HB_BT + lane * 4, smem + F2_BINIT + fpar * 1024);        \
+            if (--left > 0) { if (++fks == NS) { fks = 0; fbt += bstride; fpar ^= 1; } }                                     \
+            slot_f = (slot_f + 1) & (F2_RING - 1);                                                                           \
+        }
+        // vmcnt by hand: a batch is 4 requests in a fixed order (wave 0: now and then 5, which only makes a wait stricter).
+        // Batch j (stage j's data) is issued during stage j - 4.  Stage s + 1 must have landed at the barrier in the middle
+        // of stage s: batches s - 2 and s - 1 are younger -> "all but the newest 8".  Past the last stage the fetch position
+        // stays put (same requests again, results unused), so the count never changes.
+        F2_BATCH(bq[0][0], bq[0][1]) F2_BATCH(bq[1][0], bq[1][1]) F2_BATCH(bq[2][0], bq[2][1]) F2_BATCH(bq[3][0], bq[3][1])
+        asm volatile("s_waitcnt vmcnt(12)" : "+v"(bq[0][0]), "+v"(bq[0][1]) :: "memory");   // stage 0 has landed
+        __syncthreads();
+        int slot_c = 0, ks = 0, bt = seg.b_tile0, cpar = 0;
+#define F2_INIT_TILE()                                                                                                       \
+        {                                                                                                                    \
+            const f32x4* bi = reinterpret_cast<const f32x4*>(smem + F2_BINIT + cpar * 1024);                                 \
+            _Pragma("unroll") for (int t = 0; t < 8; ++t)                                                                    \
+                _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                              \
+                    const f32x4 v = bi[8 * t + 2 * g + h];                                                                   \
+                    acc[t][4 * g + 0] = v[0]; acc[t][4 * g + 1] = v[1]; acc[t][4 * g + 2] = v[2]; acc[t][4 * g + 3] = v[3]; \
+                }                                                                                                            \
+        }
+        {
+            const f16x8* A = reinterpret_cast<const f16x8*>(smem) + lane;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) fa[t] = A[(t * 2) * 64];
+        }
+        F2_INIT_TILE()
+#define F2_MM(T, B) acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[T], B, acc[T], 0, 0, 0);
+#define F2_STAGE(U)                                                                                                          \
+        {                                                                                                                    \
+            const f16x8* Ac = reinterpret_cast<const f16x8*>(smem + slot_c * F2_SLOT) + lane;                                \
+            const int slot_n = (slot_c + 1) & (F2_RING - 1);                                                                 \
+            const f16x8* An = reinterpret_cast<const f16x8*>(smem + slot_n * F2_SLOT) + lane;                                \
+            /* group 0; filler after MFMA t: fragment t of group 1 */                                                        \
+            KN_FENCE F2_MM(0, bq[U][0]) KN_FENCE fa[0] = Ac[(0 * 2 + 1) * 64];                                               \
+            KN_FENCE F2_MM(1, bq[U][0]) KN_FENCE fa[1] = Ac[(1 * 2 + 1) * 64];                                               \
+            KN_FENCE F2_MM(2, bq[U][0]) KN_FENCE fa[2] = Ac[(2 * 2 + 1) * 64];                                               \
+            KN_FENCE F2_MM(3, bq[U][0]) KN_FENCE fa[3] = Ac[(3 * 2 + 1) * 64];                                               \
+            KN_FENCE F2_MM(4, bq[U][0]) KN_FENCE fa[4] = Ac[(4 * 2 + 1) * 64];                                               \
+            KN_FENCE F2_MM(5, bq[U][0]) KN_FENCE fa[5] = Ac[(5 * 2 + 1) * 64];                                               \
+            KN_FENCE F2_MM(6, bq[U][0]) KN_FENCE fa[6] = Ac[(6 * 2 + 1) * 64];                                               \
+            KN_FENCE F2_MM(7, bq[U][0]) KN_FENCE fa[7] = Ac[(7 * 2 + 1) * 64];                                               \
+            KN_FENCE                                                                                                         \
+            /* the next stage has landed: my requests (and my query fragments of it), then everyone's */                    \
+            asm volatile("s_waitcnt vmcnt(8)" : "+v"(bq[(U + 1) & 3][0]), "+v"(bq[(U + 1) & 3][1]) :: "memory");             \
+            __builtin_amdgcn_s_barrier();   /* raw: __syncthreads() would drain the LDS-DMA copies (vmcnt(0)) */             \
+            /* group 1; filler after MFMA t: fragment t of the next stage's group 0; then this stage's batch */              \
+            KN_FENCE F2_MM(0, bq[U][1]) KN_FENCE fa[0] = An[(0 * 2) * 64];                                                   \
+            KN_FENCE F2_MM(1, bq[U][1]) KN_FENCE fa[1] = An[(1 * 2) * 64];                                                   \
+            KN_FENCE F2_MM(2, bq[U][1]) KN_FENCE fa[2] = An[(2 * 2) * 64];                                                   \
+            KN_FENCE F2_MM(3, bq[U][1]) KN_FENCE fa[3] = An[(3 * 2) * 64];                                                   \
+            KN_FENCE F2_MM(4, bq[U][1]) KN_FENCE fa[4] = An[(4 * 2) * 64];                                                   \
+            KN_FENCE F2_MM(5, bq[U][1]) KN_FENCE fa[5] = An[(5 * 2) * 64];                                                   \
+            KN_FENCE F2_MM(6, bq[U][1]) KN_FENCE fa[6] = An[(6 * 2) * 64];                                                   \
+            KN_FENCE F2_MM(7, bq[U][1]) KN_FENCE fa[7] = An[(7 * 2) * 64];                                                   \
+            KN_FENCE                                                                                                         \
+            F2_BATCH(bq[U][0], bq[U][1])                                                                                     \
+            KN_FENCE                                                                                                         \
+            slot_c = slot_n;                                                                                                 \
+        }
+        for (int st = 0; st < total; st += 4) {
+            F2_STAGE(0) F2_STAGE(1) F2_STAGE(2) F2_STAGE(3)
+            ks += 4;
+            if (ks == NS) {
+#if defined(F16_ABL) && (F16_ABL & 1)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) asm volatile("" :: "v"(acc[t]));   // timing only: no epilogue
+#else
+                tile_epilogue<true, true, EMAX>(acc, thr, wl_s, wl_i, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
+#endif
+                ks = 0; bt += bstride; cpar ^= 1;
+                F2_INIT_TILE()
+                {   // the next tile's first fragments again (rather than kept live across the epilogue: fewer registers)
+                    const f16x8* A = reinterpret_cast<const f16x8*>(smem + slot_c * F2_SLOT) + lane;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) fa[t] = A[(t * 2) * 64];
+                }
+            }
+        }
+        // the run-ahead requests still target the query-fragment registers: drain them while those registers are live
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]), "+v"(bq[2][0]), "+v"(bq[2][1]),
+                     "+v"(bq[3][0]), "+v"(bq[3][1]) :: "memory");
+#undef F2_STAGE
+#undef F2_MM
+#undef F2_INIT_TILE
+#undef F2_BATCH
+        pool_end(pv, seg.slot, pcnt, thr, myq, lane);
+        if (lane < 32) floor_publish(a.gthr, seg.q_tile * HB_QT + myq, thr);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
 // Exact re-rank: one wave per query; lane j scores candidates j, j+64, ... with the fp32 chain arithmetic of the fp32
 // kernel (acc = row init; acc = fmaf(q_k, b_k, acc) for k ascending over the fp32 fragment tiles), then the wave
 // ranks them by (score desc, id asc) and writes the best k.
@@ -303,7 +458,14 @@ int hb_launch_rerank(const float* tiles, const float* binit, int g8, int d, cons
     return 0;
 }
 
-int hb_knn_f16_launch(const knn16_args& args, int grid, hipStream_t s) {
+int hb_knn_f16_launch(const knn16_args& args, int grid, int design, hipStream_t s) {
+    if (design == 2 && args.cl == 1) {   // second design (no cluster support)
+        void (*fn)(knn16_args) = args.klw <= 256 ? knn_f16v2_kernel<4> : knn_f16v2_kernel<8>;
+        if (hb_ensure_dyn_lds((const void*)fn, F2_LDS_TOTAL)) return -1;
+        fn<<<dim3((unsigned)grid), dim3(HB_THREADS), F2_LDS_TOTAL, s>>>(args);
+        HB_HIP(hipGetLastError());
+        return 0;
+    }
     if (hb_ensure_dyn_lds((const void*)knn_f16_kernel, F16_LDS_TOTAL)) return -1;
     knn_f16_kernel<<<dim3((unsigned)grid), dim3(HB_THREADS), F16_LDS_TOTAL, s>>>(args);
     HB_HIP(hipGetLastError());
