@@ -149,17 +149,18 @@ int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_tiles);
 int hb_index_set_fp16(hb_index_t* ix, int enable);
 /* Number of queries of the last fp16-mode search that needed the exact fp32 re-search. */
 int hb_index_last_fp16_fallbacks(const hb_index_t* ix, int64_t* n);
-/* kNN kernel variant: 0 = 8 waves per workgroup (two per SIMD, default), 1 = 4 waves (one per SIMD, 256
- * accumulator registers per lane).  Same results; for tuning. */
+/* kNN kernel variant, for A/B runs (same results): 0 = default; 1 = fp32 kernel with 4 waves per workgroup (one per SIMD,
+ * 256 accumulator registers per lane); 2 = the first design of the fp16 candidate kernel (query fragments staged through
+ * LDS).  The environment variable HBIRD_KNN_VARIANT presets it for new handles. */
 int hb_index_set_variant(hb_index_t* ix, int variant);
 /* Work-list statistics of the last search: out[0]=workgroups, [1]=segments, [2]=slots, [3]=panel tiles,
  * [4]=max slots per query tile, [5]=query tiles, [6]=bank tiles, [7]=cluster shape (query ways * 16 + bank ways). */
 int hb_index_schedule_info(const hb_index_t* ix, int64_t out[8]);
 /* L2-sharing clusters of the kNN work list (speed only; results never depend on it): cluster_q x cluster_b workgroups
  * of one XCD walk (cluster_q query tiles) x (cluster_b interleaved bank tiles) in lockstep, so that one L2 fill serves
- * several workgroups.  0 x 0 or 1 x 1 = off (the default: neither kernel is bound by the fabric); q x b
- * with q * b <= 8 otherwise (2 x 2 recommended).  sync_lag: stages a member may run ahead of the slowest one before it
- * waits (-1 = 16, 0 = never wait). */
+ * several workgroups.  0 x 0 = automatic (the fp16 candidate kernel of big searches: 8 x 1, or 4 x 2 / 2 x 2 when that
+ * idles fewer pairs; the fp32 kernel: off -- it is bound by the matrix pipe), 1 x 1 = off, q x b with
+ * q * b <= 8 otherwise.  sync_lag: stages a member may run ahead of the slowest one before it waits (-1 = 16, 0 = never). */
 int hb_index_set_cluster(hb_index_t* ix, int cluster_q, int cluster_b, int sync_lag);
 /* Soft-sync statistics of the last clustered search (synchronises the stream): out[0] = progress checks, [1] = waits
  * (re-polls while a member was behind), [2] = members that gave up waiting (bounded spin); zeros without clusters. */

@@ -179,7 +179,7 @@ extern "C" int hb_index_cluster_stats(hb_index_t* ix, int64_t out[4]) {
 extern "C" int hb_index_set_cluster(hb_index_t* ix, int cluster_q, int cluster_b, int sync_lag) {
     if (!ix) return hb_fail("hb_index_set_cluster: NULL index handle");
     if (cluster_q < 0 || cluster_b < 0 || cluster_q * cluster_b > HB_CLUSTER_MAX)
-        return hb_fail("hb_index_set_cluster: cluster shape must be 0 x 0 (automatic) or q x b with q * b <= " + std::to_string(HB_CLUSTER_MAX));
+        return hb_fail("hb_index_set_cluster: cluster shape must be 0 x 0 (automatic), 1 x 1 (off) or q x b with q * b <= " + std::to_string(HB_CLUSTER_MAX));
     ix->force_cq = cluster_q; ix->force_cb = cluster_b; ix->sync_lag = sync_lag; ix->sched = hb_schedule();
     return 0;
 }

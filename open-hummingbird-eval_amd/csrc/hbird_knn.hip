@@ -47,6 +47,8 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
     cl_sync cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + KN_CLWORDS);
 
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
+    // "everything before my first segment is done" (a member without any work: everything)
+    if (w == 0) cl_publish(cs, seg_begin < seg_end ? a.segs[seg_begin].tile0 * g8 : 0x7FFFFFFF, lane);
     for (int si = seg_begin; si < seg_end; ++si) {
         const hb_seg seg = a.segs[si];
         const int klw = a.klw;   // list row stride (HB_KL on the LDS path)
@@ -407,10 +409,19 @@ int hb_default_panel(int nqt, int G, size_t tile_bytes, int cq, int cb) {
 // members hold each other within a few stages through the progress words (soft sync in the kernels); placement and
 // lockstep are speed only, any schedule gives the same result.
 void hb_default_cluster(int nqt, int nbt, int G, int* cq, int* cb) {
+    // The widest query way whose ragged last group idles at most 2.5 % of the pairs: 8 x 1 (eight workgroups stream the
+    // same bank tiles: measured best on the fp16 candidate kernel, 10 M x 768), else 4 x 2, else 2 x 2, else none.
     *cq = 1; *cb = 1;
-    if (G % 32 != 0 || (long long)nqt * nbt < 64LL * G) return;   // 2 x 2 clusters, 8 XCDs; enough work to share
-    if (nqt < 2 || (nqt % 2 != 0 && nqt < 32)) return;           // an odd query-tile count idles 1 / (nqt + 1) of the pairs
-    *cq = 2; *cb = 2;
+    if ((long long)nqt * nbt < 64LL * G) return;                 // enough work to share
+    static const int shapes[3][2] = {{8, 1}, {4, 2}, {2, 2}};
+    for (const auto& sh : shapes) {
+        const int q = sh[0], b = sh[1];
+        if (G % (8 * q * b) != 0 || nqt < q) continue;
+        const int padded = (nqt + q - 1) / q * q;
+        if ((padded - nqt) * 40 > padded) continue;
+        *cq = q; *cb = b;
+        return;
+    }
 }
 
 static void hb_finish_schedule(hb_schedule& out, std::vector<std::vector<hb_seg>>& per_wg, const std::vector<int>& logical_of_block,
@@ -571,7 +582,8 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // its LDS traffic, neither by the fabric (profiles/r02).  The 4-wave variant does not know strided segments.
     int cq = 1, cb = 1;
     if (ix->force_cq > 0 && ix->force_cb > 0) { cq = ix->force_cq; cb = ix->force_cb; }
-    if (ix->variant != 0 || (long long)nqt * nbt < G || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
+    else if (f16 && ix->variant == 0 && ix->force_cq == 0) hb_default_cluster(nqt, nbt, G, &cq, &cb);   // fp16 second design: -8 %
+    if (ix->variant == 1 || (long long)nqt * nbt < G || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
     const int panel = ix->force_panel > 0 ? ix->force_panel
                                           : hb_default_panel(nqt, std::min<long long>(G, (long long)nqt * nbt), tile_bytes, cq, cb);
     hb_schedule& sc = ix->sched;
@@ -647,7 +659,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         h.state_cnt = a.state_cnt; h.state_thr = a.state_thr; h.gthr = a.gthr;
         h.wg_member = a.wg_member; h.prog = a.prog; h.cl = a.cl; h.lag = a.lag; h.cl_stats = a.cl_stats;
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev0, s));
-        if (hb_knn_f16_launch(h, sc.G, ix->variant == 2 ? 2 : 1, s)) return -1;
+        if (hb_knn_f16_launch(h, sc.G, ix->variant == 2 ? 1 : 2, s)) return -1;   // variant 2 = the first design, for A/B
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
         if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
                          reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, kc, klw, 0, 0, nullptr,

@@ -186,18 +186,19 @@ __device__ __forceinline__ unsigned pool_kth(const unsigned (&key)[EMAX], bool (
     return prefix;
 }
 
-// Compact the full pool (cap entries, cap <= 64 EMAX) at (gs, gi) to its best k in entries [0, k); returns the k-th best score.
+// Compact the pool at (gs, gi) -- its first n entries are valid, k <= n <= 64 EMAX -- to its best k in entries [0, k);
+// returns the k-th best score.
 template <int EMAX = HB_POOL_MAX / 64>
-__device__ __forceinline__ float pool_compact(float* gs, unsigned* gi, int cap, int k, int lane) {
-    const int E = cap >> 6;
+__device__ __forceinline__ float pool_compact(float* gs, unsigned* gi, int n, int k, int lane) {
+    const int E = (n + 63) >> 6;
     float es[EMAX];
     unsigned ei[EMAX], key[EMAX];
     bool act[EMAX];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's appends have landed
 #pragma unroll
     for (int e = 0; e < EMAX; ++e) {
-        es[e] = 0.f; ei[e] = 0; key[e] = 0; act[e] = false;
-        if (e < E) {
+        es[e] = 0.f; ei[e] = 0; key[e] = 0; act[e] = false;   // key 0 is below every score's key: never counted, never kept
+        if (e < E && e * 64 + lane < n) {
             es[e] = __hip_atomic_load(gs + e * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ei[e] = __hip_atomic_load(gi + e * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             key[e] = pool_key(es[e]);
@@ -213,7 +214,7 @@ __device__ __forceinline__ float pool_compact(float* gs, unsigned* gi, int cap, 
     if (above + tied > k) {
         unsigned ik[EMAX];
 #pragma unroll
-        for (int e = 0; e < EMAX; ++e) { ik[e] = ~ei[e]; act[e] = (e < E) && key[e] == kt; }
+        for (int e = 0; e < EMAX; ++e) { ik[e] = ~ei[e]; act[e] = (e < E) && key[e] == kt; }   // kt > 0: no padding entry
         id_cut = ~pool_kth<EMAX>(ik, act, E, k - above);
     }
     float kth = 0.f;
@@ -280,12 +281,14 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, floa
                         lst_i[(size_t)myq * klw + c] = row_base + hh * 4 + j;
                         cnt[myq] = c + 1;
                     }
-                    unsigned long long full = __ballot(pass && c + 1 == klw);
+                    // a pool is compacted as soon as fewer than two free entries are left (pool_epilogue_scan appends up to two
+                    // entries per query at a time)
+                    unsigned long long full = __ballot(pass && c + 2 >= klw);
                     while (full) {
                         const int n = __builtin_ctzll(full) & 31;
                         full &= full - 1;
                         const size_t off = (size_t)(qb + n) * klw;
-                        const float kth = pool_compact<EMAX>(lst_s + off, lst_i + off, klw, k, lane);
+                        const float kth = pool_compact<EMAX>(lst_s + off, lst_i + off, klw - 1, k, lane);
                         if (lane == 0) cnt[qb + n] = k;
                         if ((lane & 31) == n) thr = fmaxf(thr, kth);
                     }
@@ -303,6 +306,96 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, floa
                     }
                 }
             }
+    }
+}
+
+// ---- pool epilogue, second design: scan into a per-lane register queue, then drain ---------------------------------------
+// With candidate pools a 32-query x 256-row tile has SEVERAL survivors (k' = 64 and thresholds as stale as the last
+// compaction: about four per tile at 10 M rows), so the "rare slow path" of tile_epilogue is the common path there: per
+// flagged quarter it dumps registers to LDS and walks them back one LDS round trip at a time (measured on the fp16
+// candidate kernel: 72 of 344 ms).  Here every accumulator register is tested once (v_cmp into VCC + a branch that is
+// almost never taken), a passing lane pushes (score, row code) onto a four-deep queue in its own registers, and the
+// queues are drained afterwards, one lane half at a time (the two halves hold different rows of the SAME query).  A
+// lane with more than four survivors in one tile (the first tiles of a slot) sends the wave through tile_epilogue
+// instead -- nothing has been appended by then, so nothing is appended twice.
+#define HB_SCAN_REG(T, R)                                                                                    \
+    {                                                                                                        \
+        if (__builtin_expect(__ballot(acc[T][R] > thr) != 0ull, 0)) {                                        \
+            float a_ = acc[T][R];                                                                            \
+            asm volatile("" : "+v"(a_));   /* compare again in here: the mask of the test need not be kept for this path */ \
+            if (a_ > thr) {                                                                                  \
+                q3v = q2v; q3c = q2c; q2v = q1v; q2c = q1c; q1v = q0v; q1c = q0c;                            \
+                q0v = a_; q0c = (T) * 32 + 8 * ((R) >> 2) + ((R) & 3);                                       \
+                ++np;                                                                                        \
+            }                                                                                                \
+            asm volatile("" : "+v"(np), "+v"(q0v), "+v"(q0c));   /* the push happens HERE */                  \
+        }                                                                                                    \
+    }
+// four registers (8 bank rows x 32 queries) share one test: a VALU compare feeding a scalar branch costs about 20 cycles,
+// two max instructions 8
+#define HB_SCAN_QUAD(T, Q)                                                                                   \
+    {                                                                                                        \
+        const float m_ = fmaxf(fmaxf(acc[T][4 * (Q)], acc[T][4 * (Q) + 1]), fmaxf(acc[T][4 * (Q) + 2], acc[T][4 * (Q) + 3])); \
+        if (__builtin_expect(__ballot(m_ > thr) != 0ull, 0)) {                                               \
+            HB_SCAN_REG(T, 4 * (Q)) HB_SCAN_REG(T, 4 * (Q) + 1) HB_SCAN_REG(T, 4 * (Q) + 2) HB_SCAN_REG(T, 4 * (Q) + 3) \
+        }                                                                                                    \
+    }
+#ifndef HB_SCAN_FLAT
+#define HB_SCAN_TILE(T) HB_SCAN_QUAD(T, 0) HB_SCAN_QUAD(T, 1) HB_SCAN_QUAD(T, 2) HB_SCAN_QUAD(T, 3)
+#else   /* experiments: every register tested on its own */
+#define HB_SCAN_TILE(T)                                                                                      \
+    HB_SCAN_REG(T, 0) HB_SCAN_REG(T, 1) HB_SCAN_REG(T, 2) HB_SCAN_REG(T, 3) HB_SCAN_REG(T, 4) HB_SCAN_REG(T, 5) \
+    HB_SCAN_REG(T, 6) HB_SCAN_REG(T, 7) HB_SCAN_REG(T, 8) HB_SCAN_REG(T, 9) HB_SCAN_REG(T, 10) HB_SCAN_REG(T, 11) \
+    HB_SCAN_REG(T, 12) HB_SCAN_REG(T, 13) HB_SCAN_REG(T, 14) HB_SCAN_REG(T, 15)
+#endif
+
+template <int EMAX>
+__device__ __forceinline__ void pool_epilogue_scan(f32x16 (&acc)[8], float& thr, float* pool_s, unsigned* pool_i, float* sc, int qb,
+                                                   int lane, int k, unsigned bt, int klw, int* cnt) {
+    float q0v = 0.f, q1v = 0.f, q2v = 0.f, q3v = 0.f;
+    int q0c = 0, q1c = 0, q2c = 0, q3c = 0, np = 0;
+    HB_SCAN_TILE(0) HB_SCAN_TILE(1) HB_SCAN_TILE(2) HB_SCAN_TILE(3) HB_SCAN_TILE(4) HB_SCAN_TILE(5) HB_SCAN_TILE(6) HB_SCAN_TILE(7)
+    if (__ballot(np != 0) == 0ull) return;
+#if defined(F16_ABL) && (F16_ABL & 512)
+    asm volatile("" :: "v"(q0v), "v"(q1v), "v"(q2v), "v"(q3v), "v"(q0c), "v"(q1c), "v"(q2c), "v"(q3c));   // timing only: no drain
+    return;
+#endif
+    if (__ballot(np > 4) != 0ull) {   // a queue overflowed: the general path rescans the tile (nothing was appended yet)
+        // (the threshold goes through an opaque copy: otherwise the compiler keeps the scan's 128 compare masks alive, in
+        // spilled SGPRs, to reuse them in the general path's own compares)
+        float t2 = thr;
+        asm volatile("" : "+v"(t2));
+        tile_epilogue<true, true, EMAX>(acc, t2, pool_s, pool_i, sc, qb, lane, k, bt, klw, cnt);
+        thr = t2;
+        return;
+    }
+    const int myq = qb + (lane & 31);
+    const unsigned row0 = bt * HB_BT + 4u * (unsigned)(lane >> 5);
+    // Drain: queue entry i of every lane at once.  The two lane halves hold different rows of the SAME query, so the
+    // slot in the query's pool comes from an LDS atomic; a pool always has two free entries when a pass starts
+    // (cnt <= klw - 2) and is compacted as soon as it has fewer.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool has = np > i;
+        if (__ballot(has) == 0ull) break;
+        const float v = i == 0 ? q0v : i == 1 ? q1v : i == 2 ? q2v : q3v;
+        const int code = i == 0 ? q0c : i == 1 ? q1c : i == 2 ? q2c : q3c;
+        int c = 0;
+        if (has) {
+            c = __hip_atomic_fetch_add(cnt + myq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            pool_s[(size_t)myq * klw + c] = v;
+            pool_i[(size_t)myq * klw + c] = row0 + (unsigned)code;
+        }
+        unsigned long long full = __ballot(has && c + 2 >= klw);   // c + 1 or c + 2 entries now: at most one free
+        while (full) {
+            const int n = __builtin_ctzll(full) & 31;
+            full &= ~((1ull << n) | (1ull << (n + 32)));
+            const size_t off = (size_t)(qb + n) * klw;
+            const int valid = __builtin_amdgcn_readfirstlane(cnt[qb + n]);
+            const float kth = pool_compact<EMAX>(pool_s + off, pool_i + off, valid, k, lane);
+            if (lane == 0) cnt[qb + n] = k;
+            if ((lane & 31) == n) thr = fmaxf(thr, kth);
+        }
     }
 }
 

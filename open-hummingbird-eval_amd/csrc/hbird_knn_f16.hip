@@ -85,6 +85,8 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
     cl_sync cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + F16_CLWORDS);
 
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
+    // "everything before my first segment is done" (a member without any work: everything)
+    if (w == 0) cl_publish(cs, seg_begin < seg_end ? a.segs[seg_begin].tile0 * NS : 0x7FFFFFFF, lane);
     for (int si = seg_begin; si < seg_end; ++si) {
         const hb_seg seg = a.segs[si];
         const int bstride = seg.stride;
@@ -227,11 +229,37 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
 // re-loaded right after MFMA t has issued, 8 MFMAs before its next use.  Per group: 64 KiB of reads + 8 KiB of copies.
 // Stages are unrolled by four so that the register buffers of the query fragments have static indices.
 #define F2_RING 8
+#if defined(F16_ABL) && (F16_ABL & 2)
+#define F2_ABL_BT(x) ((x) & 3)        // timing only: 4 bank tiles, L2-resident
+#else
+#define F2_ABL_BT(x) (x)
+#endif
+#if defined(F16_ABL) && (F16_ABL & 16)
+#define F2_RD(dst, src) asm volatile("" : "+v"(dst));     // timing only: no fragment reads
+#else
+#define F2_RD(dst, src) dst = src;
+#endif
+#if defined(F16_ABL) && (F16_ABL & 32)
+#define F2_DMA(src, dst)                                   // timing only: no bank copies
+#else
+#define F2_DMA(src, dst) __builtin_amdgcn_global_load_lds((gbl_cvoid*)(src), (lds_void*)(dst), 16, 0, 0);
+#endif
+#if defined(F16_ABL) && (F16_ABL & 128)
+#define F2_BARRIER()                                       // timing only: no barrier
+#else
+#define F2_BARRIER() __builtin_amdgcn_s_barrier();
+#endif
+#if defined(F16_ABL) && (F16_ABL & 8)
+#define F2_ABL_Q(x) (reinterpret_cast<const char*>(a.q16) + (size_t)w * g16 * 1024)   // timing only: one query tile for all
+#else
+#define F2_ABL_Q(x) (x)
+#endif
 #define F2_SLOT 16384                                  // bank fragments of one k32 stage: [row tile 0..7][group 0..1][1 KiB]
 #define F2_BINIT (F2_RING * F2_SLOT)
 #define F2_SCRATCH (F2_BINIT + 2048)
 #define F2_PCNT (F2_SCRATCH + 8192)
-#define F2_LDS_TOTAL (F2_PCNT + 1024)
+#define F2_CLWORDS (F2_PCNT + 1024)                    // landing zone of the cluster progress poll
+#define F2_LDS_TOTAL (F2_CLWORDS + 64)
 static_assert(F2_LDS_TOTAL <= 160 * 1024, "LDS budget");
 
 template <int EMAX>   // pool capacity / 64 that the instantiation can compact (registers of the rare compaction path)
@@ -247,8 +275,11 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
     const int NS = g16 / 2;   // k32 stages per bank tile, a multiple of 4 (dp16 is a multiple of 128)
     const int myq = w * 32 + (lane & 31);
     const unsigned lane_off = (unsigned)lane * 16u;
+    cl_sync cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + F2_CLWORDS);
 
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
+    // "everything before my first segment is done" (a member without any work: everything)
+    if (w == 0) cl_publish(cs, seg_begin < seg_end ? a.segs[seg_begin].tile0 * NS : 0x7FFFFFFF, lane);
     for (int si = seg_begin; si < seg_end; ++si) {
         const hb_seg seg = a.segs[si];
         const int bstride = seg.stride;
@@ -257,37 +288,62 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
         const knn_args_pool_view pv{a.state_cnt, a.state_thr};
         float thr = pool_begin(pv, seg.slot, seg.first, pcnt, myq, lane);
         thr = fmaxf(thr, floor_load(a.gthr, seg.q_tile * HB_QT + myq));
-        const int total = seg.n_tiles * NS;
+        const int total = seg.n_tiles * NS, clock0 = seg.tile0 * NS;
         f32x16 acc[8];
         f16x8 fa[8];        // bank fragments of the current group (one set)
         f16x8 bq[4][2];     // query fragments of four stages, two k16 groups each
 
-        // A batch = what one wave requests for one stage: its two 1 KiB bank pieces (row tile w, both groups; LDS-DMA) and
-        // its own two query fragments (registers).  Wave 0 adds the row-init values with the first stage of a tile.
+        // A batch = what one wave requests for one stage: its own two query fragments (registers) and -- waves 0-3 only --
+        // four 1 KiB bank pieces (row tiles w and w + 4, both groups; LDS-DMA).  A wave stalls on the issue of a copy behind
+        // the CU's other copies; waves w and w + 4 share a SIMD, and with one issuer per SIMD the partner keeps the matrix
+        // pipe fed meanwhile (all eight waves issuing: +46 ms of 344 at 10 M x 768).  Wave 0 adds the row-init values with
+        // the first stage of a tile.
         const char* bank_w = reinterpret_cast<const char*>(a.bank16) + (size_t)w * g16 * 1024;
         const char* query_w = reinterpret_cast<const char*>(a.q16) + (size_t)(seg.q_tile * 8 + w) * g16 * 1024;
         int fbt = seg.b_tile0, fks = 0, slot_f = 0, left = total, fpar = 0;
+// The two wave classes wait for different counts.  ONE asm statement with the branch inside: with two statements in an
+// if / else hipcc copied the "+v" registers ahead of the wait on one side (reading fragments that had not landed yet).
+#define F2_WAIT(N_ISSUER, N_OTHER, B0, B1)                                                                                   \
+        if (F2_SYM) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(B0), "+v"(B1) : "i"((N_ISSUER + N_OTHER) / 2) : "memory");      \
+        else asm volatile("s_cmp_lt_u32 %2, 4\n\ts_cbranch_scc1 .Lf2w_%=\n\ts_waitcnt vmcnt(" #N_OTHER ")\n\ts_branch .Lf2d_%=\n" \
+                     ".Lf2w_%=:\n\ts_waitcnt vmcnt(" #N_ISSUER ")\n.Lf2d_%=:"                                               \
+                     : "+v"(B0), "+v"(B1) : "s"(w) : "memory", "scc");
+#ifndef F2_SYM
+#define F2_SYM 1     /* 1 = all eight waves issue two copies each; 0 = waves 0-3 four each (measured: 352 vs 342 ms) */
+#endif
+#define F2_COPY(I)   /* piece I of this wave: row tile w + 4 (I >> 1), group I & 1 */                                        \
+        if (F2_SYM) {                                                                                                        \
+            if ((I) < 2) {                                                                                                   \
+                const char* bsrc = bank_w + ((size_t)F2_ABL_BT(fbt) * 8 * g16 + (size_t)fks * 2 + (I)) * 1024 + lane_off;   \
+                F2_DMA(bsrc, smem + slot_f * F2_SLOT + (w * 2 + (I)) * 1024)                                                 \
+            }                                                                                                                \
+        } else if (w < 4) {                                                                                                  \
+            const char* bsrc = bank_w + ((size_t)F2_ABL_BT(fbt) * 8 * g16 + (size_t)((I) >> 1) * 4 * g16 + (size_t)fks * 2 + ((I) & 1)) * 1024 + lane_off; \
+            char* bdst = smem + slot_f * F2_SLOT + ((w + 4 * ((I) >> 1)) * 2 + ((I) & 1)) * 1024;                            \
+            F2_DMA(bsrc, bdst)                                                                                               \
+        }
 #define F2_BATCH(B0, B1)                                                                                                     \
         {                                                                                                                    \
-            const char* bsrc = bank_w + ((size_t)fbt * 8 * g16 + (size_t)fks * 2) * 1024 + lane_off;                        \
-            char* bdst = smem + slot_f * F2_SLOT + w * 2048;                                                                 \
-            __builtin_amdgcn_global_load_lds((gbl_cvoid*)bsrc, (lds_void*)bdst, 16, 0, 0);                                   \
-            __builtin_amdgcn_global_load_lds((gbl_cvoid*)(bsrc + 1024), (lds_void*)(bdst + 1024), 16, 0, 0);                 \
-            const char* qsrc = query_w + (size_t)fks * 2048;                                                                 \
+            const char* qsrc = F2_ABL_Q(query_w) + (size_t)fks * 2048;                                                       \
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(B0) : "v"(lane_off), "s"(qsrc) : "memory");                 \
             asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(B1) : "v"(lane_off), "s"(qsrc) : "memory");     \
             if (fks == 0 && w == 0) glds16(a.binit + (size_t)fbt * HB_BT + lane * 4, smem + F2_BINIT + fpar * 1024);        \
             if (--left > 0) { if (++fks == NS) { fks = 0; fbt += bstride; fpar ^= 1; } }                                     \
             slot_f = (slot_f + 1) & (F2_RING - 1);                                                                           \
         }
-        // vmcnt by hand: a batch is 4 requests in a fixed order (wave 0: now and then 5, which only makes a wait stricter).
-        // Batch j (stage j's data) is issued during stage j - 4.  Stage s + 1 must have landed at the barrier in the middle
-        // of stage s: batches s - 2 and s - 1 are younger -> "all but the newest 8".  Past the last stage the fetch position
-        // stays put (same requests again, results unused), so the count never changes.
-        F2_BATCH(bq[0][0], bq[0][1]) F2_BATCH(bq[1][0], bq[1][1]) F2_BATCH(bq[2][0], bq[2][1]) F2_BATCH(bq[3][0], bq[3][1])
-        asm volatile("s_waitcnt vmcnt(12)" : "+v"(bq[0][0]), "+v"(bq[0][1]) :: "memory");   // stage 0 has landed
+        // vmcnt by hand: a batch is 6 requests (waves 0-3) or 2 (waves 4-7) in a fixed order (wave 0: now and then 7, which
+        // only makes a wait stricter).  Batch j (stage j's data) is issued during stage j - 4.  Stage s + 1 must have landed
+        // at the barrier in the middle of stage s: batches s - 2 and s - 1 are younger -> "all but the newest 12" (4).  Past
+        // the last stage the fetch position stays put (same requests again, results unused), so the count never changes.
+#define F2_ALL(B0, B1) F2_COPY(0) F2_COPY(1) F2_COPY(2) F2_COPY(3) F2_BATCH(B0, B1)
+        F2_ALL(bq[0][0], bq[0][1]) F2_ALL(bq[1][0], bq[1][1]) F2_ALL(bq[2][0], bq[2][1]) F2_ALL(bq[3][0], bq[3][1])
+        // stage 0 has landed: three younger batches of 6 (waves 0-3) or 2 (waves 4-7) requests
+        F2_WAIT(18, 6, bq[0][0], bq[0][1])
         __syncthreads();
         int slot_c = 0, ks = 0, bt = seg.b_tile0, cpar = 0;
+#if defined(F16_ABL) && (F16_ABL & 256)
+#define F2_INIT_TILE() { _Pragma("unroll") for (int t = 0; t < 8; ++t) asm volatile("" : "+v"(acc[t])); }   // timing only: no init
+#else
 #define F2_INIT_TILE()                                                                                                       \
         {                                                                                                                    \
             const f32x4* bi = reinterpret_cast<const f32x4*>(smem + F2_BINIT + cpar * 1024);                                 \
@@ -297,6 +353,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
                     acc[t][4 * g + 0] = v[0]; acc[t][4 * g + 1] = v[1]; acc[t][4 * g + 2] = v[2]; acc[t][4 * g + 3] = v[3]; \
                 }                                                                                                            \
         }
+#endif
         {
             const f16x8* A = reinterpret_cast<const f16x8*>(smem) + lane;
 #pragma unroll
@@ -310,27 +367,28 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
             const int slot_n = (slot_c + 1) & (F2_RING - 1);                                                                 \
             const f16x8* An = reinterpret_cast<const f16x8*>(smem + slot_n * F2_SLOT) + lane;                                \
             /* group 0; filler after MFMA t: fragment t of group 1 */                                                        \
-            KN_FENCE F2_MM(0, bq[U][0]) KN_FENCE fa[0] = Ac[(0 * 2 + 1) * 64];                                               \
-            KN_FENCE F2_MM(1, bq[U][0]) KN_FENCE fa[1] = Ac[(1 * 2 + 1) * 64];                                               \
-            KN_FENCE F2_MM(2, bq[U][0]) KN_FENCE fa[2] = Ac[(2 * 2 + 1) * 64];                                               \
-            KN_FENCE F2_MM(3, bq[U][0]) KN_FENCE fa[3] = Ac[(3 * 2 + 1) * 64];                                               \
-            KN_FENCE F2_MM(4, bq[U][0]) KN_FENCE fa[4] = Ac[(4 * 2 + 1) * 64];                                               \
-            KN_FENCE F2_MM(5, bq[U][0]) KN_FENCE fa[5] = Ac[(5 * 2 + 1) * 64];                                               \
-            KN_FENCE F2_MM(6, bq[U][0]) KN_FENCE fa[6] = Ac[(6 * 2 + 1) * 64];                                               \
-            KN_FENCE F2_MM(7, bq[U][0]) KN_FENCE fa[7] = Ac[(7 * 2 + 1) * 64];                                               \
+            KN_FENCE F2_MM(0, bq[U][0]) KN_FENCE F2_RD(fa[0], Ac[(0 * 2 + 1) * 64])                                               \
+            KN_FENCE F2_MM(1, bq[U][0]) KN_FENCE F2_RD(fa[1], Ac[(1 * 2 + 1) * 64])                                               \
+            KN_FENCE F2_MM(2, bq[U][0]) KN_FENCE F2_RD(fa[2], Ac[(2 * 2 + 1) * 64])                                               \
+            KN_FENCE F2_MM(3, bq[U][0]) KN_FENCE F2_RD(fa[3], Ac[(3 * 2 + 1) * 64])                                               \
+            KN_FENCE F2_MM(4, bq[U][0]) KN_FENCE F2_RD(fa[4], Ac[(4 * 2 + 1) * 64])                                               \
+            KN_FENCE F2_MM(5, bq[U][0]) KN_FENCE F2_RD(fa[5], Ac[(5 * 2 + 1) * 64])                                               \
+            KN_FENCE F2_MM(6, bq[U][0]) KN_FENCE F2_RD(fa[6], Ac[(6 * 2 + 1) * 64])                                               \
+            KN_FENCE F2_MM(7, bq[U][0]) KN_FENCE F2_RD(fa[7], Ac[(7 * 2 + 1) * 64])                                               \
             KN_FENCE                                                                                                         \
             /* the next stage has landed: my requests (and my query fragments of it), then everyone's */                    \
-            asm volatile("s_waitcnt vmcnt(8)" : "+v"(bq[(U + 1) & 3][0]), "+v"(bq[(U + 1) & 3][1]) :: "memory");             \
-            __builtin_amdgcn_s_barrier();   /* raw: __syncthreads() would drain the LDS-DMA copies (vmcnt(0)) */             \
+            F2_WAIT(12, 4, bq[(U + 1) & 3][0], bq[(U + 1) & 3][1])                                                          \
+            F2_BARRIER()   /* raw s_barrier: __syncthreads() would drain the LDS-DMA copies (vmcnt(0)) */                    \
             /* group 1; filler after MFMA t: fragment t of the next stage's group 0; then this stage's batch */              \
-            KN_FENCE F2_MM(0, bq[U][1]) KN_FENCE fa[0] = An[(0 * 2) * 64];                                                   \
-            KN_FENCE F2_MM(1, bq[U][1]) KN_FENCE fa[1] = An[(1 * 2) * 64];                                                   \
-            KN_FENCE F2_MM(2, bq[U][1]) KN_FENCE fa[2] = An[(2 * 2) * 64];                                                   \
-            KN_FENCE F2_MM(3, bq[U][1]) KN_FENCE fa[3] = An[(3 * 2) * 64];                                                   \
-            KN_FENCE F2_MM(4, bq[U][1]) KN_FENCE fa[4] = An[(4 * 2) * 64];                                                   \
-            KN_FENCE F2_MM(5, bq[U][1]) KN_FENCE fa[5] = An[(5 * 2) * 64];                                                   \
-            KN_FENCE F2_MM(6, bq[U][1]) KN_FENCE fa[6] = An[(6 * 2) * 64];                                                   \
-            KN_FENCE F2_MM(7, bq[U][1]) KN_FENCE fa[7] = An[(7 * 2) * 64];                                                   \
+            if (w == 0) cl_tick(cs, clock0 + st + (U), lane);   /* cluster soft sync, ahead of the stage's requests */       \
+            KN_FENCE F2_MM(0, bq[U][1]) KN_FENCE F2_RD(fa[0], An[(0 * 2) * 64]) F2_COPY(0)                                        \
+            KN_FENCE F2_MM(1, bq[U][1]) KN_FENCE F2_RD(fa[1], An[(1 * 2) * 64])                                                   \
+            KN_FENCE F2_MM(2, bq[U][1]) KN_FENCE F2_RD(fa[2], An[(2 * 2) * 64]) F2_COPY(1)                                        \
+            KN_FENCE F2_MM(3, bq[U][1]) KN_FENCE F2_RD(fa[3], An[(3 * 2) * 64])                                                   \
+            KN_FENCE F2_MM(4, bq[U][1]) KN_FENCE F2_RD(fa[4], An[(4 * 2) * 64]) F2_COPY(2)                                        \
+            KN_FENCE F2_MM(5, bq[U][1]) KN_FENCE F2_RD(fa[5], An[(5 * 2) * 64])                                                   \
+            KN_FENCE F2_MM(6, bq[U][1]) KN_FENCE F2_RD(fa[6], An[(6 * 2) * 64]) F2_COPY(3)                                        \
+            KN_FENCE F2_MM(7, bq[U][1]) KN_FENCE F2_RD(fa[7], An[(7 * 2) * 64])                                                   \
             KN_FENCE                                                                                                         \
             F2_BATCH(bq[U][0], bq[U][1])                                                                                     \
             KN_FENCE                                                                                                         \
@@ -344,7 +402,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
 #pragma unroll
                 for (int t = 0; t < 8; ++t) asm volatile("" :: "v"(acc[t]));   // timing only: no epilogue
 #else
-                tile_epilogue<true, true, EMAX>(acc, thr, wl_s, wl_i, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
+                pool_epilogue_scan<EMAX>(acc, thr, wl_s, wl_i, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
 #endif
                 ks = 0; bt += bstride; cpar ^= 1;
                 F2_INIT_TILE()
@@ -362,11 +420,16 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
 #undef F2_MM
 #undef F2_INIT_TILE
 #undef F2_BATCH
+#undef F2_COPY
+#undef F2_ALL
+#undef F2_WAIT
+        if (w == 0) cl_publish(cs, seg.next_tile0 == 0x7FFFFFFF ? 0x7FFFFFFF : seg.next_tile0 * NS, lane);   // covers idle units
         pool_end(pv, seg.slot, pcnt, thr, myq, lane);
         if (lane < 32) floor_publish(a.gthr, seg.q_tile * HB_QT + myq, thr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    cl_finish(cs, a.cl_stats, w == 0, lane);
 }
 
 // Exact re-rank: one wave per query; lane j scores candidates j, j+64, ... with the fp32 chain arithmetic of the fp32
@@ -459,7 +522,7 @@ int hb_launch_rerank(const float* tiles, const float* binit, int g8, int d, cons
 }
 
 int hb_knn_f16_launch(const knn16_args& args, int grid, int design, hipStream_t s) {
-    if (design == 2 && args.cl == 1) {   // second design (no cluster support)
+    if (design != 1) {   // second design (default)
         void (*fn)(knn16_args) = args.klw <= 256 ? knn_f16v2_kernel<4> : knn_f16v2_kernel<8>;
         if (hb_ensure_dyn_lds((const void*)fn, F2_LDS_TOTAL)) return -1;
         fn<<<dim3((unsigned)grid), dim3(HB_THREADS), F2_LDS_TOTAL, s>>>(args);

@@ -81,7 +81,7 @@ def test_clustered_work_list_invariants(nqt, nbt, G, panel, cq, cb):
     segs, st = plan(nqt, nbt, G, panel, cluster=(cq, cb))
     a, b = st["cluster"]
     if cq < 0:
-        assert (a, b) == ((2, 2) if nqt * nbt >= 64 * G and G % 32 == 0 else (1, 1))
+        assert (a, b) == (8, 1)            # 86 query tiles: 2 of 88 idle in the last group of eight (2.3 %)
     elif G % (8 * cq * cb) != 0 or nqt * nbt < G:
         assert (a, b) == (1, 1)                                  # falls back to the plain list
     else:
@@ -137,6 +137,13 @@ def test_clustered_work_list_invariants(nqt, nbt, G, panel, cq, cb):
         assert busy.max() - np.median(busy) <= npanels + 1
         if nqt % a == 0:
             assert busy.max() - busy.min() <= 2 * npanels + 1
+
+
+def test_automatic_cluster_shape():
+    """The widest query way that idles at most 2.5 % of the pairs; none for small searches or unsuitable grids."""
+    for nqt, nbt, G, want in ((86, 39063, 256, (8, 1)), (49, 8102, 256, (2, 2)), (48, 8102, 256, (8, 1)), (52, 8102, 256, (4, 2)),
+                              (51, 8102, 256, (4, 2)), (1, 100000, 256, (1, 1)), (86, 100, 256, (1, 1)), (86, 39063, 104, (1, 1)), (86, 39063, 32, (2, 2))):
+        assert plan(nqt, nbt, G, 0, cluster=(-1, -1))[1]["cluster"] == want, (nqt, nbt, G)
 
 
 def test_headline_clustered_plan_numbers():
