@@ -137,6 +137,14 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
             const f32x4* Ac = reinterpret_cast<const f32x4*>(smem + slot_c * KN_SLOT_BYTES) + lane;
             const f32x4* An = reinterpret_cast<const f32x4*>(smem + slot_n * KN_SLOT_BYTES) + lane;
             if (ks == 0) {
+                if constexpr ((ABL & 512) && !WIDE) {
+                    // small searches: the query tile's slots exchange their threshold floors every TILE, not only at the
+                    // end of a segment -- a slot sees few rows (37 tiles at 50,176 x 384) and would insert about four times
+                    // as much on its own bound.  The 32 floors of this wave's queries come in by LDS-DMA while the tile
+                    // is computed (older than the stage's copies: the hand-counted vmcnt still holds) and are read at its end.
+                    if (lane < 32)
+                        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(a.gthr + seg.q_tile * HB_QT + w * 32 + lane), (lds_void*)sc, 4, 0, 16);
+                }
                 const f32x4* bi = reinterpret_cast<const f32x4*>(smem + KN_BINIT + cpar * 1024);
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
@@ -182,8 +190,17 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
                     else {
                         if constexpr (ABL & 512) {   // small searches: radix-select cold start (separate instantiation, see launcher)
                             if (seg.first && bt == seg.b_tile0) thr = fmaxf(thr, cold_start_threshold(acc, k));
+                            // the floors requested at the tile's start (waves 4-7 have nothing else in flight; waves 0-3 have
+                            // passed dozens of counted waits since)
+                            asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 .Lfl_%=\n\ts_waitcnt vmcnt(0)\n.Lfl_%=:" :: "s"(w) : "memory", "scc");
+                            thr = fmaxf(thr, floor_from_key(reinterpret_cast<const unsigned*>(sc)[lane & 31]));
                         }
-                        tile_epilogue<!(ABL & 16), false>(acc, thr, lst_s, lst_i, sc, w * 32, lane, k, (unsigned)bt);
+                        // small searches (few rows per slot -> many insertions per tile): scan + register queue; the big
+                        // ones keep the plain epilogue (insertions are rare there, and the scan's registers would spill)
+                        if constexpr (ABL & 512) {
+                            list_epilogue_scan(acc, thr, lst_s, lst_i, w * 32, lane, k, (unsigned)bt);
+                            if (lane < 32) floor_publish(a.gthr, seg.q_tile * HB_QT + myq, thr);
+                        } else tile_epilogue<!(ABL & 16), false>(acc, thr, lst_s, lst_i, sc, w * 32, lane, k, (unsigned)bt);
                     }
                 }
                 else {
@@ -727,11 +744,15 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     };
     static const int variant_bits[] = {0, -1, 1, 2, 4, 8, 15, 16, 13, 14, 11, 7, 3, 5, 6, 9, 10, 12, 32, 64, 96, 128, 256, 384};
     knn_fn fn = variants[wide ? 1 : 0];
-    // Few stages per workgroup: the cold start of every slot (its first tile inserts all 256 rows of every query) is
-    // a visible share of the search -> the instantiation with the radix-select cold start (+14 % at 50 k x 384).  The
-    // big searches keep the plain instantiation: the extra code costs them 0.3 % (same-box A/B at 10 M x 768).
+    // Few stages per workgroup: a slot sees few rows, so its cold start (the first tile inserts all 256 rows of every
+    // query) and its insertions (k ln(rows / k) per query) are a visible share of the search -> the instantiation with the
+    // radix-select cold start, the scan epilogue (register queue + immediate inserts) and the per-tile exchange of
+    // threshold floors: 50,176 x 384: 6.3 -> 4.95 ms (0.49 -> 0.62 of the fp32 MFMA peak); 1.25 M x 768 (one of eight
+    // shards of the headline bank): 302.3 -> 300.5 ms.  The big searches keep the plain instantiation: at 10 M x 768 the
+    // extra code costs 0.3 % (same-box A/B), the crossover is near 3 M rows.
     static const knn_fn cold_fn = knn_fused_kernel<512, false>;
-    if (!wide && (long long)nqt * nbt / std::max(1, sc.G) * ix->g8 < 150000) fn = cold_fn;
+    static const long long cold_limit = getenv("HBIRD_COLD_LIMIT") ? atoll(getenv("HBIRD_COLD_LIMIT")) : 400000;   // stages per workgroup
+    if (!wide && (long long)nqt * nbt / std::max(1, sc.G) * ix->g8 < cold_limit) fn = cold_fn;
     if (!wide && ix->ablate)
         for (size_t i = 0; i < sizeof(variants) / sizeof(variants[0]); ++i) if (variant_bits[i] == ix->ablate) fn = variants[i];
     int threads = HB_THREADS;

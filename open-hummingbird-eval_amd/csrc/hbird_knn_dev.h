@@ -399,6 +399,49 @@ __device__ __forceinline__ void pool_epilogue_scan(f32x16 (&acc)[8], float& thr,
     }
 }
 
+// The same scan for the sorted LDS lists (k <= HB_KL): a flagged quad's survivors (at most four per lane) go into the
+// register queue and are inserted right away, one by one, with the wave-cooperative list_insert -- so the queue cannot
+// overflow and later quads already see the raised thresholds.  Insertion order inside a tile is free: every queued score
+// passed a threshold that is strict against rows of earlier tiles (lower ids), and list_insert compares the full key.
+// Measured at 50,176 x 384 (few rows per slot: 170 insertions per query and slot): the dump-and-walk path of
+// tile_epilogue spent 45 % of the kernel there.
+#define HB_LIST_QUAD(T, Q)                                                                                   \
+    {                                                                                                        \
+        const float m_ = fmaxf(fmaxf(acc[T][4 * (Q)], acc[T][4 * (Q) + 1]), fmaxf(acc[T][4 * (Q) + 2], acc[T][4 * (Q) + 3])); \
+        if (__builtin_expect(__ballot(m_ > thr) != 0ull, 0)) {                                               \
+            float q0v = 0.f, q1v = 0.f, q2v = 0.f, q3v = 0.f;                                                \
+            int q0c = 0, q1c = 0, q2c = 0, q3c = 0, np = 0;                                                  \
+            HB_SCAN_REG(T, 4 * (Q)) HB_SCAN_REG(T, 4 * (Q) + 1) HB_SCAN_REG(T, 4 * (Q) + 2) HB_SCAN_REG(T, 4 * (Q) + 3) \
+            list_drain(lst_s, lst_i, qb, lane, k, row0, thr, np, q0v, q1v, q2v, q3v, q0c, q1c, q2c, q3c);    \
+        }                                                                                                    \
+    }
+#define HB_LIST_TILE(T) HB_LIST_QUAD(T, 0) HB_LIST_QUAD(T, 1) HB_LIST_QUAD(T, 2) HB_LIST_QUAD(T, 3)
+__device__ __forceinline__ void list_drain(float* lst_s, unsigned* lst_i, int qb, int lane, int k, unsigned row0, float& thr, int np,
+                                           float q0v, float q1v, float q2v, float q3v, int q0c, int q1c, int q2c, int q3c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned long long m = __ballot(np > i);
+        if (m == 0ull) break;
+        const float v = i == 0 ? q0v : i == 1 ? q1v : i == 2 ? q2v : q3v;
+        const int code = i == 0 ? q0c : i == 1 ? q1c : i == 2 ? q2c : q3c;
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+            const unsigned row = row0 + 4u * (unsigned)(l >> 5) + (unsigned)__builtin_amdgcn_readlane(code, l);
+            const int n = l & 31;
+            list_insert(lst_s, lst_i, qb + n, k, s, row, lane);
+            const float kth = lst_s[(qb + n) * HB_KL + (k - 1)];
+            if ((lane & 31) == n) thr = fmaxf(thr, kth);
+        }
+    }
+}
+__device__ __forceinline__ void list_epilogue_scan(f32x16 (&acc)[8], float& thr, float* lst_s, unsigned* lst_i, int qb, int lane,
+                                                   int k, unsigned bt) {
+    const unsigned row0 = bt * HB_BT;
+    HB_LIST_TILE(0) HB_LIST_TILE(1) HB_LIST_TILE(2) HB_LIST_TILE(3) HB_LIST_TILE(4) HB_LIST_TILE(5) HB_LIST_TILE(6) HB_LIST_TILE(7)
+}
+
 // ---- shared threshold floor ----------------------------------------------------------------------------------
 // A query tile's bank rows are spread over several slots (workgroups / panels), each with its own running best-k.
 // The k-th best score of ANY slot is a lower bound of the final k-th best, so slots publish theirs (atomic max of the
@@ -407,12 +450,14 @@ __device__ __forceinline__ void pool_epilogue_scan(f32x16 (&acc)[8], float& thr,
 // k ln(rows/k) insertions of a slot that only ever sees a slice of the bank).  A foreign bound g admits ties
 // (score == g may still win on the id), hence the floor is the float just below g; own k-th scores keep the strict
 // rule.  Which scores get filtered early depends on timing, the merged result does not.
-__device__ __forceinline__ float floor_load(const unsigned* gthr, int q) {
-    unsigned g = __hip_atomic_load(gthr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ float floor_from_key(unsigned g) {
     if (g <= 0x007FFFFFu) return -INFINITY;                 // key(-inf): nothing published yet
     g -= 1u;
     if (g == 0x7FFFFFFFu) g = 0x7FFFFFFEu;                  // skip -0.0 (equal to +0.0): largest float below zero
     return __builtin_bit_cast(float, (g & 0x80000000u) ? (g ^ 0x80000000u) : ~g);
+}
+__device__ __forceinline__ float floor_load(const unsigned* gthr, int q) {
+    return floor_from_key(__hip_atomic_load(gthr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 __device__ __forceinline__ void floor_publish(unsigned* gthr, int q, float thr) {
     if (thr > -INFINITY) atomicMax(gthr + q, pool_key(thr));

@@ -293,52 +293,54 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
         f16x8 fa[8];        // bank fragments of the current group (one set)
         f16x8 bq[4][2];     // query fragments of four stages, two k16 groups each
 
-        // A batch = what one wave requests for one stage: its own two query fragments (registers) and -- waves 0-3 only --
-        // four 1 KiB bank pieces (row tiles w and w + 4, both groups; LDS-DMA).  A wave stalls on the issue of a copy behind
-        // the CU's other copies; waves w and w + 4 share a SIMD, and with one issuer per SIMD the partner keeps the matrix
-        // pipe fed meanwhile (all eight waves issuing: +46 ms of 344 at 10 M x 768).  Wave 0 adds the row-init values with
-        // the first stage of a tile.
+        // What one wave requests for one stage, in this order: query fragment B0 (group 0 of the stage; registers), two 1 KiB
+        // bank pieces C0, C1 (row tile w, both groups; LDS-DMA) -- all three during group 1 of the stage four earlier -- and
+        // query fragment B1 (group 1) during group 0 of the stage three earlier (its register is free only then).  Wave 0
+        // adds the row-init values behind the first stage of a tile.
+        // A wave stalls on the ISSUE of every such request behind the CU's other requests (measured on this kernel at
+        // 10 M x 768: the copies cost 46 ms and the query-fragment loads 48 ms of 349), and two SIMD partners stalled at the
+        // same point idle the matrix pipe.  So the requests are spread over the stage (one or two per group) and the two
+        // wave classes issue at different MFMA gaps: waves 0-3 behind MFMA 0 / 2 / 4 of a group, their partners 4-7 behind
+        // MFMA 1 / 3 / 5 (B1: 0 / 4) -- same order within a wave, so one hand-counted vmcnt serves both.
         const char* bank_w = reinterpret_cast<const char*>(a.bank16) + (size_t)w * g16 * 1024;
         const char* query_w = reinterpret_cast<const char*>(a.q16) + (size_t)(seg.q_tile * 8 + w) * g16 * 1024;
         int fbt = seg.b_tile0, fks = 0, slot_f = 0, left = total, fpar = 0;
-// The two wave classes wait for different counts.  ONE asm statement with the branch inside: with two statements in an
-// if / else hipcc copied the "+v" registers ahead of the wait on one side (reading fragments that had not landed yet).
-#define F2_WAIT(N_ISSUER, N_OTHER, B0, B1)                                                                                   \
-        if (F2_SYM) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(B0), "+v"(B1) : "i"((N_ISSUER + N_OTHER) / 2) : "memory");      \
-        else asm volatile("s_cmp_lt_u32 %2, 4\n\ts_cbranch_scc1 .Lf2w_%=\n\ts_waitcnt vmcnt(" #N_OTHER ")\n\ts_branch .Lf2d_%=\n" \
-                     ".Lf2w_%=:\n\ts_waitcnt vmcnt(" #N_ISSUER ")\n.Lf2d_%=:"                                               \
-                     : "+v"(B0), "+v"(B1) : "s"(w) : "memory", "scc");
-#ifndef F2_SYM
-#define F2_SYM 1     /* 1 = all eight waves issue two copies each; 0 = waves 0-3 four each (measured: 352 vs 342 ms) */
+        const char* qsrc_b1 = query_w;   // query fragments of the stage whose B1 is still to be requested
+#define F2_QSRC() (F2_ABL_Q(query_w) + (size_t)fks * 2048)
+        // a query-fragment load for ONE wave class (CLS 0: waves 0-3, 1: waves 4-7); the branch sits inside the statement, so
+        // the "+v" register is the same on both paths (an if / else around two statements made hipcc copy it early)
+#if defined(F16_ABL) && (F16_ABL & 64)
+#define F2_BL(REG, SRC, OFF, CLS) asm volatile("" : "+v"(REG) : "s"(SRC));   // timing only: no query fragment loads
+#define F2_BL_ALL(REG, SRC, OFF) asm volatile("" : "+v"(REG) : "s"(SRC));
+#else
+#define F2_BL(REG, SRC, OFF, CLS)                                                                                            \
+        asm volatile("s_cmp_lt_u32 %3, 4\n\ts_cbranch_scc" #CLS " .Lf2s_%=\n\tglobal_load_dwordx4 %0, %1, %2 offset:" #OFF "\n.Lf2s_%=:" \
+                     : "+v"(REG) : "v"(lane_off), "s"(SRC), "s"(w) : "memory", "scc");
+#define F2_BL_ALL(REG, SRC, OFF) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "=v"(REG) : "v"(lane_off), "s"(SRC) : "memory");
 #endif
-#define F2_COPY(I)   /* piece I of this wave: row tile w + 4 (I >> 1), group I & 1 */                                        \
-        if (F2_SYM) {                                                                                                        \
-            if ((I) < 2) {                                                                                                   \
-                const char* bsrc = bank_w + ((size_t)F2_ABL_BT(fbt) * 8 * g16 + (size_t)fks * 2 + (I)) * 1024 + lane_off;   \
-                F2_DMA(bsrc, smem + slot_f * F2_SLOT + (w * 2 + (I)) * 1024)                                                 \
-            }                                                                                                                \
-        } else if (w < 4) {                                                                                                  \
-            const char* bsrc = bank_w + ((size_t)F2_ABL_BT(fbt) * 8 * g16 + (size_t)((I) >> 1) * 4 * g16 + (size_t)fks * 2 + ((I) & 1)) * 1024 + lane_off; \
-            char* bdst = smem + slot_f * F2_SLOT + ((w + 4 * ((I) >> 1)) * 2 + ((I) & 1)) * 1024;                            \
-            F2_DMA(bsrc, bdst)                                                                                               \
-        }
-#define F2_BATCH(B0, B1)                                                                                                     \
+#define F2_COPY(I)   /* bank piece I of this wave: row tile w, group I */                                                    \
         {                                                                                                                    \
-            const char* qsrc = F2_ABL_Q(query_w) + (size_t)fks * 2048;                                                       \
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(B0) : "v"(lane_off), "s"(qsrc) : "memory");                 \
-            asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(B1) : "v"(lane_off), "s"(qsrc) : "memory");     \
+            const char* bsrc = bank_w + ((size_t)F2_ABL_BT(fbt) * 8 * g16 + (size_t)fks * 2 + (I)) * 1024 + lane_off;       \
+            F2_DMA(bsrc, smem + slot_f * F2_SLOT + (w * 2 + (I)) * 1024)                                                     \
+        }
+#define F2_ADVANCE()                                                                                                         \
+        {                                                                                                                    \
             if (fks == 0 && w == 0) glds16(a.binit + (size_t)fbt * HB_BT + lane * 4, smem + F2_BINIT + fpar * 1024);        \
+            qsrc_b1 = F2_QSRC();                                                                                             \
             if (--left > 0) { if (++fks == NS) { fks = 0; fbt += bstride; fpar ^= 1; } }                                     \
             slot_f = (slot_f + 1) & (F2_RING - 1);                                                                           \
         }
-        // vmcnt by hand: a batch is 6 requests (waves 0-3) or 2 (waves 4-7) in a fixed order (wave 0: now and then 7, which
-        // only makes a wait stricter).  Batch j (stage j's data) is issued during stage j - 4.  Stage s + 1 must have landed
-        // at the barrier in the middle of stage s: batches s - 2 and s - 1 are younger -> "all but the newest 12" (4).  Past
-        // the last stage the fetch position stays put (same requests again, results unused), so the count never changes.
-#define F2_ALL(B0, B1) F2_COPY(0) F2_COPY(1) F2_COPY(2) F2_COPY(3) F2_BATCH(B0, B1)
-        F2_ALL(bq[0][0], bq[0][1]) F2_ALL(bq[1][0], bq[1][1]) F2_ALL(bq[2][0], bq[2][1]) F2_ALL(bq[3][0], bq[3][1])
-        // stage 0 has landed: three younger batches of 6 (waves 0-3) or 2 (waves 4-7) requests
-        F2_WAIT(18, 6, bq[0][0], bq[0][1])
+        // vmcnt by hand.  Order of a wave's requests: ... B1(s+3) | B0(s+4) C0 C1 | B1(s+4) | B0(s+5) ... (wave 0: now and
+        // then one more, which only makes a wait stricter).  At the barrier in the middle of stage s everything of stage
+        // s + 1 must have landed; its youngest request is B1(s+1), behind it come B0 C0 C1 (s+2), B1(s+2), B0 C0 C1 (s+3) and
+        // B1(s+3) -> "all but the newest 8".  Past the last stage the fetch position stays put (same requests again, results
+        // unused), so the count never changes.
+        F2_BL_ALL(bq[0][0], F2_QSRC(), 0) F2_COPY(0) F2_COPY(1) F2_ADVANCE() F2_BL_ALL(bq[0][1], qsrc_b1, 1024)
+        F2_BL_ALL(bq[1][0], F2_QSRC(), 0) F2_COPY(0) F2_COPY(1) F2_ADVANCE() F2_BL_ALL(bq[1][1], qsrc_b1, 1024)
+        F2_BL_ALL(bq[2][0], F2_QSRC(), 0) F2_COPY(0) F2_COPY(1) F2_ADVANCE() F2_BL_ALL(bq[2][1], qsrc_b1, 1024)
+        F2_BL_ALL(bq[3][0], F2_QSRC(), 0) F2_COPY(0) F2_COPY(1) F2_ADVANCE()
+        // stage 0 (and B1 of it) has landed: eleven younger requests
+        asm volatile("s_waitcnt vmcnt(11)" : "+v"(bq[0][0]), "+v"(bq[0][1]) :: "memory");
         __syncthreads();
         int slot_c = 0, ks = 0, bt = seg.b_tile0, cpar = 0;
 #if defined(F16_ABL) && (F16_ABL & 256)
@@ -366,31 +368,31 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
             const f16x8* Ac = reinterpret_cast<const f16x8*>(smem + slot_c * F2_SLOT) + lane;                                \
             const int slot_n = (slot_c + 1) & (F2_RING - 1);                                                                 \
             const f16x8* An = reinterpret_cast<const f16x8*>(smem + slot_n * F2_SLOT) + lane;                                \
-            /* group 0; filler after MFMA t: fragment t of group 1 */                                                        \
-            KN_FENCE F2_MM(0, bq[U][0]) KN_FENCE F2_RD(fa[0], Ac[(0 * 2 + 1) * 64])                                               \
-            KN_FENCE F2_MM(1, bq[U][0]) KN_FENCE F2_RD(fa[1], Ac[(1 * 2 + 1) * 64])                                               \
-            KN_FENCE F2_MM(2, bq[U][0]) KN_FENCE F2_RD(fa[2], Ac[(2 * 2 + 1) * 64])                                               \
-            KN_FENCE F2_MM(3, bq[U][0]) KN_FENCE F2_RD(fa[3], Ac[(3 * 2 + 1) * 64])                                               \
-            KN_FENCE F2_MM(4, bq[U][0]) KN_FENCE F2_RD(fa[4], Ac[(4 * 2 + 1) * 64])                                               \
-            KN_FENCE F2_MM(5, bq[U][0]) KN_FENCE F2_RD(fa[5], Ac[(5 * 2 + 1) * 64])                                               \
-            KN_FENCE F2_MM(6, bq[U][0]) KN_FENCE F2_RD(fa[6], Ac[(6 * 2 + 1) * 64])                                               \
-            KN_FENCE F2_MM(7, bq[U][0]) KN_FENCE F2_RD(fa[7], Ac[(7 * 2 + 1) * 64])                                               \
+            /* group 0; filler after MFMA t: fragment t of group 1; B1 of the stage three ahead */                           \
+            KN_FENCE F2_MM(0, bq[U][0]) KN_FENCE F2_RD(fa[0], Ac[(0 * 2 + 1) * 64]) F2_BL(bq[(U + 3) & 3][1], qsrc_b1, 1024, 0)  \
+            KN_FENCE F2_MM(1, bq[U][0]) KN_FENCE F2_RD(fa[1], Ac[(1 * 2 + 1) * 64])                                          \
+            KN_FENCE F2_MM(2, bq[U][0]) KN_FENCE F2_RD(fa[2], Ac[(2 * 2 + 1) * 64])                                          \
+            KN_FENCE F2_MM(3, bq[U][0]) KN_FENCE F2_RD(fa[3], Ac[(3 * 2 + 1) * 64])                                          \
+            KN_FENCE F2_MM(4, bq[U][0]) KN_FENCE F2_RD(fa[4], Ac[(4 * 2 + 1) * 64]) F2_BL(bq[(U + 3) & 3][1], qsrc_b1, 1024, 1)  \
+            KN_FENCE F2_MM(5, bq[U][0]) KN_FENCE F2_RD(fa[5], Ac[(5 * 2 + 1) * 64])                                          \
+            KN_FENCE F2_MM(6, bq[U][0]) KN_FENCE F2_RD(fa[6], Ac[(6 * 2 + 1) * 64])                                          \
+            KN_FENCE F2_MM(7, bq[U][0]) KN_FENCE F2_RD(fa[7], Ac[(7 * 2 + 1) * 64])                                          \
             KN_FENCE                                                                                                         \
             /* the next stage has landed: my requests (and my query fragments of it), then everyone's */                    \
-            F2_WAIT(12, 4, bq[(U + 1) & 3][0], bq[(U + 1) & 3][1])                                                          \
+            asm volatile("s_waitcnt vmcnt(8)" : "+v"(bq[(U + 1) & 3][0]), "+v"(bq[(U + 1) & 3][1]), "+v"(bq[U][1]) :: "memory"); \
             F2_BARRIER()   /* raw s_barrier: __syncthreads() would drain the LDS-DMA copies (vmcnt(0)) */                    \
-            /* group 1; filler after MFMA t: fragment t of the next stage's group 0; then this stage's batch */              \
+            /* group 1; filler after MFMA t: fragment t of the next stage's group 0; B0 C0 C1 of the stage four ahead */     \
             if (w == 0) cl_tick(cs, clock0 + st + (U), lane);   /* cluster soft sync, ahead of the stage's requests */       \
-            KN_FENCE F2_MM(0, bq[U][1]) KN_FENCE F2_RD(fa[0], An[(0 * 2) * 64]) F2_COPY(0)                                        \
-            KN_FENCE F2_MM(1, bq[U][1]) KN_FENCE F2_RD(fa[1], An[(1 * 2) * 64])                                                   \
-            KN_FENCE F2_MM(2, bq[U][1]) KN_FENCE F2_RD(fa[2], An[(2 * 2) * 64]) F2_COPY(1)                                        \
-            KN_FENCE F2_MM(3, bq[U][1]) KN_FENCE F2_RD(fa[3], An[(3 * 2) * 64])                                                   \
-            KN_FENCE F2_MM(4, bq[U][1]) KN_FENCE F2_RD(fa[4], An[(4 * 2) * 64]) F2_COPY(2)                                        \
-            KN_FENCE F2_MM(5, bq[U][1]) KN_FENCE F2_RD(fa[5], An[(5 * 2) * 64])                                                   \
-            KN_FENCE F2_MM(6, bq[U][1]) KN_FENCE F2_RD(fa[6], An[(6 * 2) * 64]) F2_COPY(3)                                        \
-            KN_FENCE F2_MM(7, bq[U][1]) KN_FENCE F2_RD(fa[7], An[(7 * 2) * 64])                                                   \
+            KN_FENCE F2_MM(0, bq[U][1]) KN_FENCE F2_RD(fa[0], An[(0 * 2) * 64]) F2_BL(bq[U][0], F2_QSRC(), 0, 0)             \
+            KN_FENCE F2_MM(1, bq[U][1]) KN_FENCE F2_RD(fa[1], An[(1 * 2) * 64]) F2_BL(bq[U][0], F2_QSRC(), 0, 1)             \
+            KN_FENCE F2_MM(2, bq[U][1]) KN_FENCE F2_RD(fa[2], An[(2 * 2) * 64]) if (w < 4) F2_COPY(0)                        \
+            KN_FENCE F2_MM(3, bq[U][1]) KN_FENCE F2_RD(fa[3], An[(3 * 2) * 64]) if (w >= 4) F2_COPY(0)                       \
+            KN_FENCE F2_MM(4, bq[U][1]) KN_FENCE F2_RD(fa[4], An[(4 * 2) * 64]) if (w < 4) F2_COPY(1)                        \
+            KN_FENCE F2_MM(5, bq[U][1]) KN_FENCE F2_RD(fa[5], An[(5 * 2) * 64]) if (w >= 4) F2_COPY(1)                       \
+            KN_FENCE F2_MM(6, bq[U][1]) KN_FENCE F2_RD(fa[6], An[(6 * 2) * 64])                                              \
+            KN_FENCE F2_MM(7, bq[U][1]) KN_FENCE F2_RD(fa[7], An[(7 * 2) * 64])                                              \
             KN_FENCE                                                                                                         \
-            F2_BATCH(bq[U][0], bq[U][1])                                                                                     \
+            F2_ADVANCE()                                                                                                     \
             KN_FENCE                                                                                                         \
             slot_c = slot_n;                                                                                                 \
         }
@@ -419,10 +421,11 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
 #undef F2_STAGE
 #undef F2_MM
 #undef F2_INIT_TILE
-#undef F2_BATCH
+#undef F2_ADVANCE
 #undef F2_COPY
-#undef F2_ALL
-#undef F2_WAIT
+#undef F2_BL
+#undef F2_BL_ALL
+#undef F2_QSRC
         if (w == 0) cl_publish(cs, seg.next_tile0 == 0x7FFFFFFF ? 0x7FFFFFFF : seg.next_tile0 * NS, lane);   // covers idle units
         pool_end(pv, seg.slot, pcnt, thr, myq, lane);
         if (lane < 32) floor_publish(a.gthr, seg.q_tile * HB_QT + myq, thr);
@@ -522,8 +525,9 @@ int hb_launch_rerank(const float* tiles, const float* binit, int g8, int d, cons
 }
 
 int hb_knn_f16_launch(const knn16_args& args, int grid, int design, hipStream_t s) {
-    if (design != 1) {   // second design (default)
-        void (*fn)(knn16_args) = args.klw <= 256 ? knn_f16v2_kernel<4> : knn_f16v2_kernel<8>;
+    if (design != 1 && args.klw <= 256) {   // second design (default); pools beyond 256 entries (k > 64): the compaction's
+        // registers do not fit beside the query-fragment buffers without spills, the first design serves those
+        void (*fn)(knn16_args) = knn_f16v2_kernel<4>;
         if (hb_ensure_dyn_lds((const void*)fn, F2_LDS_TOTAL)) return -1;
         fn<<<dim3((unsigned)grid), dim3(HB_THREADS), F2_LDS_TOTAL, s>>>(args);
         HB_HIP(hipGetLastError());
