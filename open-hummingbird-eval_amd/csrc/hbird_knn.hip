@@ -31,7 +31,9 @@
 // ABL: timing-only ablation bits (results are garbage when != 0): 1 = no LDS-DMA in the steady state,
 // 2 = no fragment reads, 4 = no barrier / vmcnt wait, 8 = no epilogue.  Bit 512 is NOT an ablation: it adds the
 // radix-select cold start of a slot's first tile (exact; used for searches with few tiles per workgroup).
-template <int ABL, bool WIDE>
+// CL: support for L2-sharing clusters (strided segments, soft sync).  A separate instantiation: its extra scalar state
+// spilled SGPRs inside the stage loop of the pool (WIDE) instantiation (k = 90: +12 % kernel time).
+template <int ABL, bool WIDE, bool CL = false>
 __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -44,15 +46,16 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
     int* pcnt = reinterpret_cast<int*>(smem + KN_LISTS);
     const int g8 = a.g8, k = a.k;   // g8 = stages per bank tile
     const int myq = w * 32 + (lane & 31);
-    cl_sync cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + KN_CLWORDS);
+    cl_sync cs;
+    if constexpr (CL) cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + KN_CLWORDS);
 
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
     // "everything before my first segment is done" (a member without any work: everything)
-    if (w == 0) cl_publish(cs, seg_begin < seg_end ? a.segs[seg_begin].tile0 * g8 : 0x7FFFFFFF, lane);
+    if constexpr (CL) { if (w == 0) cl_publish(cs, seg_begin < seg_end ? a.segs[seg_begin].tile0 * g8 : 0x7FFFFFFF, lane); }
     for (int si = seg_begin; si < seg_end; ++si) {
         const hb_seg seg = a.segs[si];
         const int klw = a.klw;   // list row stride (HB_KL on the LDS path)
-        const int bstride = seg.stride, clock0 = seg.tile0 * g8;
+        const int bstride = CL ? seg.stride : 1, clock0 = CL ? seg.tile0 * g8 : 0;
         float* wl_s = a.state_s + (size_t)seg.slot * HB_QT * klw;      // this slot's lists in global memory
         unsigned* wl_i = a.state_i + (size_t)seg.slot * HB_QT * klw;
         float thr;
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
                     glds16(src + (size_t)4 * g8 * HB_BLK, smem + slot * KN_SLOT_BYTES + 8192 + (w + 4) * 1024);
                 }
             }
-            if (ks == 0 && w == 0) glds16(a.binit + (size_t)bt * HB_BT + lane * 4, smem + KN_BINIT + fpar * 1024);
+            if (ks == 0 && w == 0) glds16(a.binit + (size_t)bt * HB_BT + lane * 4, smem + KN_BINIT + (CL ? fpar : (bt & 1)) * 1024);
         };
 
         int bt = seg.b_tile0, ks = 0;          // stage being computed
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
         // stage: the steady-state loop has no data-dependent branches around its LDS traffic, so the compiler
         // counts its lgkmcnt waits instead of draining.
         auto advance_fetch = [&]() {
-            if (--left > 0) { if (++fks == g8) { fks = 0; fbt += bstride; fpar ^= 1; } }
+            if (--left > 0) { if (++fks == g8) { fks = 0; fbt += bstride; if constexpr (CL) fpar ^= 1; } }
             if (++slot_f == KN_RING) slot_f = 0;
         };
         // vmcnt is counted by hand (the compiler does not wait for LDS-DMA at a barrier): an issuing wave has
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
                     if (lane < 32)
                         __builtin_amdgcn_global_load_lds((gbl_cvoid*)(a.gthr + seg.q_tile * HB_QT + w * 32 + lane), (lds_void*)sc, 4, 0, 16);
                 }
-                const f32x4* bi = reinterpret_cast<const f32x4*>(smem + KN_BINIT + cpar * 1024);
+                const f32x4* bi = reinterpret_cast<const f32x4*>(smem + KN_BINIT + (CL ? cpar : (bt & 1)) * 1024);
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
             KN_FENCE KN_MFMA(0, fa, fb, 1) KN_MFMA(1, fa, fb, 1) KN_FENCE
             // cluster soft sync: wave 0 pays the issue of one more vector-memory instruction now and then (its SIMD partner
             // covers it like it covers the copies); issued AHEAD of the stage's copies, so the hand-counted vmcnt still holds
-            if (w == 0) cl_tick(cs, clock0 + st, lane);
+            if constexpr (CL) { if (w == 0) cl_tick(cs, clock0 + st, lane); }
             if constexpr (!(ABL & 1)) issue_a(fbt, fks, slot_f);
             KN_FENCE KN_MFMA(2, fa, fb, 1) KN_MFMA(3, fa, fb, 1) KN_MFMA(0, fa, fb, 2) KN_MFMA(1, fa, fb, 2) KN_FENCE
             if constexpr (!(ABL & 1)) issue_b(fbt, fks, slot_f);
@@ -186,7 +189,16 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
             slot_c = slot_n;
             if (++ks == g8) {
                 if constexpr (!(ABL & 8)) {
-                    if constexpr (WIDE) tile_epilogue<true, true>(acc, thr, wl_s, wl_i, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
+                    if constexpr (WIDE) {
+                        // the slot's pool pointers are derived HERE (from one scalar, laundered so that the compiler cannot
+                        // hoist them): kept live through the stage loop they crowd out the copy loop's own pointers, which
+                        // then come back from spilled SGPRs in every stage (k = 90: +10 % kernel time)
+                        int slot_ = seg.slot;
+                        asm volatile("" : "+s"(slot_));
+                        float* ps = a.state_s + (size_t)slot_ * HB_QT * klw;
+                        unsigned* pi = a.state_i + (size_t)slot_ * HB_QT * klw;
+                        tile_epilogue<true, true>(acc, thr, ps, pi, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
+                    }
                     else {
                         if constexpr (ABL & 512) {   // small searches: radix-select cold start (separate instantiation, see launcher)
                             if (seg.first && bt == seg.b_tile0) thr = fmaxf(thr, cold_start_threshold(acc, k));
@@ -208,10 +220,10 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
                     for (int t = 0; t < 8; ++t) asm volatile("" :: "v"(acc[t]));
                 }
                 ks = 0;
-                bt += bstride; cpar ^= 1;
+                bt += bstride; if constexpr (CL) cpar ^= 1;
             }
         }
-        if (w == 0) cl_publish(cs, seg.next_tile0 == 0x7FFFFFFF ? 0x7FFFFFFF : seg.next_tile0 * g8, lane);   // covers idle units
+        if constexpr (CL) { if (w == 0) cl_publish(cs, seg.next_tile0 == 0x7FFFFFFF ? 0x7FFFFFFF : seg.next_tile0 * g8, lane); }   // covers idle units
         if constexpr (!WIDE) {   // store the partial lists of this segment
             for (int e = lane; e < 1024; e += 64) { wl_s[w * 1024 + e] = lst_s[w * 1024 + e]; wl_i[w * 1024 + e] = lst_i[w * 1024 + e]; }
         } else {
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (unused) run-ahead copies
         __syncthreads();   // the ring is reused by the next segment's prologue
     }
-    cl_finish(cs, a.cl_stats, w == 0, lane);
+    if constexpr (CL) cl_finish(cs, a.cl_stats, w == 0, lane);
 }
 
 // ---- merge of the partial lists of one query: rank by counting over <= slots*k candidates --------
@@ -744,6 +756,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     };
     static const int variant_bits[] = {0, -1, 1, 2, 4, 8, 15, 16, 13, 14, 11, 7, 3, 5, 6, 9, 10, 12, 32, 64, 96, 128, 256, 384};
     knn_fn fn = variants[wide ? 1 : 0];
+    if (a.cl > 1) fn = wide ? (knn_fn)knn_fused_kernel<0, true, true> : (knn_fn)knn_fused_kernel<0, false, true>;
     // Few stages per workgroup: a slot sees few rows, so its cold start (the first tile inserts all 256 rows of every
     // query) and its insertions (k ln(rows / k) per query) are a visible share of the search -> the instantiation with the
     // radix-select cold start, the scan epilogue (register queue + immediate inserts) and the per-tile exchange of
@@ -752,7 +765,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // extra code costs 0.3 % (same-box A/B), the crossover is near 3 M rows.
     static const knn_fn cold_fn = knn_fused_kernel<512, false>;
     static const long long cold_limit = getenv("HBIRD_COLD_LIMIT") ? atoll(getenv("HBIRD_COLD_LIMIT")) : 400000;   // stages per workgroup
-    if (!wide && (long long)nqt * nbt / std::max(1, sc.G) * ix->g8 < cold_limit) fn = cold_fn;
+    if (!wide && a.cl == 1 && (long long)nqt * nbt / std::max(1, sc.G) * ix->g8 < cold_limit) fn = cold_fn;
     if (!wide && ix->ablate)
         for (size_t i = 0; i < sizeof(variants) / sizeof(variants[0]); ++i) if (variant_bits[i] == ix->ablate) fn = variants[i];
     int threads = HB_THREADS;

@@ -186,19 +186,20 @@ __device__ __forceinline__ unsigned pool_kth(const unsigned (&key)[EMAX], bool (
     return prefix;
 }
 
-// Compact the pool at (gs, gi) -- its first n entries are valid, k <= n <= 64 EMAX -- to its best k in entries [0, k);
-// returns the k-th best score.
+// Compact the full pool (cap entries, cap <= 64 EMAX) at (gs, gi) to its best k in entries [0, k); returns the k-th best
+// score.  (A variant for partly filled pools -- per-lane validity masks -- cost the fp32 pool kernel its scalar registers:
+// reloads of spilled SGPRs in every stage, +10 % kernel time at k = 90.)
 template <int EMAX = HB_POOL_MAX / 64>
-__device__ __forceinline__ float pool_compact(float* gs, unsigned* gi, int n, int k, int lane) {
-    const int E = (n + 63) >> 6;
+__device__ __forceinline__ float pool_compact(float* gs, unsigned* gi, int cap, int k, int lane) {
+    const int E = cap >> 6;
     float es[EMAX];
     unsigned ei[EMAX], key[EMAX];
     bool act[EMAX];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's appends have landed
 #pragma unroll
     for (int e = 0; e < EMAX; ++e) {
-        es[e] = 0.f; ei[e] = 0; key[e] = 0; act[e] = false;   // key 0 is below every score's key: never counted, never kept
-        if (e < E && e * 64 + lane < n) {
+        es[e] = 0.f; ei[e] = 0; key[e] = 0; act[e] = false;
+        if (e < E) {
             es[e] = __hip_atomic_load(gs + e * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ei[e] = __hip_atomic_load(gi + e * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             key[e] = pool_key(es[e]);
@@ -214,7 +215,7 @@ __device__ __forceinline__ float pool_compact(float* gs, unsigned* gi, int n, in
     if (above + tied > k) {
         unsigned ik[EMAX];
 #pragma unroll
-        for (int e = 0; e < EMAX; ++e) { ik[e] = ~ei[e]; act[e] = (e < E) && key[e] == kt; }   // kt > 0: no padding entry
+        for (int e = 0; e < EMAX; ++e) { ik[e] = ~ei[e]; act[e] = (e < E) && key[e] == kt; }
         id_cut = ~pool_kth<EMAX>(ik, act, E, k - above);
     }
     float kth = 0.f;
@@ -281,14 +282,12 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, floa
                         lst_i[(size_t)myq * klw + c] = row_base + hh * 4 + j;
                         cnt[myq] = c + 1;
                     }
-                    // a pool is compacted as soon as fewer than two free entries are left (pool_epilogue_scan appends up to two
-                    // entries per query at a time)
-                    unsigned long long full = __ballot(pass && c + 2 >= klw);
+                    unsigned long long full = __ballot(pass && c + 1 == klw);
                     while (full) {
                         const int n = __builtin_ctzll(full) & 31;
                         full &= full - 1;
                         const size_t off = (size_t)(qb + n) * klw;
-                        const float kth = pool_compact<EMAX>(lst_s + off, lst_i + off, klw - 1, k, lane);
+                        const float kth = pool_compact<EMAX>(lst_s + off, lst_i + off, klw, k, lane);
                         if (lane == 0) cnt[qb + n] = k;
                         if ((lane & 31) == n) thr = fmaxf(thr, kth);
                     }
@@ -371,30 +370,35 @@ __device__ __forceinline__ void pool_epilogue_scan(f32x16 (&acc)[8], float& thr,
     }
     const int myq = qb + (lane & 31);
     const unsigned row0 = bt * HB_BT + 4u * (unsigned)(lane >> 5);
-    // Drain: queue entry i of every lane at once.  The two lane halves hold different rows of the SAME query, so the
-    // slot in the query's pool comes from an LDS atomic; a pool always has two free entries when a pass starts
-    // (cnt <= klw - 2) and is compacted as soon as it has fewer.
+    // Drain: queue entry i of every lane, one lane half at a time (the two halves hold different rows of the SAME query and
+    // would race on its fill count; an LDS-atomic variant that drained both at once measured the same and needed a
+    // compaction of partly filled pools).
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const bool has = np > i;
         if (__ballot(has) == 0ull) break;
         const float v = i == 0 ? q0v : i == 1 ? q1v : i == 2 ? q2v : q3v;
         const int code = i == 0 ? q0c : i == 1 ? q1c : i == 2 ? q2c : q3c;
-        int c = 0;
-        if (has) {
-            c = __hip_atomic_fetch_add(cnt + myq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            pool_s[(size_t)myq * klw + c] = v;
-            pool_i[(size_t)myq * klw + c] = row0 + (unsigned)code;
-        }
-        unsigned long long full = __ballot(has && c + 2 >= klw);   // c + 1 or c + 2 entries now: at most one free
-        while (full) {
-            const int n = __builtin_ctzll(full) & 31;
-            full &= ~((1ull << n) | (1ull << (n + 32)));
-            const size_t off = (size_t)(qb + n) * klw;
-            const int valid = __builtin_amdgcn_readfirstlane(cnt[qb + n]);
-            const float kth = pool_compact<EMAX>(pool_s + off, pool_i + off, valid, k, lane);
-            if (lane == 0) cnt[qb + n] = k;
-            if ((lane & 31) == n) thr = fmaxf(thr, kth);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const bool pass = has && (lane >> 5) == hh;
+            if (__ballot(pass) == 0ull) continue;
+            int c = 0;
+            if (pass) {
+                c = cnt[myq];
+                pool_s[(size_t)myq * klw + c] = v;
+                pool_i[(size_t)myq * klw + c] = row0 + (unsigned)code;
+                cnt[myq] = c + 1;
+            }
+            unsigned long long full = __ballot(pass && c + 1 == klw);
+            while (full) {
+                const int n = __builtin_ctzll(full) & 31;
+                full &= full - 1;
+                const size_t off = (size_t)(qb + n) * klw;
+                const float kth = pool_compact<EMAX>(pool_s + off, pool_i + off, klw, k, lane);
+                if (lane == 0) cnt[qb + n] = k;
+                if ((lane & 31) == n) thr = fmaxf(thr, kth);
+            }
         }
     }
 }

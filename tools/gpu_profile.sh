@@ -1,35 +1,41 @@
 #!/bin/bash
-# rocprofv3 evidence for the headline bench: kernel-trace stats + HBM traffic counters (separate passes)
+# rocprofv3 evidence for the headline bench (round 2): kernel-trace stats + counter passes of the SHIPPED kernels, 10 M x 768.
+# usage: tools/gpu_profile.sh <tag>     -> gpurun_out/prof_<tag>/ (copy the summaries into profiles/<round>/)
 set -x
 export TMPDIR=/tmp
-OUT=gpurun_out/prof_${1:-r1}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${1:-r2}
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/trace.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_fetch.json 2> $OUT/fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_write.json 2> $OUT/write.err
-find $OUT -name "*.csv" | xargs ls -la
-# keep only the small summaries (kernel stats + the knn kernel's counter rows)
-for d in trace pmc_fetch pmc_write; do
-  find $OUT/$d -name "*kernel_stats.csv" -exec cp {} $OUT/${d}_kernel_stats.csv \;
-  find $OUT/$d -name "*counter_collection.csv" -exec sh -c 'head -1 "$1" > "$2"; grep -E "knn_|rows_to_tiles|aggregate|query_aux" "$1" >> "$2"' _ {} $OUT/${d}_counters.csv \;
-  find $OUT/$d -name "*kernel_trace.csv" -exec sh -c 'head -1 "$1" > "$2"; grep -E "knn_|aggregate_kernel|query_aux|rows_to_tiles_kernel<false, false>" "$1" | tail -40 >> "$2"' _ {} $OUT/${d}_kernel_trace_hot.csv \;
-  rm -rf $OUT/$d
-done
+cd /tmp
+B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-traffic"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_trace -- $B --steps 3 --warmup 1 > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+find /tmp/p_trace -name "*kernel_stats.csv" -exec cp {} $OUT/knn_10Mx768_kernel_stats.csv \;
+find /tmp/p_trace -name "*kernel_trace.csv" -exec sh -c 'head -1 "$1" > "$2"; grep -E "knn_|aggregate_kernel|query_aux|rerank|rows_to_tiles_kernel<false, false>|tiles_to_f16" "$1" | tail -60 >> "$2"' _ {} $OUT/knn_10Mx768_kernel_trace_hot.csv \;
+pass() {  # name, counters...
+  name=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/p_$name -- $B --steps 1 --warmup 0 > /dev/null 2> $OUT/$name.err
+  find /tmp/p_$name -name "*counter_collection.csv" -exec sh -c 'head -1 "$1" > "$2"; grep -E "knn_fused|knn_f16" "$1" >> "$2"' _ {} $OUT/knn_10Mx768_pmc_$name.csv \;
+  rm -rf /tmp/p_$name
+}
+pass FETCH_SIZE FETCH_SIZE
+pass WRITE_SIZE WRITE_SIZE
+pass TCC TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
+pass EA_LATENCY TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum
+pass SQ_GRBM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE
+pass LDS_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
 python3 - <<PY
-import csv, json
-def val(f, ctr):
-    rows = [r for r in csv.DictReader(open(f)) if "knn_fused" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
-    return sum(float(r["Counter_Value"]) for r in rows) / max(1, len(rows))
-fetch = val("$OUT/pmc_fetch_counters.csv", "FETCH_SIZE"); write = val("$OUT/pmc_write_counters.csv", "WRITE_SIZE")
-b = json.load(open("$OUT/bench_trace.json"))
-out = {"kernel": "knn_fused_kernel", "workload": {k: b["config"][k] for k in ("bank_rows", "dim", "k", "queries_per_step")},
-       "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
-       "traffic_bytes_per_launch": 2 * fetch * 1024 + write * 1024,
-       "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide streaming reads); counts L2 misses incl. Infinity-Cache hits",
-       "rocprof_avg_kernel_ms": None}
-for r in csv.DictReader(open("$OUT/trace_kernel_stats.csv")):
-    if "knn_fused" in r["Name"]: out["rocprof_avg_kernel_ms"] = float(r["AverageNs"]) / 1e6
-json.dump(out, open("$OUT/knn_traffic.json", "w"), indent=1)
-print(out)
+import csv, glob, json, os
+out = {}
+for f in sorted(glob.glob("$OUT/knn_10Mx768_pmc_*.csv")):
+    agg = {}
+    for r in csv.DictReader(open(f)):
+        key = (r["Kernel_Name"].split("(")[0][:40], int(r["Dispatch_Id"]))
+        d = agg.setdefault(key, {})
+        d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        d["ms"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    out[os.path.basename(f)] = {f"{k[0]}#{k[1]}": v for k, v in agg.items()}
+json.dump(out, open("$OUT/pmc_summary.json", "w"), indent=1)
+for f, d in out.items():
+    print(f)
+    for k, v in d.items(): print("   ", k, {a: (round(b, 2) if a == "ms" else f"{b:.5g}") for a, b in v.items()})
 PY
-ls -la $OUT; tail -3 $OUT/*.err
+ls -la $OUT; tail -2 $OUT/*.err
