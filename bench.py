@@ -226,6 +226,25 @@ def measure_traffic(a, kernel):
         f"live: rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE = {vals['FETCH_SIZE']:.0f} KiB x2 + {vals['WRITE_SIZE']:.0f} KiB"
 
 
+_JSON_FD = None
+
+
+def claim_stdout():
+    """Rank 0's stdout must carry ONE line, the JSON.  Libraries print there too (RCCL's version banner, gloo's
+    connection notes, tqdm), so file descriptor 1 is pointed at stderr for everybody else and the result line is written
+    to a private duplicate of the original stdout."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(res):
+    sys.stdout.flush()
+    os.write(_JSON_FD if _JSON_FD is not None else 1, (json.dumps(res) + "\n").encode())
+
+
 def main():
     a = parse()
     env_world = os.environ.get("WORLD_SIZE")
@@ -239,6 +258,7 @@ def main():
             raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    claim_stdout()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # HBIRD_BENCH_ONE_GPU=1 (testing only): all ranks share cuda:0 and talk over gloo, since RCCL refuses two
@@ -437,10 +457,10 @@ def main():
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(D, k, M)
         res["miou_parity"] = miou_parity(device)
-    if rank == 0:
-        print(json.dumps(res), flush=True)
     if dist_on:
         td.destroy_process_group()
+    if rank == 0:
+        emit(res)
 
 
 if __name__ == "__main__":
