@@ -70,6 +70,9 @@ struct knn16_args {
 //    copies and whose partner covers it, AHEAD of the stage's copies (so that the hand-counted vmcnt still holds):
 //    +1.9 % without any sharing, +0.3 % net with it.
 #define HB_CL_PERIOD 32
+#ifndef HB_CL_SPINS
+#define HB_CL_SPINS 1024    // re-polls before a member gives up waiting (each about 0.5-1 us)
+#endif
 struct cl_sync {
     int* line;      // progress words of the cluster, one 128-B line per member
     int* lds;       // HB_CLUSTER_MAX words of LDS: landing zone of the poll
@@ -105,7 +108,7 @@ __device__ __forceinline__ void cl_tick(cl_sync& cs, int now, int lane) {
         while (cl_min_landed(cs, lane, wait) < now - cs.lag) {
             wait = true;
             ++cs.n_spins;
-            if (++spins > 4000) { cs.on = false; ++cs.n_timeouts; break; }      // a member is not running (yet): never wait for it again
+            if (++spins > HB_CL_SPINS) { cs.on = false; ++cs.n_timeouts; break; }       // a member is not running (or not visible): never wait again
             __builtin_amdgcn_s_sleep(8);
             cl_poll(cs, lane);
         }

@@ -242,7 +242,10 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
 #if defined(F16_ABL) && (F16_ABL & 32)
 #define F2_DMA(src, dst)                                   // timing only: no bank copies
 #else
-#define F2_DMA(src, dst) __builtin_amdgcn_global_load_lds((gbl_cvoid*)(src), (lds_void*)(dst), 16, 0, 0);
+#ifndef F2_CPOL
+#define F2_CPOL 0    /* cache policy of the bank copies (experiments: 2 = nt) */
+#endif
+#define F2_DMA(src, dst) __builtin_amdgcn_global_load_lds((gbl_cvoid*)(src), (lds_void*)(dst), 16, 0, F2_CPOL);
 #endif
 #if defined(F16_ABL) && (F16_ABL & 128)
 #define F2_BARRIER()                                       // timing only: no barrier
@@ -313,10 +316,13 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
 #define F2_BL(REG, SRC, OFF, CLS) asm volatile("" : "+v"(REG) : "s"(SRC));   // timing only: no query fragment loads
 #define F2_BL_ALL(REG, SRC, OFF) asm volatile("" : "+v"(REG) : "s"(SRC));
 #else
+#ifndef F2_BPOL
+#define F2_BPOL ""   /* cache policy of the query-fragment loads (experiments: " nt", " sc1") */
+#endif
 #define F2_BL(REG, SRC, OFF, CLS)                                                                                            \
-        asm volatile("s_cmp_lt_u32 %3, 4\n\ts_cbranch_scc" #CLS " .Lf2s_%=\n\tglobal_load_dwordx4 %0, %1, %2 offset:" #OFF "\n.Lf2s_%=:" \
+        asm volatile("s_cmp_lt_u32 %3, 4\n\ts_cbranch_scc" #CLS " .Lf2s_%=\n\tglobal_load_dwordx4 %0, %1, %2 offset:" #OFF F2_BPOL "\n.Lf2s_%=:" \
                      : "+v"(REG) : "v"(lane_off), "s"(SRC), "s"(w) : "memory", "scc");
-#define F2_BL_ALL(REG, SRC, OFF) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "=v"(REG) : "v"(lane_off), "s"(SRC) : "memory");
+#define F2_BL_ALL(REG, SRC, OFF) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF F2_BPOL : "=v"(REG) : "v"(lane_off), "s"(SRC) : "memory");
 #endif
 #define F2_COPY(I)   /* bank piece I of this wave: row tile w, group I */                                                    \
         {                                                                                                                    \
