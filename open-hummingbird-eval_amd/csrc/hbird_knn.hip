@@ -585,8 +585,9 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     const bool f16 = ix->fp16 != 0 && k <= 128;
     // fp16 mode: the fused kernel collects kc >= 2k candidates, the fp32 chain arithmetic re-ranks them
     const int kc = f16 ? std::min(256, std::max(64, (2 * k + 63) / 64 * 64)) : k;
-    const bool wide = f16 || k > HB_KL;
+    const bool wide = f16 || k > HB_KL;   // (pools for k <= 32 on small searches were tried: 8.1 vs 5.0 ms at 50,176 x 384)
     // pools (k > HB_KL): capacity >= 2 kc so that a compaction is paid for by >= kc cheap appends
+    // (smaller / larger pools measure the same on the fp16 candidate kernel: kc + 64, kc + 192)
     const int klw = wide ? std::min(HB_POOL_MAX, (std::max(2 * kc, kc + 128) + 63) / 64 * 64) : HB_KL;
     if (nq == 0) return 0;
     // score output (sharded searches): the ordering score goes out as it is, whatever the metric
@@ -764,7 +765,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // shards of the headline bank): 302.3 -> 300.5 ms.  The big searches keep the plain instantiation: at 10 M x 768 the
     // extra code costs 0.3 % (same-box A/B), the crossover is near 3 M rows.
     static const knn_fn cold_fn = knn_fused_kernel<512, false>;
-    static const long long cold_limit = getenv("HBIRD_COLD_LIMIT") ? atoll(getenv("HBIRD_COLD_LIMIT")) : 400000;   // stages per workgroup
+    const long long cold_limit = 400000;   // stages per workgroup
     if (!wide && a.cl == 1 && (long long)nqt * nbt / std::max(1, sc.G) * ix->g8 < cold_limit) fn = cold_fn;
     if (!wide && ix->ablate)
         for (size_t i = 0; i < sizeof(variants) / sizeof(variants[0]); ++i) if (variant_bits[i] == ix->ablate) fn = variants[i];

@@ -1,3 +1,3 @@
 #!/bin/bash
 export TMPDIR=/tmp
-for c in "8,1,16" "8,1,4" "8,1,8" "8,1,12" "8,1,24" "8,1,40" "1,1,0"; do EXP_CL=$c python tools/exp_f16_abl.py 10000000 768 21904 0 2>&1 | tail -1; done
+for e in 128 64 192; do HBIRD_POOL_EXTRA=$e EXP_CL=0,0,-1 python tools/exp_f16_abl.py 10000000 768 21904 0 2>&1 | tail -1; done
