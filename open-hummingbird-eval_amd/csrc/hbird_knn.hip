@@ -765,7 +765,11 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // shards of the headline bank): 302.3 -> 300.5 ms.  The big searches keep the plain instantiation: at 10 M x 768 the
     // extra code costs 0.3 % (same-box A/B), the crossover is near 3 M rows.
     static const knn_fn cold_fn = knn_fused_kernel<512, false>;
-    const long long cold_limit = 400000;   // stages per workgroup
+    // stages per workgroup below which the small-search instantiation wins: against the kernel with register-resident
+    // query fragments (below) the crossover is near 16 k stages (300 k x 768: 72.7 vs 73.9 ms; 200 k x 384: 17.6 vs 15.8 ms),
+    // against the LDS-staged kernel (shapes the other one does not serve) near 400 k
+    const bool bd_shape = !wide && a.cl == 1 && ix->g8 % 4 == 0 && !ix->ablate && ix->variant != 4;
+    const long long cold_limit = bd_shape ? 16000 : 400000;
     if (!wide && a.cl == 1 && (long long)nqt * nbt / std::max(1, sc.G) * ix->g8 < cold_limit) fn = cold_fn;
     if (!wide && ix->ablate)
         for (size_t i = 0; i < sizeof(variants) / sizeof(variants[0]); ++i) if (variant_bits[i] == ix->ablate) fn = variants[i];
@@ -774,9 +778,17 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         fn = hb_knn_w4_kernel(false);
         threads = 256;
     }
-    if (hb_ensure_dyn_lds((const void*)fn, KN_LDS_TOTAL)) return -1;   // per (kernel, device)
+    int lds_bytes = KN_LDS_TOTAL;
+    // The query fragments straight into registers (hbird_knn_bd.hip): -3.8 % kernel time at 10 M x 768 (0.895 -> 0.93 of the
+    // fp32 MFMA peak), same bits.  Default for the big LDS-list searches whose stage count per tile is a multiple of four
+    // (D = 384, 768, 1024, ...); variant 3 forces it wherever it applies (tests), variant 4 keeps the LDS-staged kernel.
+    if (bd_shape && ((ix->variant == 0 && fn == variants[0]) || ix->variant == 3)) {
+        fn = hb_knn_bd_kernel();
+        lds_bytes = hb_knn_bd_lds_bytes();
+    }
+    if (hb_ensure_dyn_lds((const void*)fn, lds_bytes)) return -1;   // per (kernel, device)
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev0, s));
-    fn<<<dim3((unsigned)sc.G), dim3(threads), KN_LDS_TOTAL, s>>>(a);
+    fn<<<dim3((unsigned)sc.G), dim3(threads), lds_bytes, s>>>(a);
     HB_HIP(hipGetLastError());
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
     const float* qn2 = ix->q_aux;   // [nq] chain ||q||^2 (valid for L2)

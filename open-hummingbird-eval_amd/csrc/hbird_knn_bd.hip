@@ -1,0 +1,153 @@
+// Variant 3 of the fp32 kNN kernel (hb_index_set_variant(ix, 3)): the same fused fp32-MFMA running top-k as
+// hbird_knn.hip -- same tiles, same k-ascending fmaf chains, same lists, hence the same bits -- with the QUERY fragments
+// loaded straight from global memory into registers instead of being staged through LDS.
+//
+// A wave's query fragment (32 queries x k8 = 1 KiB per stage) is read by that wave only, so the LDS stage buys no reuse: it
+// costs an LDS-DMA write (the expensive side of the LDS) and a ds_read per stage.  Here the LDS ring holds bank fragments
+// only (8 KiB per stage), the query fragment of stage s + 3 is requested during stage s by an inline-asm
+// global_load_dwordx4 (invisible to hipcc's wait-count pass, counted by hand with the copies) into one of four register
+// buffers; the stage loop is unrolled by four so that the buffers have static indices (g8 must be a multiple of 4).
+// LDS-list path (k <= 32) only; no clusters; big searches (the small-search instantiation stays in hbird_knn.hip).
+#include "hbird_knn_dev.h"
+
+#define BD_SLOT 8192                        // bank fragments of one k8 stage: 8 row tiles x 1 KiB
+#define BD_RING 4
+#define BD_BINIT (BD_RING * BD_SLOT)        // 2 x 1 KiB
+#define BD_LISTS (BD_BINIT + 2048)
+#define BD_SCRATCH (BD_LISTS + 2 * HB_QT * HB_KL * 4)
+#define BD_LDS_TOTAL (BD_SCRATCH + 8192)
+
+#define BD_MFMA(T, FR, B, S) acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(FR[(T) & 3][S], B[S], acc[T], 0, 0, 0);
+// the two wave classes have different numbers of requests in flight: ONE statement with the branch inside, so that the
+// "+v" register is the same on both paths (hbird_knn_f16.hip: two statements in an if / else made hipcc copy it early)
+#define BD_WAIT(N_ISSUER, N_OTHER, B)                                                                                   \
+    asm volatile("s_cmp_lt_u32 %1, 4\n\ts_cbranch_scc1 .Lbdw_%=\n\ts_waitcnt vmcnt(" #N_OTHER ")\n\ts_branch .Lbdd_%=\n"  \
+                 ".Lbdw_%=:\n\ts_waitcnt vmcnt(" #N_ISSUER ")\n.Lbdd_%=:"                                               \
+                 : "+v"(B) : "s"(w) : "memory", "scc");
+#define BD_BLOAD(B) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(B) : "v"(lane_off), "s"(qsrc + (size_t)fks * 1024) : "memory");
+
+__global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    float* lst_s = reinterpret_cast<float*>(smem + BD_LISTS);
+    unsigned* lst_i = reinterpret_cast<unsigned*>(smem + BD_LISTS + HB_QT * HB_KL * 4);
+    float* sc = reinterpret_cast<float*>(smem + BD_SCRATCH) + w * 256;
+    const int g8 = a.g8, k = a.k;
+    const int myq = w * 32 + (lane & 31);
+    const unsigned lane_off = (unsigned)lane * 16u;
+
+    const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
+    for (int si = seg_begin; si < seg_end; ++si) {
+        const hb_seg seg = a.segs[si];
+        float* wl_s = a.state_s + (size_t)seg.slot * HB_QT * HB_KL;
+        unsigned* wl_i = a.state_i + (size_t)seg.slot * HB_QT * HB_KL;
+        for (int e = lane; e < 1024; e += 64) {
+            lst_s[w * 1024 + e] = seg.first ? -INFINITY : wl_s[w * 1024 + e];
+            lst_i[w * 1024 + e] = seg.first ? HB_ID_NONE : wl_i[w * 1024 + e];
+        }
+        float thr = lst_s[myq * HB_KL + (k - 1)];
+        thr = fmaxf(thr, floor_load(a.gthr, seg.q_tile * HB_QT + myq));
+        const char* qsrc = reinterpret_cast<const char*>(a.q_tiles + ((size_t)(seg.q_tile * 8 + w) * g8) * HB_BLK);
+        const int total = seg.n_tiles * g8;
+        f32x16 acc[8];
+        f32x4 fa[4], fy[4];   // X-half / Y-half bank fragments
+        f32x4 bq[4];          // query fragments of four stages
+
+        // waves 0-3 copy the bank row tiles w and w + 4 of a stage (their SIMD partners 4-7 issue no copies, hbird_knn.hip)
+        auto issue_a = [&](int bt, int ks, int slot) {
+            if (w < 4) {
+                const float* src = a.bank_tiles + ((size_t)(bt * 8 + w) * g8 + ks) * HB_BLK + lane * 4;
+                glds16(src, smem + slot * BD_SLOT + w * 1024);
+                glds16(src + (size_t)4 * g8 * HB_BLK, smem + slot * BD_SLOT + (w + 4) * 1024);
+            }
+        };
+        int bt = seg.b_tile0, ks = 0;          // tile / stage being computed
+        int fbt = seg.b_tile0, fks = 0;        // next stage to fetch
+        int slot_c = 0, slot_f = 0, left = total;
+        auto advance_fetch = [&]() {
+            if (fks == 0 && w == 0) glds16(a.binit + (size_t)fbt * HB_BT + lane * 4, smem + BD_BINIT + (fbt & 1) * 1024);
+            if (--left > 0) { if (++fks == g8) { fks = 0; ++fbt; } }
+            if (++slot_f == BD_RING) slot_f = 0;
+        };
+        // vmcnt by hand.  Per stage a wave requests, in this order: (waves 0-3) two bank pieces, then its query fragment
+        // (wave 0, first stage of a tile: the row-init values behind it, which only makes a wait stricter).  The requests
+        // of stage j are issued during stage j - 3; at the top of stage s those of stage s + 1 must have landed, those of
+        // stage s + 2 may be in flight: "all but the newest 3" (waves 4-7: 1).  Past the last stage the fetch position stays
+        // put (same requests again, results unused), so the count never changes.
+        issue_a(fbt, fks, slot_f); BD_BLOAD(bq[0]) advance_fetch();
+        issue_a(fbt, fks, slot_f); BD_BLOAD(bq[1]) advance_fetch();
+        issue_a(fbt, fks, slot_f); BD_BLOAD(bq[2]) advance_fetch();
+        BD_WAIT(6, 2, bq[0])     // stage 0 landed; stages 1-2 in flight
+        __syncthreads();
+        {
+            const f32x4* A = reinterpret_cast<const f32x4*>(smem);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fa[t] = A[t * 64 + lane];
+        }
+#define BD_STAGE(U)                                                                                                     \
+        {                                                                                                               \
+            BD_WAIT(3, 1, bq[((U) + 1) & 3])   /* stage st + 1 has landed for me (st + 2 in flight) ... */              \
+            __builtin_amdgcn_s_barrier();      /* ... and for everyone; the slot of stage st - 1 is free for st + 3 */   \
+            int slot_n = slot_c + 1; if (slot_n == BD_RING) slot_n = 0;                                                 \
+            const f32x4* Ac = reinterpret_cast<const f32x4*>(smem + slot_c * BD_SLOT) + lane;                           \
+            const f32x4* An = reinterpret_cast<const f32x4*>(smem + slot_n * BD_SLOT) + lane;                           \
+            /* X half: tiles 0-3, k-steps 0-3; fillers: the four Y fragments, the copies, the query fragment of st + 3 */ \
+            KN_FENCE BD_MFMA(0, fa, bq[U], 0) KN_FENCE fy[0] = Ac[4 * 64];                                              \
+            KN_FENCE BD_MFMA(1, fa, bq[U], 0) KN_FENCE fy[1] = Ac[5 * 64];                                              \
+            KN_FENCE BD_MFMA(2, fa, bq[U], 0) KN_FENCE fy[2] = Ac[6 * 64];                                              \
+            KN_FENCE BD_MFMA(3, fa, bq[U], 0) KN_FENCE fy[3] = Ac[7 * 64];                                              \
+            KN_FENCE BD_MFMA(0, fa, bq[U], 1) BD_MFMA(1, fa, bq[U], 1) KN_FENCE                                         \
+            issue_a(fbt, fks, slot_f);                                                                                  \
+            KN_FENCE BD_MFMA(2, fa, bq[U], 1) BD_MFMA(3, fa, bq[U], 1) BD_MFMA(0, fa, bq[U], 2) BD_MFMA(1, fa, bq[U], 2) KN_FENCE \
+            BD_BLOAD(bq[((U) + 3) & 3])                                                                                 \
+            KN_FENCE BD_MFMA(2, fa, bq[U], 2) BD_MFMA(3, fa, bq[U], 2) KN_FENCE                                         \
+            advance_fetch();                                                                                            \
+            KN_FENCE BD_MFMA(0, fa, bq[U], 3) BD_MFMA(1, fa, bq[U], 3) BD_MFMA(2, fa, bq[U], 3) BD_MFMA(3, fa, bq[U], 3) KN_FENCE \
+            /* Y half: tiles 4-7; fillers: the X fragments of stage st + 1 */                                           \
+            KN_FENCE BD_MFMA(4, fy, bq[U], 0) KN_FENCE fa[0] = An[0 * 64];                                              \
+            KN_FENCE BD_MFMA(5, fy, bq[U], 0) KN_FENCE fa[1] = An[1 * 64];                                              \
+            KN_FENCE BD_MFMA(6, fy, bq[U], 0) KN_FENCE fa[2] = An[2 * 64];                                              \
+            KN_FENCE BD_MFMA(7, fy, bq[U], 0) KN_FENCE fa[3] = An[3 * 64];                                              \
+            KN_FENCE                                                                                                    \
+            BD_MFMA(4, fy, bq[U], 1) BD_MFMA(5, fy, bq[U], 1) BD_MFMA(6, fy, bq[U], 1) BD_MFMA(7, fy, bq[U], 1)         \
+            BD_MFMA(4, fy, bq[U], 2) BD_MFMA(5, fy, bq[U], 2) BD_MFMA(6, fy, bq[U], 2) BD_MFMA(7, fy, bq[U], 2)         \
+            BD_MFMA(4, fy, bq[U], 3) BD_MFMA(5, fy, bq[U], 3) BD_MFMA(6, fy, bq[U], 3) BD_MFMA(7, fy, bq[U], 3)         \
+            KN_FENCE                                                                                                    \
+            slot_c = slot_n;                                                                                            \
+        }
+        for (int st = 0; st < total; st += 4) {
+            if (ks == 0) {   // accumulators start from the bank rows' init values (landed with the tile's first stage)
+                // the init values of this tile were published by an earlier barrier (they ride with the tile's first stage)
+                const f32x4* bi = reinterpret_cast<const f32x4*>(smem + BD_BINIT + (bt & 1) * 1024);
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = bi[8 * t + 2 * g + h];
+                        acc[t][4 * g + 0] = v[0]; acc[t][4 * g + 1] = v[1];
+                        acc[t][4 * g + 2] = v[2]; acc[t][4 * g + 3] = v[3];
+                    }
+            }
+            BD_STAGE(0) BD_STAGE(1) BD_STAGE(2) BD_STAGE(3)
+            ks += 4;
+            if (ks == g8) {
+                tile_epilogue<true, false>(acc, thr, lst_s, lst_i, sc, w * 32, lane, k, (unsigned)bt);
+                ks = 0;
+                ++bt;
+            }
+        }
+#undef BD_STAGE
+        // the run-ahead requests still target the query-fragment registers: drain them while those registers are live
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) :: "memory");
+        for (int e = lane; e < 1024; e += 64) { wl_s[w * 1024 + e] = lst_s[w * 1024 + e]; wl_i[w * 1024 + e] = lst_i[w * 1024 + e]; }
+        if (lane < 32) floor_publish(a.gthr, seg.q_tile * HB_QT + myq, thr);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // the ring and the lists are reused by the next segment
+    }
+}
+
+hb_knn_fn hb_knn_bd_kernel() { return knn_fused_bd_kernel; }
+int hb_knn_bd_lds_bytes() { return BD_LDS_TOTAL; }
