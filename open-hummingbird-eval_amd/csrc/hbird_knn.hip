@@ -768,7 +768,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // stages per workgroup below which the small-search instantiation wins: against the kernel with register-resident
     // query fragments (below) the crossover is near 16 k stages (300 k x 768: 72.7 vs 73.9 ms; 200 k x 384: 17.6 vs 15.8 ms),
     // against the LDS-staged kernel (shapes the other one does not serve) near 400 k
-    const bool bd_shape = !wide && a.cl == 1 && ix->g8 % 4 == 0 && !ix->ablate && ix->variant != 4;
+    const bool bd_shape = a.cl == 1 && ix->g8 % 4 == 0 && !ix->ablate && ix->variant != 4;
     const long long cold_limit = bd_shape ? 16000 : 400000;
     if (!wide && a.cl == 1 && (long long)nqt * nbt / std::max(1, sc.G) * ix->g8 < cold_limit) fn = cold_fn;
     if (!wide && ix->ablate)
@@ -782,8 +782,8 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // The query fragments straight into registers (hbird_knn_bd.hip): -3.8 % kernel time at 10 M x 768 (0.895 -> 0.93 of the
     // fp32 MFMA peak), same bits.  Default for the big LDS-list searches whose stage count per tile is a multiple of four
     // (D = 384, 768, 1024, ...); variant 3 forces it wherever it applies (tests), variant 4 keeps the LDS-staged kernel.
-    if (bd_shape && ((ix->variant == 0 && fn == variants[0]) || ix->variant == 3)) {
-        fn = hb_knn_bd_kernel();
+    if (bd_shape && ((ix->variant == 0 && fn == variants[wide ? 1 : 0]) || ix->variant == 3)) {
+        fn = hb_knn_bd_kernel(wide);
         lds_bytes = hb_knn_bd_lds_bytes();
     }
     if (hb_ensure_dyn_lds((const void*)fn, lds_bytes)) return -1;   // per (kernel, device)

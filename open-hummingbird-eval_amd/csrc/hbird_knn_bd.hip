@@ -20,12 +20,17 @@
 #define BD_MFMA(T, FR, B, S) acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(FR[(T) & 3][S], B[S], acc[T], 0, 0, 0);
 // the two wave classes have different numbers of requests in flight: ONE statement with the branch inside, so that the
 // "+v" register is the same on both paths (hbird_knn_f16.hip: two statements in an if / else made hipcc copy it early)
+#ifdef BD_SYM
+#define BD_WAIT(N_ISSUER, N_OTHER, B) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(B) : "i"((N_ISSUER + N_OTHER) / 2) : "memory");
+#else
 #define BD_WAIT(N_ISSUER, N_OTHER, B)                                                                                   \
     asm volatile("s_cmp_lt_u32 %1, 4\n\ts_cbranch_scc1 .Lbdw_%=\n\ts_waitcnt vmcnt(" #N_OTHER ")\n\ts_branch .Lbdd_%=\n"  \
                  ".Lbdw_%=:\n\ts_waitcnt vmcnt(" #N_ISSUER ")\n.Lbdd_%=:"                                               \
                  : "+v"(B) : "s"(w) : "memory", "scc");
+#endif
 #define BD_BLOAD(B) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(B) : "v"(lane_off), "s"(qsrc + (size_t)fks * 1024) : "memory");
 
+template <bool WIDE>   // WIDE: k > HB_KL, candidate pools in global memory (as in hbird_knn.hip)
 __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -35,6 +40,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
     float* lst_s = reinterpret_cast<float*>(smem + BD_LISTS);
     unsigned* lst_i = reinterpret_cast<unsigned*>(smem + BD_LISTS + HB_QT * HB_KL * 4);
     float* sc = reinterpret_cast<float*>(smem + BD_SCRATCH) + w * 256;
+    int* pcnt = reinterpret_cast<int*>(smem + BD_LISTS);   // WIDE: pool fill counts in the (otherwise unused) list area
     const int g8 = a.g8, k = a.k;
     const int myq = w * 32 + (lane & 31);
     const unsigned lane_off = (unsigned)lane * 16u;
@@ -42,13 +48,19 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
     for (int si = seg_begin; si < seg_end; ++si) {
         const hb_seg seg = a.segs[si];
-        float* wl_s = a.state_s + (size_t)seg.slot * HB_QT * HB_KL;
-        unsigned* wl_i = a.state_i + (size_t)seg.slot * HB_QT * HB_KL;
-        for (int e = lane; e < 1024; e += 64) {
-            lst_s[w * 1024 + e] = seg.first ? -INFINITY : wl_s[w * 1024 + e];
-            lst_i[w * 1024 + e] = seg.first ? HB_ID_NONE : wl_i[w * 1024 + e];
+        const int klw = a.klw;
+        float* wl_s = a.state_s + (size_t)seg.slot * HB_QT * klw;
+        unsigned* wl_i = a.state_i + (size_t)seg.slot * HB_QT * klw;
+        float thr;
+        if constexpr (WIDE) {
+            thr = pool_begin(knn_args_pool_view{a.state_cnt, a.state_thr}, seg.slot, seg.first, pcnt, myq, lane);
+        } else {
+            for (int e = lane; e < 1024; e += 64) {
+                lst_s[w * 1024 + e] = seg.first ? -INFINITY : wl_s[w * 1024 + e];
+                lst_i[w * 1024 + e] = seg.first ? HB_ID_NONE : wl_i[w * 1024 + e];
+            }
+            thr = lst_s[myq * HB_KL + (k - 1)];
         }
-        float thr = lst_s[myq * HB_KL + (k - 1)];
         thr = fmaxf(thr, floor_load(a.gthr, seg.q_tile * HB_QT + myq));
         const char* qsrc = reinterpret_cast<const char*>(a.q_tiles + ((size_t)(seg.q_tile * 8 + w) * g8) * HB_BLK);
         const int total = seg.n_tiles * g8;
@@ -58,11 +70,16 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
 
         // waves 0-3 copy the bank row tiles w and w + 4 of a stage (their SIMD partners 4-7 issue no copies, hbird_knn.hip)
         auto issue_a = [&](int bt, int ks, int slot) {
+#ifdef BD_SYM   // experiments: every wave copies its own row tile
+            const float* src = a.bank_tiles + ((size_t)(bt * 8 + w) * g8 + ks) * HB_BLK + lane * 4;
+            glds16(src, smem + slot * BD_SLOT + w * 1024);
+#else
             if (w < 4) {
                 const float* src = a.bank_tiles + ((size_t)(bt * 8 + w) * g8 + ks) * HB_BLK + lane * 4;
                 glds16(src, smem + slot * BD_SLOT + w * 1024);
                 glds16(src + (size_t)4 * g8 * HB_BLK, smem + slot * BD_SLOT + (w + 4) * 1024);
             }
+#endif
         };
         int bt = seg.b_tile0, ks = 0;          // tile / stage being computed
         int fbt = seg.b_tile0, fks = 0;        // next stage to fetch
@@ -134,7 +151,8 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
             BD_STAGE(0) BD_STAGE(1) BD_STAGE(2) BD_STAGE(3)
             ks += 4;
             if (ks == g8) {
-                tile_epilogue<true, false>(acc, thr, lst_s, lst_i, sc, w * 32, lane, k, (unsigned)bt);
+                if constexpr (WIDE) tile_epilogue<true, true>(acc, thr, wl_s, wl_i, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
+                else tile_epilogue<true, false>(acc, thr, lst_s, lst_i, sc, w * 32, lane, k, (unsigned)bt);
                 ks = 0;
                 ++bt;
             }
@@ -142,12 +160,13 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
 #undef BD_STAGE
         // the run-ahead requests still target the query-fragment registers: drain them while those registers are live
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) :: "memory");
-        for (int e = lane; e < 1024; e += 64) { wl_s[w * 1024 + e] = lst_s[w * 1024 + e]; wl_i[w * 1024 + e] = lst_i[w * 1024 + e]; }
+        if constexpr (WIDE) pool_end(knn_args_pool_view{a.state_cnt, a.state_thr}, seg.slot, pcnt, thr, myq, lane);
+        else for (int e = lane; e < 1024; e += 64) { wl_s[w * 1024 + e] = lst_s[w * 1024 + e]; wl_i[w * 1024 + e] = lst_i[w * 1024 + e]; }
         if (lane < 32) floor_publish(a.gthr, seg.q_tile * HB_QT + myq, thr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // the ring and the lists are reused by the next segment
     }
 }
 
-hb_knn_fn hb_knn_bd_kernel() { return knn_fused_bd_kernel; }
+hb_knn_fn hb_knn_bd_kernel(bool wide) { return wide ? knn_fused_bd_kernel<true> : knn_fused_bd_kernel<false>; }
 int hb_knn_bd_lds_bytes() { return BD_LDS_TOTAL; }
