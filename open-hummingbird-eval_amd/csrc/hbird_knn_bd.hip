@@ -45,6 +45,11 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
     const int myq = w * 32 + (lane & 31);
     const unsigned lane_off = (unsigned)lane * 16u;
 
+#if defined(BD_PRIO) && BD_PRIO == 1
+    if (w >= 4) __builtin_amdgcn_s_setprio(1);   // experiments: static priority for the later-dispatched half
+#elif defined(BD_PRIO) && BD_PRIO == 2
+    if (w < 4) __builtin_amdgcn_s_setprio(1);    // ... or for the copy-issuing half
+#endif
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
     for (int si = seg_begin; si < seg_end; ++si) {
         const hb_seg seg = a.segs[si];

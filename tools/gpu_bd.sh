@@ -1,4 +1,4 @@
 #!/bin/bash
-HBIRD_KNN_VARIANT=3 python -m pytest tests/test_knn_gpu.py tests/test_configs_gpu.py -m gpu -x -q -k "not headline and not full_size" 2>&1 | tail -2
-python tools/exp_variant.py 5000000 768 21904 90 4,0
-python tools/exp_variant.py 5000000 768 21904 30 4,0
+python tools/exp_variant.py 5000000 768 21904 30 0
+for f in prio1 prio2; do HBIRD_HIP_LIB=$GRAFT_REPO_ROOT/open-hummingbird-eval_amd/lib/abl/libhbird_hip_$f.so python tools/exp_variant.py 5000000 768 21904 30 0 | sed "s/^/$f /"; done
+python tools/exp_variant.py 5000000 768 21904 30 0
