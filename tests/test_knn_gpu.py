@@ -344,6 +344,24 @@ def test_four_wave_kernel_variant_bit_exact(cuda_device, M, D, nq, k):
     _check_exact(idx, dist, q, bank, k, "dot_product")
 
 
+@pytest.mark.parametrize("variant", [3, 4])
+@pytest.mark.parametrize("M,D,nq,k,metric", [(5000, 64, 300, 30, "dot_product"), (20000, 384, 520, 30, "l2"), (7000, 96, 257, 5, "dot_product"),
+                                              (3000, 32, 100, 90, "dot_product"), (9000, 128, 300, 200, "l2"), (4000, 40, 64, 30, "dot_product")])
+def test_register_resident_query_fragment_kernel_bit_exact(cuda_device, variant, M, D, nq, k, metric):
+    """hb_index_set_variant(3) forces the big-search fp32 kernel (query fragments straight into registers, hbird_knn_bd.hip) on
+    any search it can run -- D padded to a multiple of 32; D = 40 pads to 40 and must fall back by itself --, 4 forbids it: either
+    way the oracle's bits, on the lists (k <= 32) and on the candidate pools (k > 32), with odd work-list splits."""
+    bank = gi.unit_bank(M, D, seed=1)
+    q = gi.vit_like_queries(nq, D, seed=2)
+    ix = HipFlatIndex(D, 0 if metric == "dot_product" else 1, 0)
+    ix.add(bank)
+    ix.set_variant(variant)
+    for G, panel in ((0, 0), (5, 2), (256, 1)):
+        ix.set_tuning(G, panel)
+        idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
+        _check_exact(idx, dist, q, bank, k, metric)
+
+
 def test_reference_named_backends(cuda_device):
     """hbird_mi.nn.search_faiss / search_scann carry the reference's class names and keyword surfaces."""
     from hbird_mi.nn.search_faiss import NearestNeighborSearchFaiss
