@@ -353,10 +353,16 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, floa
 
 template <int EMAX>
 __device__ __forceinline__ void pool_epilogue_scan(f32x16 (&acc)[8], float& thr, float* pool_s, unsigned* pool_i, float* sc, int qb,
-                                                   int lane, int k, unsigned bt, int klw, int* cnt) {
+                                                   int lane, int k, unsigned bt, int klw, int* cnt,
+                                                   unsigned long long* stamp_after_scan = nullptr /* diagnostic builds */) {
     float q0v = 0.f, q1v = 0.f, q2v = 0.f, q3v = 0.f;
     int q0c = 0, q1c = 0, q2c = 0, q3c = 0, np = 0;
     HB_SCAN_TILE(0) HB_SCAN_TILE(1) HB_SCAN_TILE(2) HB_SCAN_TILE(3) HB_SCAN_TILE(4) HB_SCAN_TILE(5) HB_SCAN_TILE(6) HB_SCAN_TILE(7)
+    if (stamp_after_scan) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(*stamp_after_scan) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
     if (__ballot(np != 0) == 0ull) return;
 #if defined(F16_ABL) && (F16_ABL & 512)
     asm volatile("" :: "v"(q0v), "v"(q1v), "v"(q2v), "v"(q3v), "v"(q0c), "v"(q1c), "v"(q2c), "v"(q3c));   // timing only: no drain

@@ -368,12 +368,25 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
             for (int t = 0; t < 8; ++t) fa[t] = A[(t * 2) * 64];
         }
         F2_INIT_TILE()
+#ifdef F2_STAMPS   // diagnostic build (make var NAME=stamps EXTRA=-DF2_STAMPS): where a tile boundary spends its cycles; never timed
+#define F2_STAMP(T) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+        unsigned long long ts_a = 0, ts_m = 0, ts_b = 0, ts_c = 0, ts_s = 0, ts_e = 0;
+        unsigned long long sum_scan = 0, sum_drain = 0, sum_init = 0, sum_bar_first = 0, sum_bar_other = 0, sum_all = 0;
+        int n_first = 0, n_other = 0, after_epi = 0;
+        unsigned long long ts_begin; F2_STAMP(ts_begin)
+#define F2_STAMP_STAGE_BEGIN(U) if ((U) == 0) F2_STAMP(ts_s)
+#define F2_STAMP_STAGE_BARRIER(U) if ((U) == 0) { F2_STAMP(ts_e) if (after_epi) { sum_bar_first += ts_e - ts_s; ++n_first; after_epi = 0; } else { sum_bar_other += ts_e - ts_s; ++n_other; } }
+#else
+#define F2_STAMP_STAGE_BEGIN(U)
+#define F2_STAMP_STAGE_BARRIER(U)
+#endif
 #define F2_MM(T, B) acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[T], B, acc[T], 0, 0, 0);
 #define F2_STAGE(U)                                                                                                          \
         {                                                                                                                    \
             const f16x8* Ac = reinterpret_cast<const f16x8*>(smem + slot_c * F2_SLOT) + lane;                                \
             const int slot_n = (slot_c + 1) & (F2_RING - 1);                                                                 \
             const f16x8* An = reinterpret_cast<const f16x8*>(smem + slot_n * F2_SLOT) + lane;                                \
+            F2_STAMP_STAGE_BEGIN(U)                                                                                          \
             /* group 0; filler after MFMA t: fragment t of group 1; B1 of the stage three ahead */                           \
             KN_FENCE F2_MM(0, bq[U][0]) KN_FENCE F2_RD(fa[0], Ac[(0 * 2 + 1) * 64]) F2_BL(bq[(U + 3) & 3][1], qsrc_b1, 1024, 0)  \
             KN_FENCE F2_MM(1, bq[U][0]) KN_FENCE F2_RD(fa[1], Ac[(1 * 2 + 1) * 64])                                          \
@@ -387,6 +400,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
             /* the next stage has landed: my requests (and my query fragments of it), then everyone's */                    \
             asm volatile("s_waitcnt vmcnt(8)" : "+v"(bq[(U + 1) & 3][0]), "+v"(bq[(U + 1) & 3][1]), "+v"(bq[U][1]) :: "memory"); \
             F2_BARRIER()   /* raw s_barrier: __syncthreads() would drain the LDS-DMA copies (vmcnt(0)) */                    \
+            F2_STAMP_STAGE_BARRIER(U)                                                                                        \
             /* group 1; filler after MFMA t: fragment t of the next stage's group 0; B0 C0 C1 of the stage four ahead */     \
             if (w == 0) cl_tick(cs, clock0 + st + (U), lane);   /* cluster soft sync, ahead of the stage's requests */       \
             KN_FENCE F2_MM(0, bq[U][1]) KN_FENCE F2_RD(fa[0], An[(0 * 2) * 64]) F2_BL(bq[U][0], F2_QSRC(), 0, 0)             \
@@ -409,6 +423,11 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
 #if defined(F16_ABL) && (F16_ABL & 1)
 #pragma unroll
                 for (int t = 0; t < 8; ++t) asm volatile("" :: "v"(acc[t]));   // timing only: no epilogue
+#elif defined(F2_STAMPS)
+                F2_STAMP(ts_a)
+                pool_epilogue_scan<EMAX>(acc, thr, wl_s, wl_i, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt, &ts_m);
+                F2_STAMP(ts_b)
+                sum_scan += ts_m - ts_a; sum_drain += ts_b - ts_m; after_epi = 1;
 #else
                 pool_epilogue_scan<EMAX>(acc, thr, wl_s, wl_i, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
 #endif
@@ -419,11 +438,26 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
 #pragma unroll
                     for (int t = 0; t < 8; ++t) fa[t] = A[(t * 2) * 64];
                 }
+#ifdef F2_STAMPS
+                F2_STAMP(ts_c)
+                sum_init += ts_c - ts_b;
+#endif
             }
         }
         // the run-ahead requests still target the query-fragment registers: drain them while those registers are live
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]), "+v"(bq[2][0]), "+v"(bq[2][1]),
                      "+v"(bq[3][0]), "+v"(bq[3][1]) :: "memory");
+#ifdef F2_STAMPS
+        { unsigned long long ts_end; F2_STAMP(ts_end) sum_all = ts_end - ts_begin; }
+        if ((blockIdx.x == 0 || blockIdx.x == 101) && lane == 0 && (w == 0 || w == 5) && (si - seg_begin) % 64 == 17)
+            printf("STAMPS wg %d wave %d tiles %d: segment %llu cycles; per tile: scan %llu drain %llu init+refetch %llu; stage begin -> barrier passed: "
+                   "after an epilogue %llu (n %d), otherwise %llu (n %d)\n", (int)blockIdx.x, w, seg.n_tiles, sum_all, sum_scan / seg.n_tiles,
+                   sum_drain / seg.n_tiles, sum_init / seg.n_tiles, n_first ? sum_bar_first / n_first : 0ull, n_first,
+                   n_other ? sum_bar_other / n_other : 0ull, n_other);
+#undef F2_STAMP
+#endif
+#undef F2_STAMP_STAGE_BEGIN
+#undef F2_STAMP_STAGE_BARRIER
 #undef F2_STAGE
 #undef F2_MM
 #undef F2_INIT_TILE
