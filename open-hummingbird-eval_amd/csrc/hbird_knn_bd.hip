@@ -55,20 +55,20 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
     for (int si = seg_begin; si < seg_end; ++si) {
         const hb_seg seg = a.segs[si];
-        const int klw = a.klw;
-        float* wl_s = a.state_s + (size_t)seg.slot * HB_QT * klw;
-        unsigned* wl_i = a.state_i + (size_t)seg.slot * HB_QT * klw;
+        // (arguments of the segment / tile boundaries come from the kernarg segment where they are used: HB_KARG)
         float thr;
         if constexpr (WIDE) {
-            thr = pool_begin(knn_args_pool_view{a.state_cnt, a.state_thr}, seg.slot, seg.first, pcnt, myq, lane);
+            thr = pool_begin(knn_args_pool_view{HB_KARG(knn_args, state_cnt), HB_KARG(knn_args, state_thr)}, seg.slot, seg.first, pcnt, myq, lane);
         } else {
+            const float* wl_s = HB_KARG(knn_args, state_s) + (size_t)seg.slot * HB_QT * HB_KL;
+            const unsigned* wl_i = HB_KARG(knn_args, state_i) + (size_t)seg.slot * HB_QT * HB_KL;
             for (int e = lane; e < 1024; e += 64) {
                 lst_s[w * 1024 + e] = seg.first ? -INFINITY : wl_s[w * 1024 + e];
                 lst_i[w * 1024 + e] = seg.first ? HB_ID_NONE : wl_i[w * 1024 + e];
             }
             thr = lst_s[myq * HB_KL + (k - 1)];
         }
-        thr = fmaxf(thr, floor_load(a.gthr, seg.q_tile * HB_QT + myq));
+        thr = fmaxf(thr, floor_load(HB_KARG(knn_args, gthr), seg.q_tile * HB_QT + myq));
         const char* qsrc = reinterpret_cast<const char*>(a.q_tiles + ((size_t)(seg.q_tile * 8 + w) * g8) * HB_BLK);
         const int total = seg.n_tiles * g8;
         f32x16 acc[8];
@@ -158,8 +158,16 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
             BD_STAGE(0) BD_STAGE(1) BD_STAGE(2) BD_STAGE(3)
             ks += 4;
             if (ks == g8) {
-                if constexpr (WIDE) tile_epilogue<true, true>(acc, thr, wl_s, wl_i, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
-                else tile_epilogue<true, false>(acc, thr, lst_s, lst_i, sc, w * 32, lane, k, (unsigned)bt);
+                if constexpr (WIDE) {
+                    // the slot's pool pointers are derived HERE from one laundered scalar (hbird_knn.hip: kept live through
+                    // the stage loop they push the loop's own pointers into spilled SGPRs, reloaded in every stage)
+                    int slot_ = seg.slot;
+                    asm volatile("" : "+s"(slot_));
+                    const int klw = HB_KARG(knn_args, klw);
+                    float* ps = HB_KARG(knn_args, state_s) + (size_t)slot_ * HB_QT * klw;
+                    unsigned* pi = HB_KARG(knn_args, state_i) + (size_t)slot_ * HB_QT * klw;
+                    tile_epilogue<true, true>(acc, thr, ps, pi, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
+                } else tile_epilogue<true, false>(acc, thr, lst_s, lst_i, sc, w * 32, lane, k, (unsigned)bt);
                 ks = 0;
                 ++bt;
             }
@@ -167,9 +175,13 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
 #undef BD_STAGE
         // the run-ahead requests still target the query-fragment registers: drain them while those registers are live
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) :: "memory");
-        if constexpr (WIDE) pool_end(knn_args_pool_view{a.state_cnt, a.state_thr}, seg.slot, pcnt, thr, myq, lane);
-        else for (int e = lane; e < 1024; e += 64) { wl_s[w * 1024 + e] = lst_s[w * 1024 + e]; wl_i[w * 1024 + e] = lst_i[w * 1024 + e]; }
-        if (lane < 32) floor_publish(a.gthr, seg.q_tile * HB_QT + myq, thr);
+        if constexpr (WIDE) pool_end(knn_args_pool_view{HB_KARG(knn_args, state_cnt), HB_KARG(knn_args, state_thr)}, seg.slot, pcnt, thr, myq, lane);
+        else {
+            float* wl_s = HB_KARG(knn_args, state_s) + (size_t)seg.slot * HB_QT * HB_KL;
+            unsigned* wl_i = HB_KARG(knn_args, state_i) + (size_t)seg.slot * HB_QT * HB_KL;
+            for (int e = lane; e < 1024; e += 64) { wl_s[w * 1024 + e] = lst_s[w * 1024 + e]; wl_i[w * 1024 + e] = lst_i[w * 1024 + e]; }
+        }
+        if (lane < 32) floor_publish(HB_KARG(knn_args, gthr), seg.q_tile * HB_QT + myq, thr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // the ring and the lists are reused by the next segment
     }

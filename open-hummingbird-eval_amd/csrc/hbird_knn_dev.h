@@ -30,6 +30,17 @@ struct knn_args {
     int* cl_stats;          // {checks, spins, timeouts} of the launch
 };
 
+// A kernel argument read again from the kernarg segment at the point of use (through a laundered pointer, so that the
+// compiler cannot keep it in an SGPR from the kernel's start): for arguments used only at segment / tile boundaries, which
+// would otherwise crowd the stage loop's own scalars into spills that are reloaded in every stage.
+#define HB_KARG(ARGS_T, FIELD) hb_karg<decltype(ARGS_T::FIELD)>(offsetof(ARGS_T, FIELD))
+template <class T>
+__device__ __forceinline__ T hb_karg(size_t offset) {
+    const char __attribute__((address_space(4)))* p = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *reinterpret_cast<const T __attribute__((address_space(4)))*>(p + offset);
+}
+
 // arguments of the fp16 candidate kernel (hbird_knn_f16.hip); the fields shared with knn_args mean the same
 struct knn16_args {
     const _Float16* bank16;   // fp16 copies of the bank fragment tiles

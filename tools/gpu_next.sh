@@ -1,4 +1,9 @@
 #!/bin/bash
 export TMPDIR=/tmp
-export EXP_CL=8,1,16
-HBIRD_HIP_LIB=$GRAFT_REPO_ROOT/open-hummingbird-eval_amd/lib/abl/libhbird_hip_stamps.so python tools/exp_f16_abl.py 10000000 768 21904 0 2>&1 | grep -E "STAMPS|cluster" | head -40
+timeout 900 python -m pytest tests/test_knn_gpu.py -m gpu -x -q -k "register_resident or wide or candidate_pool or k90 or random" 2>&1 | tail -2
+for r in 1 2; do
+HBIRD_HIP_LIB=$GRAFT_REPO_ROOT/open-hummingbird-eval_amd/lib/abl/libhbird_hip_prev.so python tools/exp_variant.py 5000000 768 21904 90 0 | sed "s/^/prev k90 /"
+python tools/exp_variant.py 5000000 768 21904 90 0 | sed "s/^/new  k90 /"
+done
+HBIRD_HIP_LIB=$GRAFT_REPO_ROOT/open-hummingbird-eval_amd/lib/abl/libhbird_hip_prev.so python tools/exp_variant.py 5000000 768 21904 30 0 | sed "s/^/prev k30 /"
+python tools/exp_variant.py 5000000 768 21904 30 0 | sed "s/^/new  k30 /"
