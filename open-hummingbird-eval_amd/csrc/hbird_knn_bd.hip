@@ -30,7 +30,21 @@
                  ".Lbdw_%=:\n\ts_waitcnt vmcnt(" #N_ISSUER ")\n.Lbdd_%=:"                                               \
                  : "+v"(B) : "s"(w) : "memory", "scc");
 #endif
+// timing-only ablation builds (results are garbage): make varu UNIT=hbird_knn_bd NAME=<tag> EXTRA=-DBD_ABL=<bits>
+//   1 no bank copies, 2 no query-fragment loads, 4 no epilogue, 8 no bank-fragment reads
+#ifndef BD_ABL
+#define BD_ABL 0
+#endif
+#if BD_ABL & 2
+#define BD_BLOAD(B) asm volatile("" : "+v"(B));
+#else
 #define BD_BLOAD(B) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(B) : "v"(lane_off), "s"(qsrc + (size_t)fks * 1024) : "memory");
+#endif
+#if BD_ABL & 8
+#define BD_RD(DST, SRC) asm volatile("" : "+v"(DST));
+#else
+#define BD_RD(DST, SRC) DST = SRC;
+#endif
 
 template <bool WIDE>   // WIDE: k > HB_KL, candidate pools in global memory (as in hbird_knn.hip)
 __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a) {
@@ -81,7 +95,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
             const float* src = a.bank_tiles + ((size_t)(bt * 8 + w) * g8 + ks) * HB_BLK + lane * 4;
             glds16(src, smem + slot * BD_SLOT + w * 1024);
 #else
-            if (w < 4) {
+            if (w < 4 && !(BD_ABL & 1)) {
                 const float* src = a.bank_tiles + ((size_t)(bt * 8 + w) * g8 + ks) * HB_BLK + lane * 4;
                 glds16(src, smem + slot * BD_SLOT + w * 1024);
                 glds16(src + (size_t)4 * g8 * HB_BLK, smem + slot * BD_SLOT + (w + 4) * 1024);
@@ -119,10 +133,10 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
             const f32x4* Ac = reinterpret_cast<const f32x4*>(smem + slot_c * BD_SLOT) + lane;                           \
             const f32x4* An = reinterpret_cast<const f32x4*>(smem + slot_n * BD_SLOT) + lane;                           \
             /* X half: tiles 0-3, k-steps 0-3; fillers: the four Y fragments, the copies, the query fragment of st + 3 */ \
-            KN_FENCE BD_MFMA(0, fa, bq[U], 0) KN_FENCE fy[0] = Ac[4 * 64];                                              \
-            KN_FENCE BD_MFMA(1, fa, bq[U], 0) KN_FENCE fy[1] = Ac[5 * 64];                                              \
-            KN_FENCE BD_MFMA(2, fa, bq[U], 0) KN_FENCE fy[2] = Ac[6 * 64];                                              \
-            KN_FENCE BD_MFMA(3, fa, bq[U], 0) KN_FENCE fy[3] = Ac[7 * 64];                                              \
+            KN_FENCE BD_MFMA(0, fa, bq[U], 0) KN_FENCE BD_RD(fy[0], Ac[4 * 64])                                              \
+            KN_FENCE BD_MFMA(1, fa, bq[U], 0) KN_FENCE BD_RD(fy[1], Ac[5 * 64])                                              \
+            KN_FENCE BD_MFMA(2, fa, bq[U], 0) KN_FENCE BD_RD(fy[2], Ac[6 * 64])                                              \
+            KN_FENCE BD_MFMA(3, fa, bq[U], 0) KN_FENCE BD_RD(fy[3], Ac[7 * 64])                                              \
             KN_FENCE BD_MFMA(0, fa, bq[U], 1) BD_MFMA(1, fa, bq[U], 1) KN_FENCE                                         \
             issue_a(fbt, fks, slot_f);                                                                                  \
             KN_FENCE BD_MFMA(2, fa, bq[U], 1) BD_MFMA(3, fa, bq[U], 1) BD_MFMA(0, fa, bq[U], 2) BD_MFMA(1, fa, bq[U], 2) KN_FENCE \
@@ -131,10 +145,10 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
             advance_fetch();                                                                                            \
             KN_FENCE BD_MFMA(0, fa, bq[U], 3) BD_MFMA(1, fa, bq[U], 3) BD_MFMA(2, fa, bq[U], 3) BD_MFMA(3, fa, bq[U], 3) KN_FENCE \
             /* Y half: tiles 4-7; fillers: the X fragments of stage st + 1 */                                           \
-            KN_FENCE BD_MFMA(4, fy, bq[U], 0) KN_FENCE fa[0] = An[0 * 64];                                              \
-            KN_FENCE BD_MFMA(5, fy, bq[U], 0) KN_FENCE fa[1] = An[1 * 64];                                              \
-            KN_FENCE BD_MFMA(6, fy, bq[U], 0) KN_FENCE fa[2] = An[2 * 64];                                              \
-            KN_FENCE BD_MFMA(7, fy, bq[U], 0) KN_FENCE fa[3] = An[3 * 64];                                              \
+            KN_FENCE BD_MFMA(4, fy, bq[U], 0) KN_FENCE BD_RD(fa[0], An[0 * 64])                                              \
+            KN_FENCE BD_MFMA(5, fy, bq[U], 0) KN_FENCE BD_RD(fa[1], An[1 * 64])                                              \
+            KN_FENCE BD_MFMA(6, fy, bq[U], 0) KN_FENCE BD_RD(fa[2], An[2 * 64])                                              \
+            KN_FENCE BD_MFMA(7, fy, bq[U], 0) KN_FENCE BD_RD(fa[3], An[3 * 64])                                              \
             KN_FENCE                                                                                                    \
             BD_MFMA(4, fy, bq[U], 1) BD_MFMA(5, fy, bq[U], 1) BD_MFMA(6, fy, bq[U], 1) BD_MFMA(7, fy, bq[U], 1)         \
             BD_MFMA(4, fy, bq[U], 2) BD_MFMA(5, fy, bq[U], 2) BD_MFMA(6, fy, bq[U], 2) BD_MFMA(7, fy, bq[U], 2)         \
@@ -158,7 +172,10 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
             BD_STAGE(0) BD_STAGE(1) BD_STAGE(2) BD_STAGE(3)
             ks += 4;
             if (ks == g8) {
-                if constexpr (WIDE) {
+                if constexpr (BD_ABL & 4) {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) asm volatile("" :: "v"(acc[t]));
+                } else if constexpr (WIDE) {
                     // the slot's pool pointers are derived HERE from one laundered scalar (hbird_knn.hip: kept live through
                     // the stage loop they push the loop's own pointers into spilled SGPRs, reloaded in every stage)
                     int slot_ = seg.slot;
