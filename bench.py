@@ -425,6 +425,22 @@ def main():
                             ", exposed after the kNN kernel (it owns every CU's registers, nothing can run beside it)"),
                 "packed_list_bytes_per_rank": ex[0].part_bytes,
             }
+        if world == 1 and not dist_on and not a.fp16 and tuple(index.schedule_info().get("cluster", (1, 1))) != (1, 1):
+            # extra, not the headline: the timed steps ran with the automatic L2-sharing clusters (the biggest searches:
+            # -60 % fabric reads for under 1 % of kernel time); the same step without them, so that the price is on the line
+            cl_auto = tuple(index.schedule_info()["cluster"])
+            index.set_cluster(1, 1, 0)
+            index.search_aggregate(q, k, beta=0.02); torch.cuda.synchronize(device)
+            index.set_timing(True)
+            kms_off = []
+            for _ in range(3):
+                index.search_aggregate(q, k, beta=0.02)
+                kms_off.append(index.last_knn_ms())
+            index.set_timing(False)
+            index.set_cluster(0, 0, -1)
+            res["without_clusters"] = {"cluster_in_timed_steps": list(cl_auto), "avg_kernel_ms": float(np.mean(kms_off)),
+                                       "frac": flops / (float(np.mean(kms_off)) * 1e-3) / 1e12 / peak,
+                                       "note": "hb_index_set_cluster(ix, 1, 1, 0); same outputs; roofline.traffic is of the timed (clustered) kernel"}
         if world == 1 and not dist_on and not a.fp16:
             # extra, not the headline: the same step in use_fp16 mode (fp16 candidate pass + certified exact fp32
             # re-rank; returns the identical bits)

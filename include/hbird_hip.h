@@ -161,8 +161,9 @@ int hb_index_schedule_info(const hb_index_t* ix, int64_t out[8]);
 /* L2-sharing clusters of the kNN work list (speed only; results never depend on it): cluster_q x cluster_b workgroups
  * of one XCD walk (cluster_q query tiles) x (cluster_b interleaved bank tiles) in lockstep, so that one L2 fill serves
  * several workgroups.  0 x 0 = automatic (the fp16 candidate kernel of big searches: 8 x 1, or 4 x 2 / 2 x 2 when that
- * idles fewer pairs; the fp32 kernel: off -- it is bound by the matrix pipe), 1 x 1 = off, q x b with
- * q * b <= 8 otherwise.  sync_lag: stages a member may run ahead of the slowest one before it waits (-1 = 16, 0 = never). */
+ * idles fewer pairs; the fp32 kernel: 2 x 4 or 2 x 2, only from one million k8 stages per workgroup up -- it is bound by
+ * the matrix pipe, clusters cut its fabric reads by 60 % for under 1 % of time there and cost more on smaller searches,
+ * DESIGN.md), 1 x 1 = off, q x b with q * b <= 8 otherwise.  sync_lag: stages a member may run ahead of the slowest one before it waits (-1 = 16, 0 = never). */
 int hb_index_set_cluster(hb_index_t* ix, int cluster_q, int cluster_b, int sync_lag);
 /* Soft-sync statistics of the last clustered search (synchronises the stream): out[0] = progress checks, [1] = waits
  * (re-polls while a member was behind), [2] = members that gave up waiting (bounded spin); zeros without clusters. */
@@ -170,7 +171,7 @@ int hb_index_cluster_stats(hb_index_t* ix, int64_t out[4]);
 
 /* Host-only (no GPU needed): the work list the kNN kernel would run for nqt query tiles (256 rows) x nbt bank tiles
  * (256 rows) on `workgroups` workgroups; panel_tiles = 0 selects the automatic panel; cluster_q / cluster_b as in
- * hb_index_set_cluster (negative = automatic).  segs_out (may be NULL) receives up to max_segs rows {block, q_tile,
+ * hb_index_set_cluster (-1 = the fp16 candidate kernel's automatic shape, -2 = the fp32 kernel's).  segs_out (may be NULL) receives up to max_segs rows {block, q_tile,
  * b_tile0, n_tiles, slot, first, tile stride, cluster clock at the first tile, cluster clock of the block's next segment,
  * progress word of the block (-1: no cluster)}; stats as hb_index_schedule_info. */
 int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b, int* segs_out,

@@ -144,7 +144,7 @@ extern "C" int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tile
     const int dp = (d + HB_KC - 1) / HB_KC * HB_KC;
     const int G = (int)std::min<long long>(workgroups, (long long)nqt * nbt);
     int cq = cluster_q, cb = cluster_b;
-    if (cq < 0 || cb < 0) hb_default_cluster(nqt, nbt, G, &cq, &cb);           // negative: the automatic shape
+    if (cq < 0 || cb < 0) hb_default_cluster(nqt, nbt, G, cq == -2, &cq, &cb);  // negative: the automatic shape (-1 fp16, -2 fp32 kernel)
     if (cq < 1 || cb < 1 || (long long)nqt * nbt < workgroups || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
     const int panel = panel_tiles > 0 ? panel_tiles : hb_default_panel(nqt, G, (size_t)HB_BT * dp * 4, cq, cb);
     hb_schedule sc;

@@ -62,7 +62,7 @@ struct hb_schedule {
 void hb_build_schedule(int nqt, int nbt, int G, int panel_tiles, hb_schedule& out, int cq = 1, int cb = 1);
 int hb_default_panel(int nqt, int G, size_t tile_bytes, int cq = 1, int cb = 1);
 // automatic cluster shape for a search (1 x 1 when clusters do not apply)
-void hb_default_cluster(int nqt, int nbt, int G, int* cq, int* cb);
+void hb_default_cluster(int nqt, int nbt, int G, bool fp32_kernel, int* cq, int* cb);
 
 struct hb_index {
     int d = 0, dp = 0, g8 = 0, metric = 0, device = 0;

@@ -437,13 +437,16 @@ int hb_default_panel(int nqt, int G, size_t tile_bytes, int cq, int cb) {
 // fill serves cq (bank) or cb (query) consumers, fabric traffic per pair drops from Q + B to Q / cb + B / cq.  The
 // members hold each other within a few stages through the progress words (soft sync in the kernels); placement and
 // lockstep are speed only, any schedule gives the same result.
-void hb_default_cluster(int nqt, int nbt, int G, int* cq, int* cb) {
-    // The widest query way whose ragged last group idles at most 2.5 % of the pairs: 8 x 1 (eight workgroups stream the
-    // same bank tiles: measured best on the fp16 candidate kernel, 10 M x 768), else 4 x 2, else 2 x 2, else none.
+void hb_default_cluster(int nqt, int nbt, int G, bool fp32_kernel, int* cq, int* cb) {
+    // The first shape whose ragged last group idles at most 2.5 % of the pairs.  fp16 candidate kernel: 8 x 1 (eight
+    // workgroups stream the same bank tiles: measured best at 10 M x 768), else 4 x 2, else 2 x 2, else none.  fp32 kernel
+    // (bound by the matrix pipe, so only the cheapest sharing pays): 2 x 4, else 2 x 2 -- at 10 M x 768 fabric reads
+    // 4.79 -> 1.93 TB for +0.5 % time; 4 x 2 and 8 x 1 cost 3 %.
     *cq = 1; *cb = 1;
     if ((long long)nqt * nbt < 64LL * G) return;                 // enough work to share
-    static const int shapes[3][2] = {{8, 1}, {4, 2}, {2, 2}};
-    for (const auto& sh : shapes) {
+    static const int shapes16[3][2] = {{8, 1}, {4, 2}, {2, 2}};
+    static const int shapes32[3][2] = {{2, 4}, {2, 2}, {2, 2}};
+    for (const auto& sh : fp32_kernel ? shapes32 : shapes16) {
         const int q = sh[0], b = sh[1];
         if (G % (8 * q * b) != 0 || nqt < q) continue;
         const int padded = (nqt + q - 1) / q * q;
@@ -606,13 +609,23 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     }
     const int G = ix->force_G > 0 ? ix->force_G : ix->num_cu;
     const size_t tile_bytes = (size_t)HB_BT * ix->dp * 4;
-    // L2-sharing clusters are opt-in (hb_index_set_cluster): measured on 10 M x 768 they raise the L2 hit rate from 12 %
-    // to 20 % (2 x 2, any lag the cheap sync can hold) for +0.3 % kernel time, and to 53 % / -46 % fabric reads only with a
-    // per-stage exchange that costs 1.5-5 % -- the fp32 kernel is bound by the matrix pipe and the fp16 candidate kernel by
-    // its LDS traffic, neither by the fabric (profiles/r02).  The 4-wave variant does not know strided segments.
+    // L2-sharing clusters (hb_index_set_cluster; automatic shapes below): q x b workgroups of one XCD walk the same bank /
+    // query tiles within `lag` stages of each other, so one L2 fill serves several.  Neither kernel is bound by the fabric
+    // (the fp32 one by the matrix pipe, the fp16 candidate kernel by its LDS-DMA copies and the power the chip grants it:
+    // DESIGN.md, profiles/r02), so what they buy is traffic, and time only for the fp16 kernel (-8 %).  The 4-wave variant
+    // does not know strided segments.
     int cq = 1, cb = 1;
     if (ix->force_cq > 0 && ix->force_cb > 0) { cq = ix->force_cq; cb = ix->force_cb; }
-    else if (f16 && ix->variant == 0 && ix->force_cq == 0) hb_default_cluster(nqt, nbt, G, &cq, &cb);   // fp16 second design: -8 %
+    else if (f16 && ix->variant == 0 && ix->force_cq == 0) hb_default_cluster(nqt, nbt, G, false, &cq, &cb);   // fp16 second design: -8 %
+    // fp32: only beside the kernel with register-resident query fragments (its sync is free of spills), and only for the
+    // biggest searches: 2 x 4 clusters cut the fabric reads by 60 % (10 M x 768: 4.79 -> 1.93 TB per search, L2 hit rate
+    // 10 % -> 63 %) but the kernel is bound by the matrix pipe, so all they can do for the time is cost little -- measured
+    // (same box, kernel ms, none vs 2 x 4): 10 M x 768 2280 vs 2298 (+0.8 %), 5 M x 1024 1528 vs 1531 (+0.2 %), but
+    // 1.25 M x 768 289.3 vs 293.9 (+1.6 %), 2 M x 384 142.3 vs 146.4 (+2.9 %): more slots, shorter segments.  Automatic from
+    // one million stages per workgroup up (8 M rows at D = 768); hb_index_set_cluster(ix, 1, 1, 0) turns them off, (ix, 2, 4, -1) forces them.
+    else if (!f16 && !wide && ix->variant == 0 && ix->force_cq == 0 && !ix->ablate && ix->g8 % 4 == 0 &&
+             (long long)nqt * nbt / std::max(1, G) * ix->g8 >= 1000000)
+        hb_default_cluster(nqt, nbt, G, true, &cq, &cb);
     if (ix->variant == 1 || (long long)nqt * nbt < G || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
     const int panel = ix->force_panel > 0 ? ix->force_panel
                                           : hb_default_panel(nqt, std::min<long long>(G, (long long)nqt * nbt), tile_bytes, cq, cb);
@@ -768,7 +781,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // stages per workgroup below which the small-search instantiation wins: against the kernel with register-resident
     // query fragments (below) the crossover is near 16 k stages (300 k x 768: 72.7 vs 73.9 ms; 200 k x 384: 17.6 vs 15.8 ms),
     // against the LDS-staged kernel (shapes the other one does not serve) near 400 k
-    const bool bd_shape = a.cl == 1 && ix->g8 % 4 == 0 && !ix->ablate && ix->variant != 4;
+    const bool bd_shape = ix->g8 % 4 == 0 && !ix->ablate && ix->variant != 4;
     const long long cold_limit = bd_shape ? 16000 : 400000;
     if (!wide && a.cl == 1 && (long long)nqt * nbt / std::max(1, sc.G) * ix->g8 < cold_limit) fn = cold_fn;
     if (!wide && ix->ablate)
@@ -782,8 +795,8 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // The query fragments straight into registers (hbird_knn_bd.hip): -3.8 % kernel time at 10 M x 768 (0.895 -> 0.93 of the
     // fp32 MFMA peak), same bits.  Default for the big LDS-list searches whose stage count per tile is a multiple of four
     // (D = 384, 768, 1024, ...); variant 3 forces it wherever it applies (tests), variant 4 keeps the LDS-staged kernel.
-    if (bd_shape && ((ix->variant == 0 && fn == variants[wide ? 1 : 0]) || ix->variant == 3)) {
-        fn = hb_knn_bd_kernel(wide);
+    if (bd_shape && ((ix->variant == 0 && fn != cold_fn) || ix->variant == 3)) {
+        fn = hb_knn_bd_kernel(wide, a.cl > 1);
         lds_bytes = hb_knn_bd_lds_bytes();
     }
     if (hb_ensure_dyn_lds((const void*)fn, lds_bytes)) return -1;   // per (kernel, device)

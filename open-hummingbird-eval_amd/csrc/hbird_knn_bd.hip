@@ -17,7 +17,8 @@
 #define BD_BINIT (BD_RING * BD_SLOT)        // 2 x 1 KiB
 #define BD_LISTS (BD_BINIT + 2048)
 #define BD_SCRATCH (BD_LISTS + 2 * HB_QT * HB_KL * 4)
-#define BD_LDS_TOTAL (BD_SCRATCH + 8192)
+#define BD_CLWORDS (BD_SCRATCH + 8192)       // landing zone of the cluster progress poll
+#define BD_LDS_TOTAL (BD_CLWORDS + 64)
 
 #define BD_MFMA(T, FR, B, S) acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(FR[(T) & 3][S], B[S], acc[T], 0, 0, 0);
 // the two wave classes have different numbers of requests in flight: ONE statement with the branch inside, so that the
@@ -46,7 +47,9 @@
 #define BD_RD(DST, SRC) DST = SRC;
 #endif
 
-template <bool WIDE>   // WIDE: k > HB_KL, candidate pools in global memory (as in hbird_knn.hip)
+// WIDE: k > HB_KL, candidate pools in global memory; CL: member of an L2-sharing cluster (strided segments on a common
+// clock, soft sync from wave 0) -- both as in hbird_knn.hip
+template <bool WIDE, bool CL>
 __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -60,6 +63,8 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
     const int g8 = a.g8, k = a.k;
     const int myq = w * 32 + (lane & 31);
     const unsigned lane_off = (unsigned)lane * 16u;
+    cl_sync cs;
+    if constexpr (CL) cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + BD_CLWORDS);
 
 #if defined(BD_PRIO) && BD_PRIO == 1
     if (w >= 4) __builtin_amdgcn_s_setprio(1);   // experiments: static priority for the later-dispatched half
@@ -67,8 +72,11 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
     if (w < 4) __builtin_amdgcn_s_setprio(1);    // ... or for the copy-issuing half
 #endif
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
+    // "everything before my first segment is done" (a member without any work: everything)
+    if constexpr (CL) { if (w == 0) cl_publish(cs, seg_begin < seg_end ? a.segs[seg_begin].tile0 * g8 : 0x7FFFFFFF, lane); }
     for (int si = seg_begin; si < seg_end; ++si) {
         const hb_seg seg = a.segs[si];
+        const int bstride = CL ? seg.stride : 1, clock0 = CL ? seg.tile0 * g8 : 0;
         // (arguments of the segment / tile boundaries come from the kernarg segment where they are used: HB_KARG)
         float thr;
         if constexpr (WIDE) {
@@ -105,9 +113,10 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
         int bt = seg.b_tile0, ks = 0;          // tile / stage being computed
         int fbt = seg.b_tile0, fks = 0;        // next stage to fetch
         int slot_c = 0, slot_f = 0, left = total;
+        int fpar = 0, cpar = 0;                // row-init double buffer: parity of the tile being fetched / computed
         auto advance_fetch = [&]() {
-            if (fks == 0 && w == 0) glds16(a.binit + (size_t)fbt * HB_BT + lane * 4, smem + BD_BINIT + (fbt & 1) * 1024);
-            if (--left > 0) { if (++fks == g8) { fks = 0; ++fbt; } }
+            if (fks == 0 && w == 0) glds16(a.binit + (size_t)fbt * HB_BT + lane * 4, smem + BD_BINIT + fpar * 1024);
+            if (--left > 0) { if (++fks == g8) { fks = 0; fbt += bstride; fpar ^= 1; } }
             if (++slot_f == BD_RING) slot_f = 0;
         };
         // vmcnt by hand.  Per stage a wave requests, in this order: (waves 0-3) two bank pieces, then its query fragment
@@ -138,6 +147,8 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
             KN_FENCE BD_MFMA(2, fa, bq[U], 0) KN_FENCE BD_RD(fy[2], Ac[6 * 64])                                              \
             KN_FENCE BD_MFMA(3, fa, bq[U], 0) KN_FENCE BD_RD(fy[3], Ac[7 * 64])                                              \
             KN_FENCE BD_MFMA(0, fa, bq[U], 1) BD_MFMA(1, fa, bq[U], 1) KN_FENCE                                         \
+            /* cluster soft sync (acts every 4th stage; the clock is a multiple of 4 at U == 0), AHEAD of the stage's requests */ \
+            if constexpr (CL && (U) == 0) { if (w == 0) cl_tick(cs, clock0 + st, lane); }                               \
             issue_a(fbt, fks, slot_f);                                                                                  \
             KN_FENCE BD_MFMA(2, fa, bq[U], 1) BD_MFMA(3, fa, bq[U], 1) BD_MFMA(0, fa, bq[U], 2) BD_MFMA(1, fa, bq[U], 2) KN_FENCE \
             BD_BLOAD(bq[((U) + 3) & 3])                                                                                 \
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
         for (int st = 0; st < total; st += 4) {
             if (ks == 0) {   // accumulators start from the bank rows' init values (landed with the tile's first stage)
                 // the init values of this tile were published by an earlier barrier (they ride with the tile's first stage)
-                const f32x4* bi = reinterpret_cast<const f32x4*>(smem + BD_BINIT + (bt & 1) * 1024);
+                const f32x4* bi = reinterpret_cast<const f32x4*>(smem + BD_BINIT + cpar * 1024);
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -186,12 +197,13 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
                     tile_epilogue<true, true>(acc, thr, ps, pi, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
                 } else tile_epilogue<true, false>(acc, thr, lst_s, lst_i, sc, w * 32, lane, k, (unsigned)bt);
                 ks = 0;
-                ++bt;
+                bt += bstride; cpar ^= 1;
             }
         }
 #undef BD_STAGE
         // the run-ahead requests still target the query-fragment registers: drain them while those registers are live
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) :: "memory");
+        if constexpr (CL) { if (w == 0) cl_publish(cs, seg.next_tile0 == 0x7FFFFFFF ? 0x7FFFFFFF : seg.next_tile0 * g8, lane); }   // covers idle units
         if constexpr (WIDE) pool_end(knn_args_pool_view{HB_KARG(knn_args, state_cnt), HB_KARG(knn_args, state_thr)}, seg.slot, pcnt, thr, myq, lane);
         else {
             float* wl_s = HB_KARG(knn_args, state_s) + (size_t)seg.slot * HB_QT * HB_KL;
@@ -202,7 +214,11 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // the ring and the lists are reused by the next segment
     }
+    if constexpr (CL) cl_finish(cs, a.cl_stats, w == 0, lane);
 }
 
-hb_knn_fn hb_knn_bd_kernel(bool wide) { return wide ? knn_fused_bd_kernel<true> : knn_fused_bd_kernel<false>; }
+hb_knn_fn hb_knn_bd_kernel(bool wide, bool clustered) {
+    if (clustered) return wide ? knn_fused_bd_kernel<true, true> : knn_fused_bd_kernel<false, true>;
+    return wide ? knn_fused_bd_kernel<true, false> : knn_fused_bd_kernel<false, false>;
+}
 int hb_knn_bd_lds_bytes() { return BD_LDS_TOTAL; }

@@ -544,5 +544,5 @@ __device__ __forceinline__ float cold_start_threshold(const f32x16 (&acc)[8], in
 
 typedef void (*hb_knn_fn)(knn_args);
 hb_knn_fn hb_knn_w4_kernel(bool wide);   // 4-wave (one wave per SIMD) variant, hbird_knn_w4.hip
-hb_knn_fn hb_knn_bd_kernel(bool wide);   // query fragments straight into registers, hbird_knn_bd.hip
+hb_knn_fn hb_knn_bd_kernel(bool wide, bool clustered);   // query fragments straight into registers, hbird_knn_bd.hip
 int hb_knn_bd_lds_bytes();

@@ -144,6 +144,10 @@ def test_automatic_cluster_shape():
     for nqt, nbt, G, want in ((86, 39063, 256, (8, 1)), (49, 8102, 256, (2, 2)), (48, 8102, 256, (8, 1)), (52, 8102, 256, (4, 2)),
                               (51, 8102, 256, (4, 2)), (1, 100000, 256, (1, 1)), (86, 100, 256, (1, 1)), (86, 39063, 104, (1, 1)), (86, 39063, 32, (2, 2))):
         assert plan(nqt, nbt, G, 0, cluster=(-1, -1))[1]["cluster"] == want, (nqt, nbt, G)
+    # the fp32 kernel's automatic shape (cluster_q = -2): 2 x 4, else 2 x 2
+    for nqt, nbt, G, want in ((86, 39063, 256, (2, 4)), (49, 8102, 256, (2, 4)), (86, 4883, 256, (2, 4)), (1, 100000, 256, (1, 1)),
+                              (86, 100, 256, (1, 1)), (86, 39063, 32, (2, 2)), (86, 39063, 104, (1, 1))):
+        assert plan(nqt, nbt, G, 0, cluster=(-2, -2))[1]["cluster"] == want, (nqt, nbt, G)
 
 
 def test_headline_clustered_plan_numbers():
