@@ -18,6 +18,11 @@
 #define BD_LISTS (BD_BINIT + 2048)
 #define BD_SCRATCH (BD_LISTS + 2 * HB_QT * HB_KL * 4)
 #define BD_CLWORDS (BD_SCRATCH + 8192)       // landing zone of the cluster progress poll
+// Stages between two looks at the other cluster members.  Measured at 10 M x 768, 2 x 4, lag 16 (kernel ms over no clusters /
+// FETCH_SIZE x 2): every 16 stages +1.3 %, 32: +0.9 % / 1.93 TB, 64: +0.8 %, 128: +0.3 % / 1.97 TB, 256: +0.4 % / 2.12 TB.
+#ifndef BD_CL_PERIOD
+#define BD_CL_PERIOD 128
+#endif
 #define BD_LDS_TOTAL (BD_CLWORDS + 64)
 
 #define BD_MFMA(T, FR, B, S) acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(FR[(T) & 3][S], B[S], acc[T], 0, 0, 0);
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
             KN_FENCE BD_MFMA(3, fa, bq[U], 0) KN_FENCE BD_RD(fy[3], Ac[7 * 64])                                              \
             KN_FENCE BD_MFMA(0, fa, bq[U], 1) BD_MFMA(1, fa, bq[U], 1) KN_FENCE                                         \
             /* cluster soft sync (acts every 4th stage; the clock is a multiple of 4 at U == 0), AHEAD of the stage's requests */ \
-            if constexpr (CL && (U) == 0) { if (w == 0) cl_tick(cs, clock0 + st, lane); }                               \
+            if constexpr (CL && (U) == 0) { if (w == 0) cl_tick<BD_CL_PERIOD>(cs, clock0 + st, lane); }                 \
             issue_a(fbt, fks, slot_f);                                                                                  \
             KN_FENCE BD_MFMA(2, fa, bq[U], 1) BD_MFMA(3, fa, bq[U], 1) BD_MFMA(0, fa, bq[U], 2) BD_MFMA(1, fa, bq[U], 2) KN_FENCE \
             BD_BLOAD(bq[((U) + 3) & 3])                                                                                 \

@@ -80,7 +80,9 @@ struct knn16_args {
 //    its SIMD partner stalled together idle the matrix pipe.  Issued by wave 0, which already pays that price for its
 //    copies and whose partner covers it, AHEAD of the stage's copies (so that the hand-counted vmcnt still holds):
 //    +1.9 % without any sharing, +0.3 % net with it.
+#ifndef HB_CL_PERIOD
 #define HB_CL_PERIOD 32
+#endif
 #ifndef HB_CL_SPINS
 #define HB_CL_SPINS 1024    // re-polls before a member gives up waiting (each about 0.5-1 us)
 #endif
@@ -106,10 +108,11 @@ __device__ __forceinline__ int cl_min_landed(const cl_sync& cs, int lane, bool w
     return __builtin_amdgcn_readfirstlane(m);
 }
 // Called by wave 0, once per stage (acts every 4th), ahead of the stage's copies.
+template <int PERIOD = HB_CL_PERIOD>   // stages between two looks at the other members (a power of two >= 16)
 __device__ __forceinline__ void cl_tick(cl_sync& cs, int now, int lane) {
     if (!cs.on || (now & 3) != 0) return;
     if (lane == 0) cl_store(cs.line + cs.me * HB_CLUSTER_LINE, now);
-    const int ph = now & (HB_CL_PERIOD - 1);
+    const int ph = now & (PERIOD - 1);
     if (ph == 4) cl_poll(cs, lane);
     else if (ph == 12) {
         // the poll was issued two exchanges ago, ahead of that stage's copies: the per-stage vmcnt wait has covered it

@@ -1,12 +1,8 @@
 #!/bin/bash
 export TMPDIR=/tmp
-OUT=gpurun_out/r2final4; mkdir -p $OUT
-python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; tail -2 $OUT/pytest.log
-python bench.py --steps 10 --warmup 3 > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
-python bench.py --rows 5000000 --steps 5 --warmup 2 --no-cpu-baseline --no-traffic > $OUT/bench_shard_5000000.json 2>/dev/null
-python - <<'PY'
-import json
-for n in ("default", "shard_5000000"):
-    r = json.load(open(f"gpurun_out/r2final4/bench_{n}.json")); u = r.get("use_fp16_mode") or {}
-    print(n, round(r["value"]), round(r["ms_per_step"], 1), round(r["roofline"]["frac"], 4), r["roofline"]["kernel"], r["roofline"]["traffic"], r["config"]["schedule"].get("cluster"), r.get("without_clusters"), "| fp16", round(u.get("value", 0)), round(u.get("ms_per_step", 0), 1))
-PY
+timeout 900 python -m pytest tests/test_knn_gpu.py -m gpu -x -q -k "cluster" 2>&1 | tail -1
+EXP_MODES=f32 EXP_ROUNDS=3 EXP_CFGS="1,1,0;0,0,-1" python tools/exp_cluster.py | sed "s/^/final /"
+export EXP_CL=8,1,16
+python tools/exp_f16_abl.py 10000000 768 21904 0 | tail -1
+for f in f16p64 f16p128; do HBIRD_HIP_LIB=$GRAFT_REPO_ROOT/open-hummingbird-eval_amd/lib/abl/libhbird_hip_$f.so python tools/exp_f16_abl.py 10000000 768 21904 0 | tail -1; done
+python tools/exp_f16_abl.py 10000000 768 21904 0 | tail -1
