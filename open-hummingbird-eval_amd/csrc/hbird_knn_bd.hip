@@ -139,6 +139,30 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
 #pragma unroll
             for (int t = 0; t < 4; ++t) fa[t] = A[t * 64 + lane];
         }
+        // where in the stage the requests are issued (experiments: -DBD_PLACE=1 query fragment in the Y half, 2 the bank pieces
+        // and the query fragment in the Y half; 5 M x 768, same box: 1149 / 1147 / 1161 ms -- no gain, the X half it is)
+#ifndef BD_PLACE
+#define BD_PLACE 0
+#endif
+#if BD_PLACE == 0
+#define BD_REQ_X1 issue_a(fbt, fks, slot_f);
+#define BD_REQ_X2(U) BD_BLOAD(bq[((U) + 3) & 3])
+#define BD_REQ_X3 advance_fetch();
+#define BD_REQ_Y1(U)
+#define BD_REQ_Y2
+#elif BD_PLACE == 1
+#define BD_REQ_X1 issue_a(fbt, fks, slot_f);
+#define BD_REQ_X2(U)
+#define BD_REQ_X3
+#define BD_REQ_Y1(U) BD_BLOAD(bq[((U) + 3) & 3])
+#define BD_REQ_Y2 advance_fetch();
+#else
+#define BD_REQ_X1
+#define BD_REQ_X2(U)
+#define BD_REQ_X3
+#define BD_REQ_Y1(U) issue_a(fbt, fks, slot_f); BD_BLOAD(bq[((U) + 3) & 3])
+#define BD_REQ_Y2 advance_fetch();
+#endif
 #define BD_STAGE(U)                                                                                                     \
         {                                                                                                               \
             BD_WAIT(3, 1, bq[((U) + 1) & 3])   /* stage st + 1 has landed for me (st + 2 in flight) ... */              \
@@ -154,11 +178,11 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
             KN_FENCE BD_MFMA(0, fa, bq[U], 1) BD_MFMA(1, fa, bq[U], 1) KN_FENCE                                         \
             /* cluster soft sync (acts every 4th stage; the clock is a multiple of 4 at U == 0), AHEAD of the stage's requests */ \
             if constexpr (CL && (U) == 0) { if (w == 0) cl_tick<BD_CL_PERIOD>(cs, clock0 + st, lane); }                 \
-            issue_a(fbt, fks, slot_f);                                                                                  \
+            BD_REQ_X1                                                                                                   \
             KN_FENCE BD_MFMA(2, fa, bq[U], 1) BD_MFMA(3, fa, bq[U], 1) BD_MFMA(0, fa, bq[U], 2) BD_MFMA(1, fa, bq[U], 2) KN_FENCE \
-            BD_BLOAD(bq[((U) + 3) & 3])                                                                                 \
+            BD_REQ_X2(U)                                                                                                \
             KN_FENCE BD_MFMA(2, fa, bq[U], 2) BD_MFMA(3, fa, bq[U], 2) KN_FENCE                                         \
-            advance_fetch();                                                                                            \
+            BD_REQ_X3                                                                                                   \
             KN_FENCE BD_MFMA(0, fa, bq[U], 3) BD_MFMA(1, fa, bq[U], 3) BD_MFMA(2, fa, bq[U], 3) BD_MFMA(3, fa, bq[U], 3) KN_FENCE \
             /* Y half: tiles 4-7; fillers: the X fragments of stage st + 1 */                                           \
             KN_FENCE BD_MFMA(4, fy, bq[U], 0) KN_FENCE BD_RD(fa[0], An[0 * 64])                                              \
@@ -166,8 +190,8 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
             KN_FENCE BD_MFMA(6, fy, bq[U], 0) KN_FENCE BD_RD(fa[2], An[2 * 64])                                              \
             KN_FENCE BD_MFMA(7, fy, bq[U], 0) KN_FENCE BD_RD(fa[3], An[3 * 64])                                              \
             KN_FENCE                                                                                                    \
-            BD_MFMA(4, fy, bq[U], 1) BD_MFMA(5, fy, bq[U], 1) BD_MFMA(6, fy, bq[U], 1) BD_MFMA(7, fy, bq[U], 1)         \
-            BD_MFMA(4, fy, bq[U], 2) BD_MFMA(5, fy, bq[U], 2) BD_MFMA(6, fy, bq[U], 2) BD_MFMA(7, fy, bq[U], 2)         \
+            BD_MFMA(4, fy, bq[U], 1) BD_MFMA(5, fy, bq[U], 1) KN_FENCE BD_REQ_Y1(U) KN_FENCE BD_MFMA(6, fy, bq[U], 1) BD_MFMA(7, fy, bq[U], 1) \
+            BD_MFMA(4, fy, bq[U], 2) BD_MFMA(5, fy, bq[U], 2) KN_FENCE BD_REQ_Y2 KN_FENCE BD_MFMA(6, fy, bq[U], 2) BD_MFMA(7, fy, bq[U], 2)    \
             BD_MFMA(4, fy, bq[U], 3) BD_MFMA(5, fy, bq[U], 3) BD_MFMA(6, fy, bq[U], 3) BD_MFMA(7, fy, bq[U], 3)         \
             KN_FENCE                                                                                                    \
             slot_c = slot_n;                                                                                            \
