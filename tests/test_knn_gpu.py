@@ -69,15 +69,16 @@ def test_search_any_work_partition(cuda_device, G, panel):
     _check_exact(idx, dist, q, bank, k, "dot_product")
 
 
+@pytest.mark.parametrize("D", [48, 64])     # 6 k8 stages per tile: the LDS-staged kernels; 8: the kernel with register-resident query fragments
 @pytest.mark.parametrize("cq,cb,lag,G,panel,k,fp16,metric", [
     (2, 2, 6, 32, 0, 30, False, "dot_product"), (2, 2, 0, 64, 6, 30, False, "l2"), (4, 2, 3, 64, 0, 30, False, "dot_product"),
     (2, 4, 1, 64, 5, 90, False, "dot_product"), (1, 4, 6, 32, 3, 30, True, "dot_product"), (8, 1, 2, 64, 0, 30, True, "l2"),
-    (2, 2, 6, 256, 0, 30, False, "dot_product"), (2, 2, 4, 256, 0, 64, True, "dot_product"),
+    (2, 2, 6, 256, 0, 30, False, "dot_product"), (2, 2, 4, 256, 0, 64, True, "dot_product"), (2, 4, 16, 256, 0, 30, False, "l2"),
 ])
-def test_clustered_schedules_bit_exact(cuda_device, cq, cb, lag, G, panel, k, fp16, metric):
+def test_clustered_schedules_bit_exact(cuda_device, cq, cb, lag, G, panel, k, fp16, metric, D):
     """L2-sharing clusters (strided segments, common cluster clock, soft sync on progress words) are a speed feature: the
     result must be the oracle's bits for any cluster shape, sync lag (0 = never wait), ragged query / bank groups."""
-    M, D, nq = 70_001, 48, 1300            # 6 query tiles (ragged), 274 bank tiles (odd: partial bank groups)
+    M, nq = 70_001, 1300                   # 6 query tiles (ragged), 274 bank tiles (odd: partial bank groups)
     bank = gi.unit_bank(M, D, seed=31)
     bank[60_000:60_004] = bank[11]; bank[257] = bank[11]
     q = gi.vit_like_queries(nq, D, seed=32); q[:4] = 3.0 * bank[11]
