@@ -169,10 +169,10 @@ extern "C" int hb_index_cluster_stats(hb_index_t* ix, int64_t out[4]) {
     out[0] = out[1] = out[2] = out[3] = 0;
     if (!ix->cl_stats_dev) return 0;
     HB_HIP(hipSetDevice(ix->device));
-    int h[3] = {0, 0, 0};
+    int h[4] = {0, 0, 0, 0};
     HB_HIP(hipMemcpyAsync(h, ix->cl_stats_dev, sizeof(h), hipMemcpyDeviceToHost, ix->stream));
     HB_HIP(hipStreamSynchronize(ix->stream));
-    out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
+    out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = h[3];   // [3]: diagnostic builds only
     return 0;
 }
 

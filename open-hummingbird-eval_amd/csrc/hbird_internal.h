@@ -41,6 +41,8 @@ struct hb_seg {
     int stride;    // bank-tile stride (1, or the cluster's bank ways: the members interleave the tiles of a range)
     int tile0;     // cluster clock (tiles) at the segment's first tile; next_tile0 at its end (INT_MAX: no more work)
     int next_tile0;
+    int ord;       // ordinal of `slot` among the slots of its query tile, and their number (quota floors, hbird_knn.hip)
+    int nsl;
 };
 
 #define HB_CLUSTER_MAX 8      // workgroups per L2-sharing cluster

@@ -43,6 +43,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
     float* lst_s = reinterpret_cast<float*>(smem + KN_LISTS);
     unsigned* lst_i = reinterpret_cast<unsigned*>(smem + KN_LISTS + HB_QT * HB_KL * 4);
     float* sc = reinterpret_cast<float*>(smem + KN_SCRATCH) + w * 256;
+    unsigned* qf = reinterpret_cast<unsigned*>(smem + KN_QF) + w * 512;   // small-search instantiation: landing zone of the quota floors
     int* pcnt = reinterpret_cast<int*>(smem + KN_LISTS);
     const int g8 = a.g8, k = a.k;   // g8 = stages per bank tile
     const int myq = w * 32 + (lane & 31);
@@ -50,6 +51,10 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
     if constexpr (CL) cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + KN_CLWORDS);
 
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
+#ifdef KN_STAMPS
+    int kn_dbg[2] = {0, 0}, kn_tiles = 0; unsigned long long kn_epi = 0, kn_t0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kn_t0) :: "memory");
+#endif
     // "everything before my first segment is done" (a member without any work: everything)
     if constexpr (CL) { if (w == 0) cl_publish(cs, seg_begin < seg_end ? a.segs[seg_begin].tile0 * g8 : 0x7FFFFFFF, lane); }
     for (int si = seg_begin; si < seg_end; ++si) {
@@ -145,7 +150,19 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
                     // end of a segment -- a slot sees few rows (37 tiles at 50,176 x 384) and would insert about four times
                     // as much on its own bound.  The 32 floors of this wave's queries come in by LDS-DMA while the tile
                     // is computed (older than the stage's copies: the hand-counted vmcnt still holds) and are read at its end.
-                    if (lane < 32)
+                    // Up to seven slots per query tile: QUOTA floors as well.  The slots of a query tile see disjoint rows, so if
+                    // each of the S slots knows c = ceil(k / S) rows that reach v_i, S * c >= k rows reach min v_i: every slot
+                    // publishes its c-th best (a column of its own) and filters below the minimum of the S columns -- the c-th
+                    // best of a slot's share is about the k-th best of all rows, where the maximum of the slots' k-th bests (the
+                    // bound above; column 7 here) is only the k-th best of ONE share.  A query tile's first slot starts late (its
+                    // workgroup finishes another query tile first), so every slot also publishes its ceil(k / (S - 1))-th best
+                    // (columns 8..14): the SECOND smallest of those columns bounds the union whenever S - 1 slots have published.
+                    // 16 keys per query, 2 KiB per wave and tile.  50,176 x 384: 105 -> 60 candidates per wave and tile.
+                    if (seg.nsl <= 7) {
+                        const unsigned* src = a.qfl + (size_t)(seg.q_tile * HB_QT + w * 32) * 16 + lane * 4;
+                        __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)qf, 16, 0, 16);
+                        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(src + 256), (lds_void*)(qf + 256), 16, 0, 16);
+                    } else if (lane < 32)
                         __builtin_amdgcn_global_load_lds((gbl_cvoid*)(a.gthr + seg.q_tile * HB_QT + w * 32 + lane), (lds_void*)sc, 4, 0, 16);
                 }
                 const f32x4* bi = reinterpret_cast<const f32x4*>(smem + KN_BINIT + (CL ? cpar : (bt & 1)) * 1024);
@@ -205,13 +222,44 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
                             // the floors requested at the tile's start (waves 4-7 have nothing else in flight; waves 0-3 have
                             // passed dozens of counted waits since)
                             asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 .Lfl_%=\n\ts_waitcnt vmcnt(0)\n.Lfl_%=:" :: "s"(w) : "memory", "scc");
-                            thr = fmaxf(thr, floor_from_key(reinterpret_cast<const unsigned*>(sc)[lane & 31]));
+                            if (seg.nsl <= 7) {
+                                const unsigned* kk = qf + (lane & 31) * 16;   // my query's columns
+                                unsigned m1 = 0xFFFFFFFFu, lo = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;   // min of level 1; smallest, second smallest of level 2
+#pragma unroll
+                                for (int i = 0; i < 7; ++i) {
+                                    const unsigned v1 = kk[i], v2 = kk[8 + i];
+                                    if (i < seg.nsl) {
+                                        m1 = min(m1, v1);
+                                        m2 = min(m2, max(lo, v2));
+                                        lo = min(lo, v2);
+                                    }
+                                }
+                                if (seg.nsl < 2) m2 = 0u;   // a single slot: no "all but one"
+                                thr = fmaxf(thr, floor_from_key(max(max(m1, m2), kk[7])));
+                            } else thr = fmaxf(thr, floor_from_key(reinterpret_cast<const unsigned*>(sc)[lane & 31]));
                         }
                         // small searches (few rows per slot -> many insertions per tile): scan + register queue; the big
                         // ones keep the plain epilogue (insertions are rare there, and the scan's registers would spill)
                         if constexpr (ABL & 512) {
+#ifdef KN_STAMPS   // diagnostic build (make varu UNIT=hbird_knn NAME=stamps EXTRA=-DKN_STAMPS): the small-search epilogue in numbers
+                            unsigned long long t0_, t1_;
+                            __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory"); __builtin_amdgcn_sched_barrier(0);
+                            list_epilogue_scan(acc, thr, lst_s, lst_i, w * 32, lane, k, (unsigned)bt, kn_dbg);
+                            __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) :: "memory"); __builtin_amdgcn_sched_barrier(0);
+                            kn_epi += t1_ - t0_; ++kn_tiles;
+#else
                             list_epilogue_scan(acc, thr, lst_s, lst_i, w * 32, lane, k, (unsigned)bt);
-                            if (lane < 32) floor_publish(a.gthr, seg.q_tile * HB_QT + myq, thr);
+#endif
+                            if (seg.nsl <= 7) {
+                                if (lane < 32) {
+                                    unsigned* col = a.qfl + (size_t)(seg.q_tile * HB_QT + myq) * 16;
+                                    const int c1 = (k + seg.nsl - 1) / seg.nsl, c2 = seg.nsl > 1 ? (k + seg.nsl - 2) / (seg.nsl - 1) : k;
+                                    const float v1 = lst_s[myq * HB_KL + (c1 - 1)], v2 = lst_s[myq * HB_KL + (c2 - 1)];
+                                    if (v1 > -INFINITY) __hip_atomic_store(col + seg.ord, pool_key(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    if (v2 > -INFINITY) __hip_atomic_store(col + 8 + seg.ord, pool_key(v2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    floor_publish(col, 7, thr);
+                                }
+                            } else if (lane < 32) floor_publish(a.gthr, seg.q_tile * HB_QT + myq, thr);
                         } else tile_epilogue<!(ABL & 16), false>(acc, thr, lst_s, lst_i, sc, w * 32, lane, k, (unsigned)bt);
                     }
                 }
@@ -234,6 +282,19 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
         __syncthreads();   // the ring is reused by the next segment's prologue
     }
     if constexpr (CL) cl_finish(cs, a.cl_stats, w == 0, lane);
+#ifdef KN_STAMPS
+    if constexpr ((ABL & 512) != 0) {
+        unsigned long long kn_t1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kn_t1) :: "memory");
+        // max / sum over the workgroups of (cycles, epilogue cycles, candidates) / 1024 through the statistics words of the
+        // cluster sync (hb_index_cluster_stats; no printf: 256 of them distort the timing)
+        if (lane == 0 && w == 0) {
+            atomicMax(a.cl_stats, (int)((kn_t1 - kn_t0) >> 10));
+            atomicAdd(a.cl_stats + 1, (int)((kn_t1 - kn_t0) >> 10));
+            atomicAdd(a.cl_stats + 2, (int)(kn_epi >> 10));
+            atomicAdd(a.cl_stats + 3, kn_dbg[1]);
+        }
+    }
+#endif
 }
 
 // ---- merge of the partial lists of one query: rank by counting over <= slots*k candidates --------
@@ -459,8 +520,14 @@ void hb_default_cluster(int nqt, int nbt, int G, bool fp32_kernel, int* cq, int*
 static void hb_finish_schedule(hb_schedule& out, std::vector<std::vector<hb_seg>>& per_wg, const std::vector<int>& logical_of_block,
                                const std::vector<std::vector<int>>& slots_of_qt) {
     const int G = out.G;
+    std::map<int, std::pair<int, int>> ord_of;   // slot -> (ordinal among its query tile's slots, their number)
+    for (const auto& sl : slots_of_qt)
+        for (size_t i = 0; i < sl.size(); ++i) ord_of[sl[i]] = {(int)i, (int)sl.size()};
     for (auto& v : per_wg)
-        for (size_t i = 0; i < v.size(); ++i) v[i].next_tile0 = i + 1 < v.size() ? v[i + 1].tile0 : 0x7FFFFFFF;
+        for (size_t i = 0; i < v.size(); ++i) {
+            v[i].next_tile0 = i + 1 < v.size() ? v[i + 1].tile0 : 0x7FFFFFFF;
+            v[i].ord = ord_of[v[i].slot].first; v[i].nsl = ord_of[v[i].slot].second;
+        }
     out.wg_off.assign(G + 1, 0);
     for (int b = 0; b < G; ++b) {
         const int w = logical_of_block[b];
@@ -650,7 +717,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     }
     const size_t state_half = (size_t)sc.n_slots * HB_QT * klw * 4;
     const size_t state_aux = wide ? (size_t)sc.n_slots * HB_QT * 4 : 0;   // pools: fill counts + thresholds
-    const size_t floor_bytes = (size_t)nqt * HB_QT * 4;                   // shared threshold floors, one per query
+    const size_t floor_bytes = (size_t)nqt * HB_QT * 4 * 17;              // shared threshold floors, one per query, + 16 quota-floor keys per query
     const size_t prog_bytes = ((size_t)std::max(1, sc.n_clusters) * HB_CLUSTER_MAX + 1) * HB_CLUSTER_LINE * 4;   // progress words, a line each, + statistics
     if (ensure_bytes(&ix->state, &ix->state_bytes, 2 * state_half + 2 * state_aux + floor_bytes + prog_bytes)) return -1;
 
@@ -665,7 +732,8 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     a.state_thr = reinterpret_cast<float*>(ix->state + 2 * state_half + state_aux);
     const int* pool_cnt = wide ? a.state_cnt : nullptr;
     a.gthr = reinterpret_cast<unsigned*>(ix->state + 2 * state_half + 2 * state_aux);
-    HB_HIP(hipMemsetD32Async((hipDeviceptr_t)a.gthr, 0x007FFFFF, (size_t)nqt * HB_QT, s));   // key(-inf)
+    a.qfl = a.gthr + (size_t)nqt * HB_QT;
+    HB_HIP(hipMemsetD32Async((hipDeviceptr_t)a.gthr, 0x007FFFFF, (size_t)nqt * HB_QT * 17, s));   // key(-inf)
     a.wg_member = reinterpret_cast<const int*>(ix->sched_dev + o_wm);
     a.prog = reinterpret_cast<int*>(ix->state + 2 * state_half + 2 * state_aux + floor_bytes);
     a.cl = sc.cq * sc.cb;
@@ -675,6 +743,10 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     a.cl_stats = a.prog + (size_t)std::max(1, sc.n_clusters) * HB_CLUSTER_MAX * HB_CLUSTER_LINE;
     ix->cl_stats_dev = a.cl > 1 ? a.cl_stats : nullptr;
     if (a.cl > 1) HB_HIP(hipMemsetAsync(a.prog, 0, prog_bytes, s));
+#ifdef KN_STAMPS
+    ix->cl_stats_dev = a.cl_stats;
+    HB_HIP(hipMemsetAsync(a.prog, 0, prog_bytes, s));
+#endif
     if (f16) {
         // bring the fp16 copies of the bank / query fragment tiles up to date
         const int64_t need_rt = (ix->ntotal + 31) / 32;
@@ -791,7 +863,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         fn = hb_knn_w4_kernel(false);
         threads = 256;
     }
-    int lds_bytes = KN_LDS_TOTAL;
+    int lds_bytes = fn == cold_fn ? KN_LDS_TOTAL_COLD : KN_LDS_TOTAL;
     // The query fragments straight into registers (hbird_knn_bd.hip): -3.8 % kernel time at 10 M x 768 (0.895 -> 0.93 of the
     // fp32 MFMA peak), same bits.  Default for the big LDS-list searches whose stage count per tile is a multiple of four
     // (D = 384, 768, 1024, ...); variant 3 forces it wherever it applies (tests), variant 4 keeps the LDS-staged kernel.

@@ -28,6 +28,7 @@ struct knn_args {
     int cl;                 // workgroups per cluster (1: no clusters)
     int lag;                // soft sync: a member waits while another one is more than `lag` stages behind (0: never)
     int* cl_stats;          // {checks, spins, timeouts} of the launch
+    unsigned* qfl;          // [query][16]: quota floors of small searches (monotone keys; columns 0-6 / 8-14 per slot of the query tile, 7 the plain floor)
 };
 
 // A kernel argument read again from the kernarg segment at the point of use (through a laundered pointer, so that the
@@ -432,6 +433,11 @@ __device__ __forceinline__ void pool_epilogue_scan(f32x16 (&acc)[8], float& thr,
 // passed a threshold that is strict against rows of earlier tiles (lower ids), and list_insert compares the full key.
 // Measured at 50,176 x 384 (few rows per slot: 170 insertions per query and slot): the dump-and-walk path of
 // tile_epilogue spent 45 % of the kernel there.
+#ifdef KN_STAMPS   // diagnostic build: flagged quads and queued candidates per call
+#define HB_DBG_COUNT(VAR, N) VAR += (N);
+#else
+#define HB_DBG_COUNT(VAR, N)
+#endif
 #define HB_LIST_QUAD(T, Q)                                                                                   \
     {                                                                                                        \
         const float m_ = fmaxf(fmaxf(acc[T][4 * (Q)], acc[T][4 * (Q) + 1]), fmaxf(acc[T][4 * (Q) + 2], acc[T][4 * (Q) + 3])); \
@@ -439,6 +445,7 @@ __device__ __forceinline__ void pool_epilogue_scan(f32x16 (&acc)[8], float& thr,
             float q0v = 0.f, q1v = 0.f, q2v = 0.f, q3v = 0.f;                                                \
             int q0c = 0, q1c = 0, q2c = 0, q3c = 0, np = 0;                                                  \
             HB_SCAN_REG(T, 4 * (Q)) HB_SCAN_REG(T, 4 * (Q) + 1) HB_SCAN_REG(T, 4 * (Q) + 2) HB_SCAN_REG(T, 4 * (Q) + 3) \
+            HB_DBG_COUNT(dbg_quads, 1) HB_DBG_COUNT(dbg_cands, __popcll(__ballot(np > 0)) + __popcll(__ballot(np > 1)) + __popcll(__ballot(np > 2)) + __popcll(__ballot(np > 3))) \
             list_drain(lst_s, lst_i, qb, lane, k, row0, thr, np, q0v, q1v, q2v, q3v, q0c, q1c, q2c, q3c);    \
         }                                                                                                    \
     }
@@ -464,9 +471,12 @@ __device__ __forceinline__ void list_drain(float* lst_s, unsigned* lst_i, int qb
     }
 }
 __device__ __forceinline__ void list_epilogue_scan(f32x16 (&acc)[8], float& thr, float* lst_s, unsigned* lst_i, int qb, int lane,
-                                                   int k, unsigned bt) {
+                                                   int k, unsigned bt, int* dbg = nullptr /* diagnostic builds */) {
     const unsigned row0 = bt * HB_BT;
+    int dbg_quads = 0, dbg_cands = 0;
+    (void)dbg_quads; (void)dbg_cands;
     HB_LIST_TILE(0) HB_LIST_TILE(1) HB_LIST_TILE(2) HB_LIST_TILE(3) HB_LIST_TILE(4) HB_LIST_TILE(5) HB_LIST_TILE(6) HB_LIST_TILE(7)
+    if (dbg) { dbg[0] += dbg_quads; dbg[1] += dbg_cands; }
 }
 
 // ---- shared threshold floor ----------------------------------------------------------------------------------
@@ -543,6 +553,8 @@ __device__ __forceinline__ float cold_start_threshold(const f32x16 (&acc)[8], in
 #define KN_SCRATCH (KN_LISTS + 2 * HB_QT * HB_KL * 4)
 #define KN_CLWORDS (KN_SCRATCH + 8192)        // scratch: 1 KiB per wave (8 waves) / 2 KiB per wave (4 waves)
 #define KN_LDS_TOTAL (KN_CLWORDS + 64)        // landing zone of the cluster progress poll
+#define KN_QF KN_LDS_TOTAL                    // small-search instantiation only: quota floors, 2 KiB per wave
+#define KN_LDS_TOTAL_COLD (KN_QF + 8 * 2048)
 #define KN_FENCE __builtin_amdgcn_sched_barrier(0);
 
 typedef void (*hb_knn_fn)(knn_args);
