@@ -145,26 +145,9 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
             const f32x4* Ac = reinterpret_cast<const f32x4*>(smem + slot_c * KN_SLOT_BYTES) + lane;
             const f32x4* An = reinterpret_cast<const f32x4*>(smem + slot_n * KN_SLOT_BYTES) + lane;
             if (ks == 0) {
-                if constexpr ((ABL & 512) && !WIDE) {
-                    // small searches: the query tile's slots exchange their threshold floors every TILE, not only at the
-                    // end of a segment -- a slot sees few rows (37 tiles at 50,176 x 384) and would insert about four times
-                    // as much on its own bound.  The 32 floors of this wave's queries come in by LDS-DMA while the tile
-                    // is computed (older than the stage's copies: the hand-counted vmcnt still holds) and are read at its end.
-                    // Up to seven slots per query tile: QUOTA floors as well.  The slots of a query tile see disjoint rows, so if
-                    // each of the S slots knows c = ceil(k / S) rows that reach v_i, S * c >= k rows reach min v_i: every slot
-                    // publishes its c-th best (a column of its own) and filters below the minimum of the S columns -- the c-th
-                    // best of a slot's share is about the k-th best of all rows, where the maximum of the slots' k-th bests (the
-                    // bound above; column 7 here) is only the k-th best of ONE share.  A query tile's first slot starts late (its
-                    // workgroup finishes another query tile first), so every slot also publishes its ceil(k / (S - 1))-th best
-                    // (columns 8..14): the SECOND smallest of those columns bounds the union whenever S - 1 slots have published.
-                    // 16 keys per query, 2 KiB per wave and tile.  50,176 x 384: 105 -> 60 candidates per wave and tile.
-                    if (seg.nsl <= 7) {
-                        const unsigned* src = a.qfl + (size_t)(seg.q_tile * HB_QT + w * 32) * 16 + lane * 4;
-                        __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)qf, 16, 0, 16);
-                        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(src + 256), (lds_void*)(qf + 256), 16, 0, 16);
-                    } else if (lane < 32)
-                        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(a.gthr + seg.q_tile * HB_QT + w * 32 + lane), (lds_void*)sc, 4, 0, 16);
-                }
+                // small searches: the floors of this tile come in by LDS-DMA while it is computed (older than the stage's copies:
+                // the hand-counted vmcnt still holds) and are read at its end
+                if constexpr ((ABL & 512) && !WIDE) small_floor_request(a.qfl, a.gthr, seg, w, lane, qf, sc);
                 const f32x4* bi = reinterpret_cast<const f32x4*>(smem + KN_BINIT + (CL ? cpar : (bt & 1)) * 1024);
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
@@ -222,21 +205,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
                             // the floors requested at the tile's start (waves 4-7 have nothing else in flight; waves 0-3 have
                             // passed dozens of counted waits since)
                             asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 .Lfl_%=\n\ts_waitcnt vmcnt(0)\n.Lfl_%=:" :: "s"(w) : "memory", "scc");
-                            if (seg.nsl <= 7) {
-                                const unsigned* kk = qf + (lane & 31) * 16;   // my query's columns
-                                unsigned m1 = 0xFFFFFFFFu, lo = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;   // min of level 1; smallest, second smallest of level 2
-#pragma unroll
-                                for (int i = 0; i < 7; ++i) {
-                                    const unsigned v1 = kk[i], v2 = kk[8 + i];
-                                    if (i < seg.nsl) {
-                                        m1 = min(m1, v1);
-                                        m2 = min(m2, max(lo, v2));
-                                        lo = min(lo, v2);
-                                    }
-                                }
-                                if (seg.nsl < 2) m2 = 0u;   // a single slot: no "all but one"
-                                thr = fmaxf(thr, floor_from_key(max(max(m1, m2), kk[7])));
-                            } else thr = fmaxf(thr, floor_from_key(reinterpret_cast<const unsigned*>(sc)[lane & 31]));
+                            thr = fmaxf(thr, small_floor_read(seg, qf, sc, lane));
                         }
                         // small searches (few rows per slot -> many insertions per tile): scan + register queue; the big
                         // ones keep the plain epilogue (insertions are rare there, and the scan's registers would spill)
@@ -250,16 +219,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
 #else
                             list_epilogue_scan(acc, thr, lst_s, lst_i, w * 32, lane, k, (unsigned)bt);
 #endif
-                            if (seg.nsl <= 7) {
-                                if (lane < 32) {
-                                    unsigned* col = a.qfl + (size_t)(seg.q_tile * HB_QT + myq) * 16;
-                                    const int c1 = (k + seg.nsl - 1) / seg.nsl, c2 = seg.nsl > 1 ? (k + seg.nsl - 2) / (seg.nsl - 1) : k;
-                                    const float v1 = lst_s[myq * HB_KL + (c1 - 1)], v2 = lst_s[myq * HB_KL + (c2 - 1)];
-                                    if (v1 > -INFINITY) __hip_atomic_store(col + seg.ord, pool_key(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    if (v2 > -INFINITY) __hip_atomic_store(col + 8 + seg.ord, pool_key(v2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    floor_publish(col, 7, thr);
-                                }
-                            } else if (lane < 32) floor_publish(a.gthr, seg.q_tile * HB_QT + myq, thr);
+                            small_floor_publish(a.qfl, a.gthr, seg, lst_s, myq, k, thr, lane);
                         } else tile_epilogue<!(ABL & 16), false>(acc, thr, lst_s, lst_i, sc, w * 32, lane, k, (unsigned)bt);
                     }
                 }
@@ -844,18 +804,18 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     knn_fn fn = variants[wide ? 1 : 0];
     if (a.cl > 1) fn = wide ? (knn_fn)knn_fused_kernel<0, true, true> : (knn_fn)knn_fused_kernel<0, false, true>;
     // Few stages per workgroup: a slot sees few rows, so its cold start (the first tile inserts all 256 rows of every
-    // query) and its insertions (k ln(rows / k) per query) are a visible share of the search -> the instantiation with the
+    // query) and its insertions (k ln(rows / k) per query) are a visible share of the search -> the instantiations with the
     // radix-select cold start, the scan epilogue (register queue + immediate inserts) and the per-tile exchange of
-    // threshold floors: 50,176 x 384: 6.3 -> 4.95 ms (0.49 -> 0.62 of the fp32 MFMA peak); 1.25 M x 768 (one of eight
-    // shards of the headline bank): 302.3 -> 300.5 ms.  The big searches keep the plain instantiation: at 10 M x 768 the
-    // extra code costs 0.3 % (same-box A/B), the crossover is near 3 M rows.
+    // threshold floors (hbird_knn_dev.h: small_floor_*).  Same box, kernel ms, LDS-staged small / B-direct plain / B-direct small:
+    // 50,176 x 384: 4.86 / 6.76 / 4.62 (round 1: 6.3; 0.49 -> 0.665 of the fp32 MFMA peak); 200 k x 384: 15.9 / 17.7 / 15.1;
+    // 300 k x 768: 74.7 / 72.8 / 70.7; 2 M x 384: 149.3 / 143.1 / 142.3; 1.25 M x 768: 305.9 / 291.2 / 289.8; 2.5 M x 768 (315 k
+    // stages per workgroup): 612.7 / 579.1 / 579.6 -> small below 400 k stages.  The big searches keep the plain
+    // instantiations: at 10 M x 768 the extra code costs 0.3 % (same-box A/B).
     static const knn_fn cold_fn = knn_fused_kernel<512, false>;
-    // stages per workgroup below which the small-search instantiation wins: against the kernel with register-resident
-    // query fragments (below) the crossover is near 16 k stages (300 k x 768: 72.7 vs 73.9 ms; 200 k x 384: 17.6 vs 15.8 ms),
-    // against the LDS-staged kernel (shapes the other one does not serve) near 400 k
     const bool bd_shape = ix->g8 % 4 == 0 && !ix->ablate && ix->variant != 4;
-    const long long cold_limit = bd_shape ? 16000 : 400000;
-    if (!wide && a.cl == 1 && (long long)nqt * nbt / std::max(1, sc.G) * ix->g8 < cold_limit) fn = cold_fn;
+    static const long long small_limit = getenv("HBIRD_SMALL_LIMIT") ? atoll(getenv("HBIRD_SMALL_LIMIT")) : 400000;   // stages per workgroup
+    const bool small = !wide && a.cl == 1 && (long long)nqt * nbt / std::max(1, sc.G) * ix->g8 < small_limit;
+    if (small) fn = cold_fn;
     if (!wide && ix->ablate)
         for (size_t i = 0; i < sizeof(variants) / sizeof(variants[0]); ++i) if (variant_bits[i] == ix->ablate) fn = variants[i];
     int threads = HB_THREADS;
@@ -867,9 +827,9 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // The query fragments straight into registers (hbird_knn_bd.hip): -3.8 % kernel time at 10 M x 768 (0.895 -> 0.93 of the
     // fp32 MFMA peak), same bits.  Default for the big LDS-list searches whose stage count per tile is a multiple of four
     // (D = 384, 768, 1024, ...); variant 3 forces it wherever it applies (tests), variant 4 keeps the LDS-staged kernel.
-    if (bd_shape && ((ix->variant == 0 && fn != cold_fn) || ix->variant == 3)) {
-        fn = hb_knn_bd_kernel(wide, a.cl > 1);
-        lds_bytes = hb_knn_bd_lds_bytes();
+    if (bd_shape && (ix->variant == 0 || ix->variant == 3)) {
+        fn = hb_knn_bd_kernel(wide, a.cl > 1, small);
+        lds_bytes = hb_knn_bd_lds_bytes(small);
     }
     if (hb_ensure_dyn_lds((const void*)fn, lds_bytes)) return -1;   // per (kernel, device)
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev0, s));

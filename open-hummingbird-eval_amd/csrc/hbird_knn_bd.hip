@@ -24,6 +24,8 @@
 #define BD_CL_PERIOD 128
 #endif
 #define BD_LDS_TOTAL (BD_CLWORDS + 64)
+#define BD_QF BD_LDS_TOTAL                    // small-search instantiation: quota floors, 2 KiB per wave
+#define BD_LDS_TOTAL_COLD (BD_QF + 8 * 2048)
 
 #define BD_MFMA(T, FR, B, S) acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(FR[(T) & 3][S], B[S], acc[T], 0, 0, 0);
 // the two wave classes have different numbers of requests in flight: ONE statement with the branch inside, so that the
@@ -53,8 +55,9 @@
 #endif
 
 // WIDE: k > HB_KL, candidate pools in global memory; CL: member of an L2-sharing cluster (strided segments on a common
-// clock, soft sync from wave 0) -- both as in hbird_knn.hip
-template <bool WIDE, bool CL>
+// clock, soft sync from wave 0); COLD: small search (radix-select cold start, scan epilogue, per-tile floors) -- all as in
+// hbird_knn.hip
+template <bool WIDE, bool CL, bool COLD = false>
 __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -64,6 +67,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
     float* lst_s = reinterpret_cast<float*>(smem + BD_LISTS);
     unsigned* lst_i = reinterpret_cast<unsigned*>(smem + BD_LISTS + HB_QT * HB_KL * 4);
     float* sc = reinterpret_cast<float*>(smem + BD_SCRATCH) + w * 256;
+    unsigned* qf = reinterpret_cast<unsigned*>(smem + BD_QF) + w * 512;   // COLD only
     int* pcnt = reinterpret_cast<int*>(smem + BD_LISTS);   // WIDE: pool fill counts in the (otherwise unused) list area
     const int g8 = a.g8, k = a.k;
     const int myq = w * 32 + (lane & 31);
@@ -167,6 +171,8 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
         {                                                                                                               \
             BD_WAIT(3, 1, bq[((U) + 1) & 3])   /* stage st + 1 has landed for me (st + 2 in flight) ... */              \
             __builtin_amdgcn_s_barrier();      /* ... and for everyone; the slot of stage st - 1 is free for st + 3 */   \
+            /* small searches: this tile's floors, requested HERE so that they are older than the stage's own requests */ \
+            if constexpr (COLD && (U) == 0) { if (ks == 0) small_floor_request(HB_KARG(knn_args, qfl), HB_KARG(knn_args, gthr), seg, w, lane, qf, sc); } \
             int slot_n = slot_c + 1; if (slot_n == BD_RING) slot_n = 0;                                                 \
             const f32x4* Ac = reinterpret_cast<const f32x4*>(smem + slot_c * BD_SLOT) + lane;                           \
             const f32x4* An = reinterpret_cast<const f32x4*>(smem + slot_n * BD_SLOT) + lane;                           \
@@ -224,6 +230,14 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
                     float* ps = HB_KARG(knn_args, state_s) + (size_t)slot_ * HB_QT * klw;
                     unsigned* pi = HB_KARG(knn_args, state_i) + (size_t)slot_ * HB_QT * klw;
                     tile_epilogue<true, true>(acc, thr, ps, pi, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
+                } else if constexpr (COLD) {
+                    if (seg.first && bt == seg.b_tile0) thr = fmaxf(thr, cold_start_threshold(acc, k));
+                    // the floors requested at the tile's start (waves 4-7: behind their query fragments; waves 0-3 have passed
+                    // counted waits that cover them)
+                    asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 .Lbfl_%=\n\ts_waitcnt vmcnt(0)\n.Lbfl_%=:" :: "s"(w) : "memory", "scc");
+                    thr = fmaxf(thr, small_floor_read(seg, qf, sc, lane));
+                    list_epilogue_scan(acc, thr, lst_s, lst_i, w * 32, lane, k, (unsigned)bt);
+                    small_floor_publish(HB_KARG(knn_args, qfl), HB_KARG(knn_args, gthr), seg, lst_s, myq, k, thr, lane);
                 } else tile_epilogue<true, false>(acc, thr, lst_s, lst_i, sc, w * 32, lane, k, (unsigned)bt);
                 ks = 0;
                 bt += bstride; cpar ^= 1;
@@ -246,8 +260,9 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
     if constexpr (CL) cl_finish(cs, a.cl_stats, w == 0, lane);
 }
 
-hb_knn_fn hb_knn_bd_kernel(bool wide, bool clustered) {
+hb_knn_fn hb_knn_bd_kernel(bool wide, bool clustered, bool small) {
+    if (small && !wide && !clustered) return knn_fused_bd_kernel<false, false, true>;
     if (clustered) return wide ? knn_fused_bd_kernel<true, true> : knn_fused_bd_kernel<false, true>;
     return wide ? knn_fused_bd_kernel<true, false> : knn_fused_bd_kernel<false, false>;
 }
-int hb_knn_bd_lds_bytes() { return BD_LDS_TOTAL; }
+int hb_knn_bd_lds_bytes(bool small) { return small ? BD_LDS_TOTAL_COLD : BD_LDS_TOTAL; }

@@ -500,6 +500,58 @@ __device__ __forceinline__ void floor_publish(unsigned* gthr, int q, float thr) 
     if (thr > -INFINITY) atomicMax(gthr + q, pool_key(thr));
 }
 
+// ---- per-tile floors of small searches (fewer than ~16 k stages per workgroup) ----------------------------------------------
+// A slot sees few rows there (37 tiles at 50,176 x 384) and would insert several times as much on its own bound, so the slots of
+// a query tile exchange floors every TILE, not only at the end of a segment.
+//  * Plain floor: the maximum of the slots' k-th bests (atomic max of a monotone key) -- the k-th best of ONE slot's share.
+//  * QUOTA floors (query tiles with up to seven slots): the slots see disjoint rows, so if each of the S slots knows
+//    c = ceil(k / S) rows that reach v_i, S * c >= k rows reach min v_i: every slot publishes its c-th best (a column of its own,
+//    plain agent-scope stores) and filters below the minimum of the S columns -- about the k-th best of ALL rows seen.  A
+//    query tile's first slot starts late (its workgroup finishes another query tile first), so every slot also publishes its
+//    ceil(k / (S - 1))-th best (columns 8..14): the SECOND smallest of those bounds the union whenever S - 1 slots have published.
+//    16 keys per query (column 7: the plain floor), 2 KiB per wave and tile.  50,176 x 384: 105 -> 55-60 candidates per wave and
+//    tile.
+// The keys come in by LDS-DMA at the tile's start (older than the stage's copies, so the kernels' hand-counted vmcnt holds) and
+// are read at its end; a foreign bound admits ties (floor_from_key: the float just below).
+#define HB_QUOTA_MAX 7
+__device__ __forceinline__ void small_floor_request(const unsigned* qfl, const unsigned* gthr, const hb_seg& seg, int w, int lane,
+                                                    unsigned* qf /* 512 words of LDS */, float* sc /* 256 words */) {
+    if (seg.nsl <= HB_QUOTA_MAX) {
+        const unsigned* src = qfl + (size_t)(seg.q_tile * HB_QT + w * 32) * 16 + lane * 4;
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)qf, 16, 0, 16);
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(src + 256), (lds_void*)(qf + 256), 16, 0, 16);
+    } else if (lane < 32)
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(gthr + seg.q_tile * HB_QT + w * 32 + lane), (lds_void*)sc, 4, 0, 16);
+}
+__device__ __forceinline__ float small_floor_read(const hb_seg& seg, const unsigned* qf, const float* sc, int lane) {
+    if (seg.nsl > HB_QUOTA_MAX) return floor_from_key(reinterpret_cast<const unsigned*>(sc)[lane & 31]);
+    const unsigned* kk = qf + (lane & 31) * 16;   // my query's columns
+    unsigned m1 = 0xFFFFFFFFu, lo = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;   // min of level 1; smallest, second smallest of level 2
+#pragma unroll
+    for (int i = 0; i < HB_QUOTA_MAX; ++i) {
+        const unsigned v1 = kk[i], v2 = kk[8 + i];
+        if (i < seg.nsl) {
+            m1 = min(m1, v1);
+            m2 = min(m2, max(lo, v2));
+            lo = min(lo, v2);
+        }
+    }
+    if (seg.nsl < 2) m2 = 0u;   // a single slot: no "all but one"
+    return floor_from_key(max(max(m1, m2), kk[7]));
+}
+__device__ __forceinline__ void small_floor_publish(unsigned* qfl, unsigned* gthr, const hb_seg& seg, const float* lst_s, int myq, int k,
+                                                    float thr, int lane) {
+    if (lane >= 32) return;
+    if (seg.nsl <= HB_QUOTA_MAX) {
+        unsigned* col = qfl + (size_t)(seg.q_tile * HB_QT + myq) * 16;
+        const int c1 = (k + seg.nsl - 1) / seg.nsl, c2 = seg.nsl > 1 ? (k + seg.nsl - 2) / (seg.nsl - 1) : k;
+        const float v1 = lst_s[myq * HB_KL + (c1 - 1)], v2 = lst_s[myq * HB_KL + (c2 - 1)];
+        if (v1 > -INFINITY) __hip_atomic_store(col + seg.ord, pool_key(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v2 > -INFINITY) __hip_atomic_store(col + 8 + seg.ord, pool_key(v2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        floor_publish(col, 7, thr);
+    } else floor_publish(gthr, seg.q_tile * HB_QT + myq, thr);
+}
+
 // pools: fill counts / thresholds of the wave's 32 queries at the start and the end of a segment
 __device__ __forceinline__ float pool_begin(const knn_args_pool_view& pv, int slot, bool first, int* cnt, int myq, int lane) {
     float thr = -INFINITY;
@@ -559,5 +611,5 @@ __device__ __forceinline__ float cold_start_threshold(const f32x16 (&acc)[8], in
 
 typedef void (*hb_knn_fn)(knn_args);
 hb_knn_fn hb_knn_w4_kernel(bool wide);   // 4-wave (one wave per SIMD) variant, hbird_knn_w4.hip
-hb_knn_fn hb_knn_bd_kernel(bool wide, bool clustered);   // query fragments straight into registers, hbird_knn_bd.hip
-int hb_knn_bd_lds_bytes();
+hb_knn_fn hb_knn_bd_kernel(bool wide, bool clustered, bool small);   // query fragments straight into registers, hbird_knn_bd.hip
+int hb_knn_bd_lds_bytes(bool small);
