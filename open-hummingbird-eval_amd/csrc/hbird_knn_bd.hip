@@ -1,5 +1,5 @@
-// The fp32 kNN kernel of big searches (default from 16 k stages per workgroup up; hb_index_set_variant(ix, 3) forces it
-// wherever it can run, 4 forbids it): the same fused fp32-MFMA running top-k as hbird_knn.hip -- same tiles, same k-ascending
+// The fp32 kNN kernel (default wherever it can run: tiles of a multiple of four k8 stages; hb_index_set_variant(ix, 4)
+// forbids it): the same fused fp32-MFMA running top-k as hbird_knn.hip -- same tiles, same k-ascending
 // fmaf chains, same lists / candidate pools, hence the same bits -- with the QUERY fragments loaded straight from global
 // memory into registers instead of being staged through LDS.
 //
@@ -9,7 +9,7 @@
 // global_load_dwordx4 (invisible to hipcc's wait-count pass, counted by hand with the copies) into one of four register
 // buffers; the stage loop is unrolled by four so that the buffers have static indices (g8 must be a multiple of 4: the
 // launcher keeps other shapes on hbird_knn.hip).  10 M x 768, k = 30: 2377 -> 2288 ms on one box (0.895 -> 0.93 of the fp32
-// MFMA peak); k = 90 (WIDE), 5 M rows: 1294 -> 1218 ms.  No clusters, no small-search epilogue (those stay in hbird_knn.hip).
+// MFMA peak); k = 90 (WIDE), 5 M rows: 1294 -> 1218 ms; 50,176 x 384 (COLD): 4.86 -> 4.62 ms.
 #include "hbird_knn_dev.h"
 
 #define BD_SLOT 8192                        // bank fragments of one k8 stage: 8 row tiles x 1 KiB
