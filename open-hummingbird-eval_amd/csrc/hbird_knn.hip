@@ -276,7 +276,7 @@ static int ensure_bytes(char** p, size_t* have, size_t need) {
 // unsorted candidate pool of which the first cnts[slot][query] entries are valid.
 __global__ __launch_bounds__(64) void knn_merge_kernel(const float* __restrict__ state_s,
                                                        const unsigned* __restrict__ state_i,
-                                                       const int* __restrict__ cnts, int per,
+                                                       const int* __restrict__ cnts, const float* __restrict__ pthr, int per,
                                                        const int* __restrict__ qt_off, const int* __restrict__ qt_slots,
                                                        int fixed_ng, int grp_size, int n_groups, float* __restrict__ tmp_s,
                                                        unsigned* __restrict__ tmp_i,
@@ -297,14 +297,59 @@ __global__ __launch_bounds__(64) void knn_merge_kernel(const float* __restrict__
     float* cs = reinterpret_cast<float*>(smem);
     unsigned* ci = reinterpret_cast<unsigned*>(smem) + ns * per;
     const int lane = threadIdx.x;
-    // gather the valid candidates of the slots, densely packed
+    // Pre-filter: a slot that knows k candidates reaching v (a sorted list: its k-th entry; a pool: the threshold of its last
+    // compaction, or a foreign floor it ran under -- both lower bounds of the k-th best of the union) rules out everything
+    // below the largest such v.  With many slots per query tile (few queries against a big bank: one slot per workgroup) the
+    // rank-by-counting below is quadratic in slots x k: 1,369 queries x 200 k rows in use_fp16 mode spent 20 ms here.
+    float tstar = -INFINITY;
+    for (int j = lane; j < ns; j += 64) {
+        const int sl = fixed_ng > 0 ? s0 + j : qt_slots[s0 + j];
+        const size_t oq = (size_t)sl * HB_QT + ql;
+        if (cnts) { if (pthr && cnts[oq] >= k) tstar = fmaxf(tstar, pthr[oq]); }
+        else tstar = fmaxf(tstar, state_s[oq * klw + (k - 1)]);
+    }
+    for (int o = 32; o > 0; o >>= 1) tstar = fmaxf(tstar, __shfl_xor(tstar, o));
+    // gather the surviving candidates of the slots, densely packed
     int n = 0;
     for (int j = 0; j < ns; ++j) {
         const int sl = fixed_ng > 0 ? s0 + j : qt_slots[s0 + j];
         const int valid = cnts ? min(per, cnts[(size_t)sl * HB_QT + ql]) : per;
         const size_t off = ((size_t)sl * HB_QT + ql) * klw;
-        for (int e = lane; e < valid; e += 64) { cs[n + e] = state_s[off + e]; ci[n + e] = state_i[off + e]; }
-        n += valid;
+        for (int e0 = 0; e0 < valid; e0 += 64) {
+            const int e = e0 + lane;
+            const float v = e < valid ? state_s[off + e] : -INFINITY;
+            const bool keep = e < valid && (v >= tstar || tstar == -INFINITY);
+            const unsigned long long m = __ballot(keep);
+            if (keep) { const int pos = n + __popcll(m & ((1ull << lane) - 1ull)); cs[pos] = v; ci[pos] = state_i[off + e]; }
+            n += __popcll(m);
+        }
+    }
+    // Still many: find the key of the k-th largest with a radix select (32 rounds of one pass over the candidates, counted
+    // 64 at a time by ballot) and keep what reaches it (its ties included), so that the rank-by-counting below sees about k
+    // candidates instead of slots x k (it is quadratic: 6,144 candidates of 32 pools took a wave 0.4 ms).
+    if (n > 2 * k + 64) {
+        unsigned prefix = 0;
+        int kk = k;
+        for (int b = 31; b >= 0; --b) {
+            const unsigned himask = ~((1u << b) - 1u), want = prefix | (1u << b);
+            int c = 0;
+            for (int base = 0; base < n; base += 64) {
+                const int idx = base + lane;
+                c += __popcll(__ballot(idx < n && (pool_key(cs[idx]) & himask) == want));
+            }
+            if (c >= kk) prefix = want; else kk -= c;
+        }
+        int m = 0;
+        for (int base = 0; base < n; base += 64) {   // in place: a kept entry moves to a position at or below its own
+            const int idx = base + lane;
+            const float v = idx < n ? cs[idx] : 0.0f;
+            const unsigned id = idx < n ? ci[idx] : 0u;
+            const bool keep = idx < n && pool_key(v) >= prefix;
+            const unsigned long long mk = __ballot(keep);
+            if (keep) { const int pos = m + __popcll(mk & ((1ull << lane) - 1ull)); cs[pos] = v; ci[pos] = id; }
+            m += __popcll(mk);
+        }
+        n = m;
     }
     const size_t tmp_off = grp_size > 0 ? ((size_t)(qt * n_groups + grp) * HB_QT + ql) * klw : 0;
     __syncthreads();
@@ -340,13 +385,13 @@ __global__ __launch_bounds__(64) void knn_merge_kernel(const float* __restrict__
 // Merge the partial lists / pools of every query: one level when the candidates of a query tile's slots fit the merge
 // block's LDS, two levels otherwise (few query tiles against a big bank: up to one slot per workgroup).
 // cnts == nullptr: sorted lists of k entries; otherwise pools of capacity klw with fill counts cnts.
-static int launch_merge(hb_index* ix, const float* state_s, const unsigned* state_i, const int* cnts, const int* qt_off,
+static int launch_merge(hb_index* ix, const float* state_s, const unsigned* state_i, const int* cnts, const float* pthr, const int* qt_off,
                         const int* qt_slots, int max_slots, int nqt, int64_t nq, int k, int klw, int64_t id_base, int metric,
                         const float* qn2, int64_t* out_idx, float* out_dist, hipStream_t s) {
     const size_t lim = 48 * 1024;
     const int per = cnts ? klw : k;
     if ((size_t)max_slots * per * 8 <= lim) {
-        knn_merge_kernel<<<dim3((unsigned)nq), dim3(64), (size_t)max_slots * per * 8, s>>>(state_s, state_i, cnts, per, qt_off, qt_slots,
+        knn_merge_kernel<<<dim3((unsigned)nq), dim3(64), (size_t)max_slots * per * 8, s>>>(state_s, state_i, cnts, pthr, per, qt_off, qt_slots,
                                                                                             0, 0, 0, nullptr, nullptr, nq, k, klw,
                                                                                             id_base, metric, qn2, out_idx, out_dist);
         HB_HIP(hipGetLastError());
@@ -359,11 +404,11 @@ static int launch_merge(hb_index* ix, const float* state_s, const unsigned* stat
     if (ensure_bytes(&ix->mtmp, &ix->mtmp_bytes, 2 * half)) return -1;
     float* ts = reinterpret_cast<float*>(ix->mtmp);
     unsigned* ti = reinterpret_cast<unsigned*>(ix->mtmp + half);
-    knn_merge_kernel<<<dim3((unsigned)nq, (unsigned)ng), dim3(64), (size_t)grp * per * 8, s>>>(state_s, state_i, cnts, per, qt_off, qt_slots,
+    knn_merge_kernel<<<dim3((unsigned)nq, (unsigned)ng), dim3(64), (size_t)grp * per * 8, s>>>(state_s, state_i, cnts, pthr, per, qt_off, qt_slots,
                                                                                                 0, grp, ng, ts, ti, nq, k, klw, 0, 0,
                                                                                                 nullptr, nullptr, nullptr);
     HB_HIP(hipGetLastError());
-    knn_merge_kernel<<<dim3((unsigned)nq), dim3(64), (size_t)ng * k * 8, s>>>(ts, ti, nullptr, k, nullptr, nullptr, ng, 0, 0, nullptr,
+    knn_merge_kernel<<<dim3((unsigned)nq), dim3(64), (size_t)ng * k * 8, s>>>(ts, ti, nullptr, nullptr, k, nullptr, nullptr, ng, 0, 0, nullptr,
                                                                                 nullptr, nq, k, klw, id_base, metric, qn2, out_idx,
                                                                                 out_dist);
     HB_HIP(hipGetLastError());
@@ -736,7 +781,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev0, s));
         if (hb_knn_f16_launch(h, sc.G, ix->variant == 2 ? 1 : 2, s)) return -1;   // variant 2 = the first design, for A/B
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
-        if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
+        if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, pool_cnt ? a.state_thr : nullptr, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
                          reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, kc, klw, 0, 0, nullptr,
                          cand_idx, cand_dist, s)) return -1;
         if (ensure_bytes(&ix->fb, &ix->fb_bytes, (size_t)nq + 64)) return -1;
@@ -837,7 +882,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     HB_HIP(hipGetLastError());
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
     const float* qn2 = ix->q_aux;   // [nq] chain ||q||^2 (valid for L2)
-    if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
+    if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, pool_cnt ? a.state_thr : nullptr, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
                      reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, k, klw, id_base, out_metric,
                      qn2, out_idx, out_dist, s)) return -1;
     if (ix->time_kernels) {
