@@ -145,7 +145,8 @@ int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_tiles);
  * fragment tiles, fp16 MFMA, k' >= 2k candidates) followed by an exact fp32 re-rank of the candidates, so the
  * returned indices / distances are those of the fp32 search.  Every query carries a certificate (exact k-th score >
  * k'-th fp16 score + rounding bound); queries that fail it are searched again with the fp32 kernel, so the result is
- * ALWAYS the fp32 result.  Applies to k <= 128; larger k use the fp32 kernel. */
+ * ALWAYS the fp32 result.  Applies to k <= 128; larger k use the fp32 kernel.  2 = the same, but only for banks of at
+ * least 131,072 rows -- below that the fp32 kernel is the faster way to the same result (what the plugin's use_fp16 sets). */
 int hb_index_set_fp16(hb_index_t* ix, int enable);
 /* Number of queries of the last fp16-mode search that needed the exact fp32 re-search. */
 int hb_index_last_fp16_fallbacks(const hb_index_t* ix, int64_t* n);

@@ -125,7 +125,7 @@ extern "C" int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_til
 }
 extern "C" int hb_index_set_fp16(hb_index_t* ix, int enable) {
     if (!ix) return hb_fail("hb_index_set_fp16: NULL index handle");
-    ix->fp16 = enable ? 1 : 0;
+    ix->fp16 = enable == 2 ? 2 : (enable ? 1 : 0);   // 2: only where it pays (hb_launch_knn)
     return 0;
 }
 

@@ -657,7 +657,11 @@ void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out, int
 // q_tiles / q_aux must already be prepared by the caller (hb_index_search).
 int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t id_base, int64_t* out_idx, float* out_dist) {
     if (k < 1 || k > 256) return hb_fail("hb_index_search: k must be in [1, 256]");
-    const bool f16 = ix->fp16 != 0 && k <= 128;
+    // fp16 mode 2 (what the plugin's use_fp16=True selects): the candidate pass only where it pays.  Its fixed costs (fp16 query
+    // tiles, re-rank, a second merge, cold pools) scale with the queries like the search itself, so the crossover is a bank size:
+    // same box, fp32 / use_fp16 ms: 50 k x 768 (nq 21,904) 13.1 / 13.0, 100 k 24.9 / 16.2; 100 k x 384 (nq 12,544) 8.3 / 10.9,
+    // 200 k 15.1 / 11.0; 50 k x 768 (nq 1,369) 2.0 / 2.6, 200 k 4.8 / 3.8.  Same results either way.
+    const bool f16 = ix->fp16 != 0 && k <= 128 && (ix->fp16 == 1 || ix->ntotal >= 131072);
     // fp16 mode: the fused kernel collects kc >= 2k candidates, the fp32 chain arithmetic re-ranks them
     const int kc = f16 ? std::min(256, std::max(64, (2 * k + 63) / 64 * 64)) : k;
     const bool wide = f16 || k > HB_KL;   // (pools for k <= 32 on small searches were tried: 8.1 vs 5.0 ms at 50,176 x 384)

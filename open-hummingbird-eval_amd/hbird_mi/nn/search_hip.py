@@ -219,9 +219,10 @@ class HipFlatIndex:
     def set_tuning(self, workgroups: int = 0, panel_tiles: int = 0):
         _lib.check(_lib.lib().hb_index_set_tuning(self._h, int(workgroups), int(panel_tiles)))
 
-    def set_fp16(self, enable: bool):
-        """fp16 candidate pass + exact fp32 re-rank (GpuIndexFlatConfig.useFloat16 of the reference)."""
-        _lib.check(_lib.lib().hb_index_set_fp16(self._h, int(bool(enable))))
+    def set_fp16(self, enable):
+        """fp16 candidate pass + exact fp32 re-rank (GpuIndexFlatConfig.useFloat16 of the reference).  True / 1: always;
+        2: only for banks of at least 131,072 rows, where it is faster than the fp32 kernel (same results either way)."""
+        _lib.check(_lib.lib().hb_index_set_fp16(self._h, 2 if enable == 2 and enable is not True else int(bool(enable))))
 
     def last_fp16_fallbacks(self) -> int:
         n = ctypes.c_int64(0)
@@ -333,7 +334,7 @@ class NearestNeighborSearchHIP(NearestNeighborSearchBase):
         out = []
         for g in self.local_gpus:
             index = HipFlatIndex(self.embed_d, _METRICS[self.distance_measure], g)
-            index.set_fp16(bool(self.use_fp16))                                         # search_faiss.py:40
+            index.set_fp16(2 if self.use_fp16 else 0)                                   # search_faiss.py:40; only where it pays
             out.append(index)
         return out
 
