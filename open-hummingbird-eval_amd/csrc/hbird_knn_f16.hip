@@ -424,11 +424,15 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
 #pragma unroll
                 for (int t = 0; t < 8; ++t) asm volatile("" :: "v"(acc[t]));   // timing only: no epilogue
 #elif defined(F2_STAMPS)
+                if (seg.first && bt == seg.b_tile0) thr = fmaxf(thr, cold_start_threshold(acc, k));
                 F2_STAMP(ts_a)
                 pool_epilogue_scan<EMAX>(acc, thr, wl_s, wl_i, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt, &ts_m);
                 F2_STAMP(ts_b)
                 sum_scan += ts_m - ts_a; sum_drain += ts_b - ts_m; after_epi = 1;
 #else
+                // a slot's first tile: filter below the k'-th largest of its 256 scores (radix select over the accumulators)
+                // instead of appending all 256 rows of every query through the overflow path
+                if (seg.first && bt == seg.b_tile0) thr = fmaxf(thr, cold_start_threshold(acc, k));
                 pool_epilogue_scan<EMAX>(acc, thr, wl_s, wl_i, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
 #endif
                 ks = 0; bt += bstride; cpar ^= 1;
