@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""One-off differential fuzz of the small / medium search paths against the CPU oracle (bit-exact indices and distances):
+random shapes, both metrics, odd workgroup counts, lists and pools, fp16 mode on and off.  usage: python tests/fuzz_small.py [cases] [seed]   (lives under tests/: it uses the oracle as the checker)"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "open-hummingbird-eval_amd"), ROOT]
+import numpy as np, torch
+import oracle
+from hbird_mi.nn.search_hip import HipFlatIndex
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for c in range(n_cases):
+    D = int(rng.choice([32, 64, 96, 100, 384]))
+    M = int(rng.integers(300, 150_000 if D < 384 else 60_000))
+    nq = int(rng.integers(1, 3000))
+    k = int(rng.choice([1, 5, 30, 32, 40, 90]))
+    metric = int(rng.integers(0, 2))
+    G = int(rng.choice([0, 0, 17, 64, 256]))
+    fp16 = bool(rng.integers(0, 2)) and k <= 128
+    bank = rng.standard_normal((M, D), dtype=np.float32); bank /= np.linalg.norm(bank, axis=1, keepdims=True)
+    if rng.integers(0, 2): bank[rng.integers(0, M, size=50)] = bank[0]          # duplicates: ties by id
+    q = (3.0 * rng.standard_normal((nq, D))).astype(np.float32)
+    ix = HipFlatIndex(D, metric, 0); ix.add(torch.from_numpy(bank).cuda()); ix.set_fp16(fp16); ix.set_tuning(G, 0)
+    idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
+    ridx, rdist = oracle.knn_chain_f32(q, bank, k, "dot_product" if metric == 0 else "l2", 0)
+    ok = np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(dist.cpu().numpy().view(np.uint32), rdist.view(np.uint32))
+    bad += not ok
+    print(f"case {c}: M {M} D {D} nq {nq} k {k} metric {metric} G {G} fp16 {fp16} -> {'ok' if ok else 'MISMATCH'} {ix.schedule_info()['slots']} slots", flush=True)
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
