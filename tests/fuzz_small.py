@@ -21,11 +21,13 @@ for c in range(n_cases):
     bank = rng.standard_normal((M, D), dtype=np.float32); bank /= np.linalg.norm(bank, axis=1, keepdims=True)
     if rng.integers(0, 2): bank[rng.integers(0, M, size=50)] = bank[0]          # duplicates: ties by id
     q = (3.0 * rng.standard_normal((nq, D))).astype(np.float32)
+    variant = int(rng.choice([0, 0, 3, 4])); cl = [(0, 0, -1), (0, 0, -1), (2, 2, 4), (2, 4, 16)][int(rng.integers(0, 4))]
     ix = HipFlatIndex(D, metric, 0); ix.add(torch.from_numpy(bank).cuda()); ix.set_fp16(fp16); ix.set_tuning(G, 0)
+    ix.set_variant(variant); ix.set_cluster(*cl)
     idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
     ridx, rdist = oracle.knn_chain_f32(q, bank, k, "dot_product" if metric == 0 else "l2", 0)
     ok = np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(dist.cpu().numpy().view(np.uint32), rdist.view(np.uint32))
     bad += not ok
-    print(f"case {c}: M {M} D {D} nq {nq} k {k} metric {metric} G {G} fp16 {fp16} -> {'ok' if ok else 'MISMATCH'} {ix.schedule_info()['slots']} slots", flush=True)
+    print(f"case {c}: M {M} D {D} nq {nq} k {k} metric {metric} G {G} fp16 {fp16} variant {variant} cluster {cl} -> {'ok' if ok else 'MISMATCH'} {ix.schedule_info()['slots']} slots", flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
