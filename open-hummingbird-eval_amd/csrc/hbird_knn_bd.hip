@@ -224,8 +224,9 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
                 } else if constexpr (WIDE) {
                     // the slot's pool pointers are derived HERE from one laundered scalar (hbird_knn.hip: kept live through
                     // the stage loop they push the loop's own pointers into spilled SGPRs, reloaded in every stage)
-                    int slot_ = seg.slot;
-                    asm volatile("" : "+s"(slot_));
+                    const hb_seg* sp_ = HB_KARG(knn_args, segs) + si;     // boundary-only fields: read again where they are used
+                    asm volatile("" : "+s"(sp_));
+                    const int slot_ = sp_->slot;
                     const int klw = HB_KARG(knn_args, klw);
                     float* ps = HB_KARG(knn_args, state_s) + (size_t)slot_ * HB_QT * klw;
                     unsigned* pi = HB_KARG(knn_args, state_i) + (size_t)slot_ * HB_QT * klw;
@@ -246,14 +247,17 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
 #undef BD_STAGE
         // the run-ahead requests still target the query-fragment registers: drain them while those registers are live
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) :: "memory");
-        if constexpr (CL) { if (w == 0) cl_publish(cs, seg.next_tile0 == 0x7FFFFFFF ? 0x7FFFFFFF : seg.next_tile0 * g8, lane); }   // covers idle units
-        if constexpr (WIDE) pool_end(knn_args_pool_view{HB_KARG(knn_args, state_cnt), HB_KARG(knn_args, state_thr)}, seg.slot, pcnt, thr, myq, lane);
+        const hb_seg* se_ = HB_KARG(knn_args, segs) + si;     // boundary-only fields: read again (not kept in scalars through the loop)
+        asm volatile("" : "+s"(se_));
+        const int e_next = se_->next_tile0, e_slot = se_->slot, e_qt = se_->q_tile;
+        if constexpr (CL) { if (w == 0) cl_publish(cs, e_next == 0x7FFFFFFF ? 0x7FFFFFFF : e_next * g8, lane); }   // covers idle units
+        if constexpr (WIDE) pool_end(knn_args_pool_view{HB_KARG(knn_args, state_cnt), HB_KARG(knn_args, state_thr)}, e_slot, pcnt, thr, myq, lane);
         else {
-            float* wl_s = HB_KARG(knn_args, state_s) + (size_t)seg.slot * HB_QT * HB_KL;
-            unsigned* wl_i = HB_KARG(knn_args, state_i) + (size_t)seg.slot * HB_QT * HB_KL;
+            float* wl_s = HB_KARG(knn_args, state_s) + (size_t)e_slot * HB_QT * HB_KL;
+            unsigned* wl_i = HB_KARG(knn_args, state_i) + (size_t)e_slot * HB_QT * HB_KL;
             for (int e = lane; e < 1024; e += 64) { wl_s[w * 1024 + e] = lst_s[w * 1024 + e]; wl_i[w * 1024 + e] = lst_i[w * 1024 + e]; }
         }
-        if (lane < 32) floor_publish(HB_KARG(knn_args, gthr), seg.q_tile * HB_QT + myq, thr);
+        if (lane < 32) floor_publish(HB_KARG(knn_args, gthr), e_qt * HB_QT + myq, thr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // the ring and the lists are reused by the next segment
     }
