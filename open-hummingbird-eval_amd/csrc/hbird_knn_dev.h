@@ -90,9 +90,9 @@ struct knn16_args {
 #endif
 struct cl_sync {
     int* line;      // progress words of the cluster, one 128-B line per member
-    int* lds;       // 16 words of LDS: [0, HB_CLUSTER_MAX) landing zone of the poll; [8, 11) statistics of this workgroup
-                    // (checks, spins, timeouts: hb_index_cluster_stats) -- in LDS, not in scalars the stage loops are short of
+    int* lds;       // HB_CLUSTER_MAX words of LDS: landing zone of the poll
     int me, cl, lag;
+    int n_checks, n_spins, n_timeouts;   // statistics of this workgroup (hb_index_cluster_stats)
     bool on;
 };
 __device__ __forceinline__ void cl_store(int* p, int v) {
@@ -120,15 +120,11 @@ __device__ __forceinline__ void cl_tick(cl_sync& cs, int now, int lane) {
         // the poll was issued two exchanges ago, ahead of that stage's copies: the per-stage vmcnt wait has covered it
         bool wait = false;
         int spins = 0;
-        if (lane == 0) __hip_atomic_fetch_add(cs.lds + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ++cs.n_checks;
         while (cl_min_landed(cs, lane, wait) < now - cs.lag) {
             wait = true;
-            if (lane == 0) __hip_atomic_fetch_add(cs.lds + 9, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (++spins > HB_CL_SPINS) {   // a member is not running (or not visible): never wait again
-                cs.on = false;
-                if (lane == 0) __hip_atomic_fetch_add(cs.lds + 10, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                break;
-            }
+            ++cs.n_spins;
+            if (++spins > HB_CL_SPINS) { cs.on = false; ++cs.n_timeouts; break; }       // a member is not running (or not visible): never wait again
             __builtin_amdgcn_s_sleep(8);
             cl_poll(cs, lane);
         }
@@ -144,14 +140,14 @@ __device__ __forceinline__ cl_sync cl_init(const int* wg_member, int* prog, int 
     cs.lds = reinterpret_cast<int*>(lds_words);
     cs.me = mem < 0 ? 0 : mem & (HB_CLUSTER_LINE - 1);
     cs.cl = cl; cs.lag = lag;
+    cs.n_checks = cs.n_spins = cs.n_timeouts = 0;
     cs.on = mem >= 0 && lag > 0 && poller;
-    if (poller && (threadIdx.x & 63) < 3) cs.lds[8 + (threadIdx.x & 63)] = 0;
     return cs;
 }
 // end of the kernel: add this workgroup's statistics to the launch's (three words behind the progress lines)
 __device__ __forceinline__ void cl_finish(const cl_sync& cs, int* stats, bool poller, int lane) {
-    if (cs.cl > 1 && poller && lane == 0 && cs.lds[8]) {
-        atomicAdd(stats, cs.lds[8]); atomicAdd(stats + 1, cs.lds[9]); atomicAdd(stats + 2, cs.lds[10]);
+    if (cs.cl > 1 && poller && lane == 0 && cs.n_checks) {
+        atomicAdd(stats, cs.n_checks); atomicAdd(stats + 1, cs.n_spins); atomicAdd(stats + 2, cs.n_timeouts);
     }
 }
 

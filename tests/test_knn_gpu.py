@@ -96,6 +96,30 @@ def test_clustered_schedules_bit_exact(cuda_device, cq, cb, lag, G, panel, k, fp
     assert ix.schedule_info()["cluster"] == [1, 1] and torch.equal(i1, idx) and torch.equal(d1, dist)
 
 
+def test_cluster_soft_sync_holds_the_members_together(cuda_device):
+    """Speed only, so the parity tests cannot see it break: in every kernel that syncs (B-direct fp32, LDS-staged fp32, fp16
+    candidate kernel) and for 4- and 8-member shapes, the members must keep meeting -- progress checks happen all along the
+    search and (almost) nobody gives up waiting.  (A change that moved the sync's counters to LDS once made every member of
+    every 4-member cluster time out at its first wait: same results, 8 ms slower per workgroup.)"""
+    M, D, nq, k = 600_000, 64, 2560, 30
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    bank = torch.nn.functional.normalize(torch.randn((M, D), generator=g, device="cuda"), dim=1)
+    q = 3.0 * torch.randn((nq, D), generator=g, device="cuda")
+    ix = HipFlatIndex(D, 0, 0)
+    ix.add(bank)
+    ref = ix.search(q, k)
+    for variant, fp16 in ((0, False), (4, False), (0, True)):
+        ix.set_variant(variant); ix.set_fp16(fp16)
+        for shape in ((2, 2, 16), (4, 1, 16), (2, 4, 16), (8, 1, 16)):
+            ix.set_cluster(*shape)
+            idx, dist = ix.search(q, k)
+            st = ix.cluster_stats()
+            assert ix.schedule_info()["cluster"] == list(shape[:2])
+            assert torch.equal(idx, ref[0]) and torch.equal(dist, ref[1])
+            assert st["checks"] >= 256 and st["timeouts"] <= 8, (variant, fp16, shape, st)
+    ix.set_cluster(0, 0, -1); ix.set_variant(0); ix.set_fp16(False)
+
+
 def test_incremental_add_and_id_base(cuda_device):
     """Appending in ragged chunks (device and host rows mixed) == adding once; id_base offsets the ids."""
     M, D, nq, k = 3001, 64, 64, 30
