@@ -118,6 +118,8 @@ __device__ __forceinline__ void cl_tick(cl_sync& cs, int now, int lane) {
     if (ph == 4) cl_poll(cs, lane);
     else if (ph == 12) {
         // the poll was issued two exchanges ago, ahead of that stage's copies: the per-stage vmcnt wait has covered it
+        // (keep this loop wave-uniform: with a divergent statement in it -- `if (lane == 0) <count in LDS>` -- hipcc structurised it into
+        // nested exec-masked loops whose inner spin no longer re-polled, and every 4-member cluster timed out on stale words)
         bool wait = false;
         int spins = 0;
         ++cs.n_checks;
