@@ -12,7 +12,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for c in range(n_cases):
     D = int(rng.choice([32, 64, 96, 100, 384]))
-    M = int(rng.integers(300, 150_000 if D < 384 else 60_000))
+    M = int(rng.integers(300, int(os.environ.get("FUZZ_MAX_ROWS", 150_000)) if D < 384 else int(os.environ.get("FUZZ_MAX_ROWS", 150_000)) * 2 // 5))
     nq = int(rng.integers(1, 3000))
     k = int(rng.choice([1, 5, 30, 32, 40, 90]))
     metric = int(rng.integers(0, 2))
