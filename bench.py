@@ -9,8 +9,9 @@ One step = one pass of the hot path over one query batch: query tiling -> exact 
 already resident in HBM.  With N GPUs the bank is row-sharded (10M / N rows per rank, one process per
 GPU), every rank searches all queries on its shard, the per-rank top-k lists are exchanged with ONE packed RCCL
 all-gather per step and merged, and each rank aggregates the labels for its slice of the queries ("strong"
-scaling: total work is fixed).  The exchange of step i (all-gather + merge + aggregation, on a side stream)
-runs under the kNN kernel of step i+1.
+scaling: total work is fixed).  The exchange of step i (all-gather + merge + aggregation) runs on the kNN stream,
+exposed after the kernel: the persistent kNN kernel owns every CU's registers and LDS, so nothing could run beside it
+(DESIGN.md section 5).  HBIRD_BENCH_OVERLAP=1 (experiments only) moves the exchange to a side stream.
 
 `python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks itself (a child
 `python -m torch.distributed.run --nproc-per-node N bench.py ...`, before this process touches a GPU); under
@@ -58,7 +59,10 @@ def parse():
     ap.add_argument("--fp16", action="store_true", help="use_fp16: fp16 candidate pass + exact fp32 re-rank")
     ap.add_argument("--variant", type=int, default=0, help="kNN kernel variant (0: 8 waves, 1: 4 waves)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 --pmc passes behind roofline.traffic")
-    ap.add_argument("--no-overlap", action="store_true", help="N > 1: run the exchange on the kNN stream (no side stream)")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: keep the exchange on the kNN stream even when "
+                    "HBIRD_BENCH_OVERLAP=1 asks for the side stream (the default is the kNN stream anyway)")
+    ap.add_argument("--checksum", action="store_true", help="add label_hat_checksum (bit sum + float64 sum of the last step's "
+                    "label_hat over all queries): equal for any number of ranks")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # one untimed step under rocprofv3 --pmc
     return ap.parse_args()
 
@@ -86,7 +90,12 @@ def launch_ranks(a):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
     env = dict(os.environ)
+    # The ranks exchange device buffers through RCCL, whose intra-node transport maps its peers' buffers with HIP IPC
+    # handles.  The host driver of this pool only supports dmabuf IPC: with the legacy mode (the ROCr default)
+    # hipIpcGetMemHandle fails with "invalid argument" at communicator set-up.  The image exports the variable already;
+    # a launcher that scrubs the environment must not lose it.
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("NCCL_DEBUG", "VERSION")      # RCCL prints its version line to stderr: the run's own record of the backend
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
     raise SystemExit(subprocess.call(cmd, env=env))
 
@@ -140,6 +149,15 @@ def cpu_baseline(D, k, M_total):
     for i in range(0, nqt, 256):
         (qb[i:i + 256] @ bb.T).topk(k, dim=1)
     dt_t = time.time() - t1
+    # the contraction alone (no k-select): what the host's BLAS sustains on this shape -- the CPU's own ceiling for the
+    # dominant term, so that the un-tuned port above can be read against it
+    qm = qb[:4096].contiguous()
+    (qm[:256] @ bb.T)
+    t3 = time.time()
+    for i in range(0, 4096, 1024):
+        (qm[i:i + 1024] @ bb.T)
+    dt_m = time.time() - t3
+    mm_tflops = 2.0 * 4096 * ms * D / dt_m / 1e12
     # the reference-equivalent CPU stage after the search (hbird_eval.py:631-637, 575-609, 235-243), one 37 x 37 image
     S, C = 37, 151
     idx1 = rng.integers(0, ms, size=(S * S, k))
@@ -154,6 +172,7 @@ def cpu_baseline(D, k, M_total):
         "unit": "query-patches/s",
         "cores": oracle.num_threads(),
         "kind": "port",
+        "tuned": False,                             # the chain oracle is a parity tool (one fmaf chain per score), not a tuned SGEMM
         "extrapolated": True,                       # value = measured sample rate x (sample rows / bank rows)
         "measured_on_sample": {"value": qps_sample, "unit": "query-patches/s", "bank_rows": ms, "queries": nqs, "seconds": round(dt, 2)},
         "sample": f"oracle exact fp32 brute force on {nqs} queries x {ms} rows x {D} dims took {dt:.2f}s "
@@ -161,6 +180,9 @@ def cpu_baseline(D, k, M_total):
                   f"backend) is not installed on this image",
         "torch_mm_topk": {"value": nqt / dt_t * ms / M_total, "unit": "query-patches/s", "threads": _t.get_num_threads(),
                           "sample_seconds": round(dt_t, 2)},
+        "torch_mm_only": {"tflops": mm_tflops, "value": 4096 / dt_m * ms / M_total, "unit": "query-patches/s (no k-select)",
+                          "threads": _t.get_num_threads(), "sample_seconds": round(dt_m, 2),
+                          "what": f"fp32 [4096,{D}] x [{D},{ms}] products only: the host BLAS ceiling for the contraction"},
         "post_knn_stage": {"value": S * S / dt_p, "unit": "query-patches/s",
                            "what": "gather + cross-attention + bilinear upsample + argmax of one 37x37-token image, C=151"},
     }
@@ -276,6 +298,7 @@ def main():
     td = torch.distributed
     backend = None
     if dist_on:
+        os.environ.setdefault("NCCL_DEBUG", "VERSION")      # RCCL's version line on stderr (read at communicator set-up)
         backend = "gloo" if one_gpu else "nccl"
         kw = {} if one_gpu else {"device_id": device}
         if env_world is None:
@@ -367,8 +390,9 @@ def main():
     sync()
     index.set_timing(True)
     t0 = time.time()
+    last_out = None
     for i in range(a.steps):
-        step(i)
+        last_out = step(i)
         knn_ms.append(index.last_knn_ms())        # waits for this step's kNN kernel (HIP events on its stream)
         if dist_on and not overlap:
             ev_done[i & 1].synchronize()
@@ -377,15 +401,29 @@ def main():
     dt = time.time() - t0
     index.set_timing(False)
     per_rank = None
+    checksum = None
+    if a.checksum and last_out is not None:
+        # every query's label_hat row is computed by exactly one rank from the merged (rank-count independent) neighbour
+        # list, so both sums are the same for any number of ranks: int64 sum of the fp32 bit patterns + float64 sum
+        lo_ = last_out.contiguous()
+        cs = torch.stack([lo_.view(torch.int32).to(torch.int64).sum(), lo_.double().sum().view(torch.int64)])
+        if world > 1:
+            parts = torch.empty(world * 2, device=device, dtype=torch.int64)
+            td.all_gather_into_tensor(parts, cs)
+            parts = parts.view(world, 2)
+            checksum = {"bits": int(parts[:, 0].sum().item()), "sum": float(parts[:, 1].contiguous().view(torch.float64).sum().item()),
+                        "rows_per_rank": [(nq * (r + 1)) // world - (nq * r) // world for r in range(world)]}
+        else:
+            checksum = {"bits": int(cs[0].item()), "sum": float(cs[1:].view(torch.float64).item()), "rows_per_rank": [nq]}
     if dist_on:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = float(t.item())
-        mine = torch.tensor([float(np.mean(knn_ms)), float(np.mean(xchg_ms)) if xchg_ms else -1.0, float(hi - lo)],
+        mine = torch.tensor([float(np.mean(knn_ms)), float(np.mean(xchg_ms)) if xchg_ms else -1.0, float(hi - lo), float(dev_index)],
                             device=device, dtype=torch.float64)
-        allr = torch.empty(world * 3, device=device, dtype=torch.float64)
+        allr = torch.empty(world * 4, device=device, dtype=torch.float64)
         td.all_gather_into_tensor(allr, mine)
-        per_rank = allr.view(world, 3).cpu().tolist()
+        per_rank = allr.view(world, 4).cpu().tolist()
 
     if rank == 0:
         kms = float(np.mean(knn_ms))
@@ -414,10 +452,12 @@ def main():
                          "algorithmic_flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": 4.0 * (hi - lo) * D + 4.0 * nq * D + 12.0 * nq * k},
         }
+        if checksum is not None:
+            res["label_hat_checksum"] = checksum
         if dist_on:
             res["multi_gpu"] = {
                 "backend": backend + (" (RCCL)" if backend == "nccl" else " (test mode, ranks share cuda:0)"),
-                "world_size": td.get_world_size(), "rows_per_rank": [int(r[2]) for r in per_rank],
+                "world_size": td.get_world_size(), "device_per_rank": [int(r[3]) for r in per_rank], "rows_per_rank": [int(r[2]) for r in per_rank],
                 "knn_ms_per_rank": [round(r[0], 3) for r in per_rank],
                 "exchange_ms_per_rank": None if overlap else [round(r[1], 3) for r in per_rank],
                 "exchange": "one packed all-gather of (id int64, score fp32) [nq,k] per rank + in-place k-way merge + "

@@ -1,5 +1,6 @@
 // Bank-build kernels: K2 (patch soft labels) and K3 (bounded-memory patch sampling) of SURVEY.md 2.3.
 #include "hbird_internal.h"
+#include <mutex>
 
 // K2 -- reference hbird_eval.py:309-310 (`y[y == 255] = 0`, optional), 555-573 (`_patchify_gt`) and
 // 319-320 (`F.one_hot(patches, C).float().mean(dim=3)`): per-patch class histogram / P, computed
@@ -43,15 +44,24 @@ int hb_launch_patch_label_hist(const int64_t* y, int64_t B, int H, int W, int ps
     if ((size_t)C * 16 > 60000) return hb_fail("hb_patch_label_hist: too many classes");
     // out-of-range classes: F.one_hot of the reference raises (hbird_eval.py:319), and so does this call -- the flag is
     // read back after the kernel (one stream synchronisation per training batch, as one_hot's own range check costs)
+    // one persistent error word per device (a 4-byte hipMalloc each, never freed: nothing to leak on a failing call)
+    static std::mutex mu;
+    static int* words[64] = {nullptr};
+    int dev = 0;
+    HB_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return hb_fail("hb_patch_label_hist: device index out of range");
     int* err = nullptr;
-    HB_HIP(hipMallocAsync((void**)&err, 4, s));
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!words[dev]) HB_HIP(hipMalloc((void**)&words[dev], 4));
+        err = words[dev];
+    }
     HB_HIP(hipMemsetAsync(err, 0, 4, s));
     patch_label_hist_kernel<<<dim3((unsigned)((np + 3) / 4)), dim3(256), (size_t)C * 16, s>>>(y, np, H, W, ps, C, map255, out, err);
     HB_HIP(hipGetLastError());
     int bad = 0;
     HB_HIP(hipMemcpyAsync(&bad, err, 4, hipMemcpyDeviceToHost, s));
     HB_HIP(hipStreamSynchronize(s));
-    HB_HIP(hipFreeAsync(err, s));
     if (bad) return hb_fail("hb_patch_label_hist: class values must be in [0, " + std::to_string(C) + ") (out-of-range class in the mask)");
     return 0;
 }

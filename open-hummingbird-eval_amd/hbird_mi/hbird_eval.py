@@ -26,7 +26,7 @@ from hbird_mi import dist as hdist
 from hbird_mi import ops
 from hbird_mi import tiling
 from hbird_mi.models import FeatureExtractor, FeatureExtractorSimple
-from hbird_mi.nn.search_hip import HipFlatIndex, MAX_K, merge_topk, merge_topk_packed, _METRICS
+from hbird_mi.nn.search_hip import HipFlatIndex, HipMultiIndex, MAX_K, merge_topk, merge_topk_packed, _METRICS
 from hbird_mi.utils.eval_metrics import PredsmIoU
 
 try:
@@ -91,16 +91,25 @@ class HbirdEvaluation:
             raise ValueError(f"Unsupported distance measure: {distance}")                 # search_faiss.py:48
         self.metric = _METRICS[distance]
         gpu_ids = nn_params.get("gpu_ids")
+        n_dev = torch.cuda.device_count()
         if gpu_ids is not None:
-            n = torch.cuda.device_count()
             for g in gpu_ids:
-                if g >= n or g < 0:
-                    raise ValueError(f"Invalid GPU ID: {g}. Available GPUs: 0-{n - 1}")    # search_faiss.py:25
-            if len(set(gpu_ids)) > 1 and self.world == 1:
-                logger.warning("nn_params['gpu_ids']=%s lists %d GPUs, but the device-resident evaluator keeps the bank on "
-                               "ONE GPU per process (%s): run one rank per GPU (torchrun) with nn_params['idx_shard']=True "
-                               "to use them all, or hbird_mi.nn.search_hip.NearestNeighborSearchHIP for a multi-GPU "
-                               "index in one process", list(gpu_ids), len(set(gpu_ids)), self.gpu_device)
+                if g >= n_dev or g < 0:
+                    raise ValueError(f"Invalid GPU ID: {g}. Available GPUs: 0-{n_dev - 1}")    # search_faiss.py:25
+        # GPUs of THIS process.  One process per GPU under torch.distributed; otherwise the reference's call shape
+        # (hbird_eval.py:267-281 -> search_faiss.py:19-20, 50-76): every listed GPU, ALL of them by default, as row shards
+        # (idx_shard=True) or replicas -- with the extractor's GPU first, the home of labels, merge and aggregation.
+        if self.world > 1:
+            self.local_gpus = [self.gpu]
+        else:
+            ids = [int(g) for g in gpu_ids] if gpu_ids is not None else list(range(n_dev))
+            if self.gpu in ids:
+                ids.remove(self.gpu)
+                ids.insert(0, self.gpu)
+            self.local_gpus = ids or [self.gpu]
+            if self.local_gpus[0] != self.gpu:
+                self.gpu = self.local_gpus[0]
+                self.gpu_device = torch.device("cuda", self.gpu)
         if not 1 <= n_neighbours <= MAX_K:
             raise ValueError(f"n_neighbours={n_neighbours} outside the supported range [1, {MAX_K}]")
         # idx_shard keeps the reference's default (False, search_faiss.py:7): with several ranks that means a full bank
@@ -110,7 +119,10 @@ class HbirdEvaluation:
         if self.world > 1:
             logger.warning("torch.distributed world of %d ranks: bank %s (nn_params['idx_shard']=%s)", self.world,
                            "row-sharded over the ranks" if self.sharded else "replicated on every rank", self.sharded)
-            if self.sharded:
+            if self.sharded or self.memory_size is not None:
+                # sharded: every rank replays the ONE random stream of the reference; replicas with a bounded memory:
+                # every rank samples the SAME patches (hbird_eval.py:500), so that all replicas are the same bank and the
+                # all-reduced mIoU is that of a single process, whatever the ranks' own seeds were
                 self._align_cpu_rng()
 
         eval_spatial_resolution = self.feature_extractor.eval_spatial_resolution
@@ -121,19 +133,28 @@ class HbirdEvaluation:
                 raise ValueError("dataset_size must be provided when memory_size is set.")  # hbird_eval.py:144-145
             denom = dataset_size * self.augmentation_epoch
             self.num_sampled_features = max(1, self.memory_size // max(1, denom))           # 146-147
+            # rows the build will fill (the reference preallocates memory_size and trims, 156-172): what shards split
+            self._planned_rows = min(self.memory_size, self.num_sampled_features * max(1, denom))
 
-        self.index = HipFlatIndex(self.feature_extractor.d_model, self.metric, self.gpu)
+        if len(self.local_gpus) > 1:
+            self.index = HipMultiIndex(self.feature_extractor.d_model, self.metric, self.local_gpus,
+                                       shard=bool(nn_params.get("idx_shard", False)))
+            logger.info("one process, %d GPUs %s: bank %s", len(self.local_gpus), self.local_gpus,
+                        "row-sharded (faiss.IndexShards)" if self.index.shard else "replicated (faiss.IndexReplicas)")
+        else:
+            self.index = HipFlatIndex(self.feature_extractor.d_model, self.metric, self.gpu)
         self.index.set_num_classes(num_classes)
-        if nn_params.get("use_fp16", False):                          # search_faiss.py:40; certified-exact fast mode
-            self.index.set_fp16(True)
+        if nn_params.get("use_fp16", False):          # search_faiss.py:40; certified-exact fast mode, only where it pays
+            self.index.set_fp16(2)                    # (banks of >= 131,072 rows), like the plugin: never slower than fp32
         self.id_base = 0            # global id of this rank's first bank row
         self.total_rows = 0         # bank rows over all ranks
         self._label_table = None    # all-gathered labels / norms in sharded mode
-        filled = self._create_memory(train_loader, num_classes=self.num_classes,
-                                     eval_spatial_resolution=eval_spatial_resolution)
-        logger.info("Memory rows: %s", filled)
-        self._save_memory()
-        self._finalize_shards()
+        with torch.cuda.device(self.gpu_device):
+            filled = self._create_memory(train_loader, num_classes=self.num_classes,
+                                         eval_spatial_resolution=eval_spatial_resolution)
+            logger.info("Memory rows: %s", filled)
+            self._save_memory()
+            self._finalize_shards()
 
     def _align_cpu_rng(self) -> None:
         """Sharded bank build: every rank replays the reference's single CPU random stream (the sampling noise of
@@ -159,7 +180,7 @@ class HbirdEvaluation:
         else:
             own_lo, own_hi = 0, float("inf")
         if self.memory_size is not None:
-            self.index.reserve(max(1, self.memory_size // max(1, self.world if self.sharded else 1)))
+            self.index.reserve(max(1, self._planned_rows // max(1, self.world if self.sharded else 1)))
         rows_before_me = 0
         flat = 0
         presized = self.memory_size is not None
@@ -310,13 +331,18 @@ class HbirdEvaluation:
             fm = torch.load(self.f_mem_p, mmap=True)
             lm = torch.load(self.l_mem_p, mmap=True)
             lo, hi = hdist.shard_range(fm.shape[0], self.rank, self.world) if self.sharded else (0, fm.shape[0])
-            self.index.reset()
-            self.index.reserve(max(1, hi - lo))
-            self.index.add(fm[lo:hi].to(self.gpu_device), normalize=False)
-            self.index.add_labels(lm[lo:hi].to(self.gpu_device))
-            self._finalize_shards()
+            with torch.cuda.device(self.gpu_device):
+                self.index.reset()
+                self.index.reserve(max(1, hi - lo))
+                self.index.add(fm[lo:hi].to(self.gpu_device), normalize=False)
+                self.index.add_labels(lm[lo:hi].to(self.gpu_device))
+                self._finalize_shards()
             logger.info("Loaded memory from disk.")
             return True
+        for p in (self.f_mem_p, self.l_mem_p):
+            if p is not None and os.path.isfile(p + ".rank0"):
+                logger.warning("%s.rankN: per-rank bank files of an earlier version are no longer read -- a sharded bank is "
+                               "saved as ONE reference-format file pair now (INTEGRATION.md); rebuilding", p)
         logger.warning("Memory files not found or paths not provided; skipping load.")
         return False
 
@@ -372,7 +398,7 @@ class HbirdEvaluation:
         S = eval_spatial_resolution
         knns, knns_labels, knns_ca_labels = [], [], []
         logger.info("Starting evaluation loop...")
-        with torch.no_grad():
+        with torch.no_grad(), torch.cuda.device(self.gpu_device):
             if self.sharded:
                 self._evaluate_sharded(val_loader, S, metric, return_knn_details, knns, knns_labels, knns_ca_labels,
                                        window)

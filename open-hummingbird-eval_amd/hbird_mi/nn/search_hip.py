@@ -274,6 +274,303 @@ def merge_topk_packed(recv: torch.Tensor, part_bytes: int, parts: int, nq: int, 
     return idx, dist
 
 
+class HipMultiIndex:
+    """Several `hb_index_t` of ONE process behind the `HipFlatIndex` interface: what the reference's single-process call
+    does with faiss (search_faiss.py:50-76).  `shard=True` = faiss.IndexShards (53-63): contiguous row ranges with
+    successive ids, one per listed GPU, every GPU searches all queries, the [nq, k] lists are peer-copied to the first
+    GPU and merged there on the ordering scores (the single-index bits).  `shard=False` = faiss.IndexReplicas (65-74):
+    every GPU holds all rows, the queries are split.  One host thread per index (faiss `threaded=True`, 57).
+
+    The FIRST listed device is the home device: queries arrive there, results are returned there, and the label rows
+    and bank-row norms of ALL rows live there (the aggregation runs on it; 6.2 GB at BASELINE cfg-3).  A GPU may be
+    listed more than once (several indices on one device: how the 1-GPU test boxes exercise this path)."""
+
+    def __init__(self, d: int, metric: int, devices, shard: bool):
+        assert len(devices) >= 1
+        self.d, self.metric, self.devices, self.shard = int(d), int(metric), [int(g) for g in devices], bool(shard)
+        self.device = self.devices[0]
+        self.home = torch.device("cuda", self.device)
+        self.indexes = [HipFlatIndex(d, metric, g) for g in self.devices]
+        self.agg = HipFlatIndex(d, metric, self.device)        # row-less handle: aggregation against the home tables
+        self._quota = None              # shard mode: planned rows per shard (reserve); None = everything into the first
+        self._labels = None             # [cap, C] on the home device, co-indexed with the global row ids
+        self._nlab = 0
+        self._norms = None              # [ntotal] on the home device (rebuilt lazily after adds)
+        self._pool = None
+        self._c = None
+        self._fallbacks = 0
+
+    # -- bookkeeping ------------------------------------------------------------------------------------------------
+    def close(self):
+        for ix in self.indexes + [self.agg]:
+            ix.close()
+        if self._pool is not None:
+            self._pool.shutdown(wait=False)
+            self._pool = None
+
+    @property
+    def ntotal(self) -> int:
+        return sum(ix.ntotal for ix in self.indexes) if self.shard else self.indexes[0].ntotal
+
+    @property
+    def shard_rows(self):
+        return [ix.ntotal for ix in self.indexes]
+
+    @property
+    def shard_bases(self):
+        if not self.shard:
+            return [0] * len(self.indexes)
+        out, b = [], 0
+        for ix in self.indexes:
+            out.append(b); b += ix.ntotal
+        return out
+
+    @property
+    def num_classes(self) -> int:
+        if self._c is None:
+            raise RuntimeError("labels were not added to this index")
+        return self._c
+
+    def set_num_classes(self, c: int):
+        self._c = int(c)
+
+    def use_current_stream(self):
+        """Work on the home device follows the caller's current stream there; the per-GPU searches run on their worker
+        threads' streams and are synchronised before their lists are handed over."""
+        self.agg.use_current_stream()
+
+    def set_fp16(self, enable):
+        for ix in self.indexes:
+            ix.set_fp16(enable)
+
+    def last_fp16_fallbacks(self) -> int:
+        return self._fallbacks
+
+    def schedule_info(self) -> dict:
+        return self.indexes[0].schedule_info()
+
+    def reserve(self, n: int):
+        """Plan for n rows in all: shard mode cuts them into equal contiguous ranges (the last shard also takes whatever
+        arrives beyond the plan)."""
+        n = max(1, int(n))
+        if self.shard:
+            per = (n + len(self.indexes) - 1) // len(self.indexes)
+            self._quota = per
+            for ix in self.indexes:
+                ix.reserve(per)
+        else:
+            for ix in self.indexes:
+                ix.reserve(n)
+
+    def reset(self):
+        for ix in self.indexes:
+            ix.reset()
+        self._nlab, self._norms = 0, None
+        self.agg.set_label_table(None, None)
+
+    # -- bank build -------------------------------------------------------------------------------------------------
+    def _on(self, i):
+        return torch.cuda.device(torch.device("cuda", self.devices[i]))
+
+    def _put(self, i, x, normalize):
+        """Rows x (CUDA tensor on any device, CPU tensor or numpy) appended to index i on ITS device and stream."""
+        ix = self.indexes[i]
+        with self._on(i):
+            if isinstance(x, torch.Tensor) and x.is_cuda and x.device.index != self.devices[i]:
+                x = x.to(torch.device("cuda", self.devices[i]))       # peer copy (xGMI), ordered by torch's streams
+            ix.use_current_stream()
+            ix.add(x, normalize=normalize)
+
+    def add(self, x, normalize: bool = False):
+        self._norms = None
+        n = x.shape[0]
+        if not self.shard:
+            for i in range(len(self.indexes)):
+                self._put(i, x, normalize)
+            return
+        lo = 0
+        while lo < n:
+            i = len(self.indexes) - 1
+            if self._quota is None:
+                i = 0
+            else:
+                for j, ix in enumerate(self.indexes[:-1]):
+                    if ix.ntotal < self._quota:
+                        i = j
+                        break
+            room = n - lo
+            if self._quota is not None and i < len(self.indexes) - 1:
+                room = min(room, self._quota - self.indexes[i].ntotal)
+            self._put(i, x[lo:lo + room], normalize)
+            lo += room
+
+    def add_labels(self, lab):
+        """label_memory rows (hbird_eval.py:329, 354) of the rows just added, in global row order, on the home device."""
+        if not isinstance(lab, torch.Tensor):
+            lab = torch.from_numpy(np.ascontiguousarray(lab, dtype=np.float32))
+        lab = lab.detach().float()
+        n, c = lab.shape
+        self._c = int(c)
+        need = self._nlab + n
+        if self._labels is None or self._labels.shape[0] < need or self._labels.shape[1] != c:
+            planned = (self._quota * len(self.indexes)) if (self.shard and self._quota) else 0
+            cap = max(need, planned, 0 if self._labels is None else self._labels.shape[0] * 3 // 2)
+            grown = torch.empty((cap, c), dtype=torch.float32, device=self.home)
+            if self._nlab:
+                grown[:self._nlab] = self._labels[:self._nlab]
+            self._labels = grown
+        self._labels[self._nlab:need] = lab.to(self.home)
+        self._nlab = need
+        self._norms = None
+
+    def _tables(self):
+        """(labels [ntotal, C], norms [ntotal]) on the home device, handed to the aggregation handle."""
+        if self._norms is None:
+            n = self.ntotal
+            with torch.cuda.device(self.home):
+                if self.shard:
+                    parts = []
+                    for i, ix in enumerate(self.indexes):
+                        with self._on(i):
+                            ix.use_current_stream()
+                            nr = ix.copy_norms()
+                            torch.cuda.current_stream(nr.device).synchronize()
+                        parts.append(nr.to(self.home))
+                    self._norms = torch.cat(parts) if parts else torch.zeros(0, device=self.home)
+                else:
+                    with self._on(0):
+                        self.indexes[0].use_current_stream()
+                        self._norms = self.indexes[0].copy_norms()
+                        torch.cuda.current_stream(self.home).synchronize()
+                if self._labels is not None and self._nlab >= n and n > 0:
+                    self.agg.set_label_table(self._labels[:n], self._norms, 0)
+        return (None if self._labels is None else self._labels[:self.ntotal]), self._norms
+
+    def copy_norms(self) -> torch.Tensor:
+        return self._tables()[1]
+
+    # -- search -----------------------------------------------------------------------------------------------------
+    def _threads(self):
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=len(self.indexes), thread_name_prefix="hbird-gpu")
+        return self._pool
+
+    def _search(self, q, k: int, id_base: int, scores: bool):
+        if isinstance(q, torch.Tensor) and q.is_cuda:
+            q = q.detach().float().contiguous()
+        else:
+            q = torch.as_tensor(np.ascontiguousarray(q.detach().cpu().numpy() if isinstance(q, torch.Tensor) else q,
+                                                     dtype=np.float32)).to(self.home)
+        n = len(self.indexes)
+        nq = q.shape[0]
+        bases = self.shard_bases
+        # q is complete before other devices' streams (and the workers' own streams on q's device) read it
+        torch.cuda.current_stream(q.device).synchronize()
+
+        def run(i):
+            index, dev = self.indexes[i], torch.device("cuda", self.devices[i])
+            with torch.cuda.device(dev):
+                if self.shard:
+                    qi = q if dev == q.device else q.to(dev)
+                else:
+                    a, b = (nq * i) // n, (nq * (i + 1)) // n       # replicas: a slice of the queries each
+                    qi = q[a:b] if dev == q.device else q[a:b].to(dev)
+                index.use_current_stream()
+                # shards always return ordering scores: the merge must see what the single index orders by
+                idx, d = (index.search_scores if (self.shard or scores) else index.search)(qi.contiguous(), k, id_base + bases[i])
+                fb = index.last_fp16_fallbacks()
+                torch.cuda.current_stream(dev).synchronize()
+                idx, d = idx.to(self.home), d.to(self.home)         # peer copy of the [nq, k] lists (xGMI)
+                # the copy was enqueued on THIS thread's current stream of the home device, the caller merges on its own:
+                # the lists must have landed before the worker hands them over
+                torch.cuda.current_stream(self.home).synchronize()
+                return idx, d, fb
+
+        parts = list(self._threads().map(run, range(n)))
+        self._fallbacks = sum(p[2] for p in parts)
+        with torch.cuda.device(self.home):
+            if not self.shard:
+                return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+            idx, sc = merge_topk(torch.stack([p[1] for p in parts]), torch.stack([p[0] for p in parts]), 0)
+            if scores:
+                return idx, sc
+            qh = q if q.device == self.home else q.to(self.home)
+            self.agg.use_current_stream()
+            return idx, self.agg.distances_from_scores(qh, sc.contiguous())
+
+    def search(self, q, k: int, id_base: int = 0, out=None):
+        host = not (isinstance(q, torch.Tensor) and q.is_cuda)
+        idx, dist = self._search(q, k, id_base, False)
+        if out is not None:
+            out[0].copy_(idx); out[1].copy_(dist)
+            return out
+        return (idx.cpu().numpy(), dist.cpu().numpy()) if host else (idx, dist)
+
+    def search_scores(self, q, k: int, id_base: int = 0, out=None):
+        idx, sc = self._search(q, k, id_base, True)
+        if out is not None:
+            out[0].copy_(idx); out[1].copy_(sc)
+            return out
+        return idx, sc
+
+    def distances_from_scores(self, q, scores):
+        return self.agg.distances_from_scores(q, scores)
+
+    def aggregate(self, q, idx, dist, beta: float = 0.02, id_base: int = 0):
+        self._tables()
+        with torch.cuda.device(self.home):
+            self.agg.use_current_stream()
+            return self.agg.aggregate(q.to(self.home), idx, dist, beta=beta, id_base=id_base)
+
+    def search_aggregate(self, q, k: int, beta: float = 0.02, id_base: int = 0, want_neighbours: bool = False):
+        """K4 on every GPU, merge on the home device, K5 there (hb_index_aggregate on the merged lists)."""
+        host = not (isinstance(q, torch.Tensor) and q.is_cuda)
+        if host:
+            q = (q if isinstance(q, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32))).to(self.home)
+        idx, dist = self._search(q, k, id_base, False)
+        out = self.aggregate(q.float().contiguous(), idx, dist, beta=beta, id_base=id_base)
+        if host:
+            out, idx, dist = out.cpu().numpy(), idx.cpu().numpy(), dist.cpu().numpy()
+        return (out, idx, dist) if want_neighbours else out
+
+    # -- row access (return_knn_details, persistence) -------------------------------------------------------------------
+    def reconstruct(self, ids, id_base: int = 0):
+        host = not (isinstance(ids, torch.Tensor) and ids.is_cuda)
+        ids_h = (torch.as_tensor(np.asarray(ids)) if host else ids).to(self.home).to(torch.int64).contiguous().view(-1)
+        if not self.shard:
+            with self._on(0):
+                self.indexes[0].use_current_stream()
+                out = self.indexes[0].reconstruct(ids_h, id_base)
+        else:
+            out = torch.zeros((ids_h.numel(), self.d), dtype=torch.float32, device=self.home)
+            bases = self.shard_bases
+            for i, ix in enumerate(self.indexes):
+                lo = id_base + bases[i]
+                own = (ids_h >= lo) & (ids_h < lo + ix.ntotal)
+                if ix.ntotal == 0:
+                    continue
+                with self._on(i):
+                    dev = torch.device("cuda", self.devices[i])
+                    mine = torch.where(own, ids_h, torch.full_like(ids_h, -1)).to(dev)
+                    ix.use_current_stream()
+                    part = ix.reconstruct(mine, lo)                 # rows of other shards (id -1) come back as zeros
+                    torch.cuda.current_stream(dev).synchronize()
+                out += part.to(self.home)
+        return out.cpu().numpy() if host else out
+
+    def gather_labels(self, ids):
+        from hbird_mi import ops
+        host = not (isinstance(ids, torch.Tensor) and ids.is_cuda)
+        ids_h = (torch.as_tensor(np.asarray(ids)) if host else ids).to(self.home).to(torch.int64).contiguous().view(-1)
+        with torch.cuda.device(self.home):
+            out = ops.gather_rows(self._labels[:self._nlab], ids_h)
+        return out.cpu().numpy() if host else out
+
+    def set_label_table(self, labels, norms, id_base: int = 0):
+        raise RuntimeError("HipMultiIndex keeps its own label table on the home device")
+
+
 class NearestNeighborSearchHIP(NearestNeighborSearchBase):
     """Exact flat search on MI355X behind the reference's plugin interface.
 
@@ -331,11 +628,14 @@ class NearestNeighborSearchHIP(NearestNeighborSearchBase):
     def _initialize_index(self):
         if self.distance_measure not in _METRICS:
             raise ValueError(f"Unsupported distance measure: {self.distance_measure}")   # search_faiss.py:48
-        out = []
-        for g in self.local_gpus:
-            index = HipFlatIndex(self.embed_d, _METRICS[self.distance_measure], g)
+        self.multi = None
+        if len(self.local_gpus) > 1:
+            self.multi = HipMultiIndex(self.embed_d, _METRICS[self.distance_measure], self.local_gpus, shard=bool(self.idx_shard))
+            out = self.multi.indexes
+        else:
+            out = [HipFlatIndex(self.embed_d, _METRICS[self.distance_measure], self.local_gpus[0])]
+        for index in out:
             index.set_fp16(2 if self.use_fp16 else 0)                                   # search_faiss.py:40; only where it pays
-            out.append(index)
         return out
 
     def _add_features_to_index(self, feature_memory):
@@ -346,23 +646,10 @@ class NearestNeighborSearchHIP(NearestNeighborSearchBase):
             per = (M + self.world - 1) // self.world
             lo, hi = min(M, self.rank * per), min(M, (self.rank + 1) * per)
         self.id_base = lo
-        n = len(self.indexes)
-        self.shard_bases = []
-        for i, index in enumerate(self.indexes):
-            if self.idx_shard and n > 1:
-                per = (hi - lo + n - 1) // n
-                a, b = min(hi, lo + i * per), min(hi, lo + (i + 1) * per)
-            else:
-                a, b = lo, hi                                   # replicas (or a single index): all local rows
-            self.shard_bases.append(a)
-            index.reserve(max(b - a, 1))
-            index.add(feature_memory[a:b])
-
-    def _threads(self):
-        if self._pool is None:
-            from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=len(self.indexes), thread_name_prefix="hbird-gpu")
-        return self._pool
+        target = self.multi if self.multi is not None else self.index
+        target.reserve(max(hi - lo, 1))       # several local GPUs + idx_shard: equal contiguous ranges, successive ids
+        target.add(feature_memory[lo:hi])
+        self.shard_bases = [lo + b for b in self.multi.shard_bases] if self.multi is not None else [lo]
 
     def find_nearest_neighbors(self, q, k=None):
         if k is None:
@@ -373,46 +660,18 @@ class NearestNeighborSearchHIP(NearestNeighborSearchBase):
             idx, dist = self._search_device(q, k)
             return idx, dist
         q_np = q.cpu().numpy() if isinstance(q, torch.Tensor) else np.asarray(q)   # search_faiss.py:88
-        if (self.idx_shard and self.world > 1) or len(self.indexes) > 1:
+        if (self.idx_shard and self.world > 1) or self.multi is not None:
             idx, dist = self._search_device(torch.from_numpy(np.ascontiguousarray(q_np, dtype=np.float32)).cuda(self.gpu), k)
             return idx.cpu().numpy(), dist.cpu().numpy()
         indices, distances = self.index.search(q_np, k, self.id_base)
         return indices, distances                                                  # (I, D) order: search_faiss.py:89-90
 
     def _search_local(self, q: torch.Tensor, k: int, id_base_unused: int = 0, scores: bool = False):
-        """All local GPUs on q (a CUDA tensor on the first one) -> (idx, dist | ordering scores) on the first GPU."""
-        n = len(self.indexes)
-        if n == 1:
-            self.index.use_current_stream()
-            return (self.index.search_scores if scores else self.index.search)(q, k, self.shard_bases[0])
-        dev0 = torch.device("cuda", self.local_gpus[0])
-        torch.cuda.current_stream(dev0).synchronize()            # q is complete before other devices' streams read it
-        nq = q.shape[0]
-
-        def run(i):
-            index, g = self.indexes[i], self.local_gpus[i]
-            dev = torch.device("cuda", g)
-            with torch.cuda.device(dev):
-                if self.idx_shard:
-                    qi = q if dev == q.device else q.to(dev)
-                else:
-                    a, b = (nq * i) // n, (nq * (i + 1)) // n       # replicas: a slice of the queries each
-                    qi = q[a:b] if dev == q.device else q[a:b].to(dev)
-                index.use_current_stream()
-                # shards always return ordering scores: the merge must see what the single index orders by
-                idx, d = (index.search_scores if (self.idx_shard or scores) else index.search)(qi.contiguous(), k, self.shard_bases[i])
-                torch.cuda.current_stream(dev).synchronize()
-                return idx.to(dev0), d.to(dev0)                    # peer copy of the [nq, k] lists (xGMI)
-
-        parts = list(self._threads().map(run, range(n)))
-        with torch.cuda.device(dev0):
-            if not self.idx_shard:
-                return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
-            idx, sc = merge_topk(torch.stack([p[1] for p in parts]), torch.stack([p[0] for p in parts]), 0)
-            if scores:
-                return idx, sc
-            self.index.use_current_stream()
-            return idx, self.index.distances_from_scores(q if q.device == dev0 else q.to(dev0), sc.contiguous())
+        """All local GPUs on q (a CUDA tensor) -> (idx, dist | ordering scores) on the first GPU."""
+        if self.multi is not None:
+            return (self.multi.search_scores if scores else self.multi.search)(q, k, self.id_base)
+        self.index.use_current_stream()
+        return (self.index.search_scores if scores else self.index.search)(q, k, self.id_base)
 
     def _search_device(self, q: torch.Tensor, k: int):
         if self.idx_shard and self.world > 1:

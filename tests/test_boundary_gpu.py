@@ -128,3 +128,25 @@ def test_bench_rccl_path_with_one_rank(cuda_device):
     r = _run_bench(["--gpus", "1"] + _SMALL, {"HBIRD_BENCH_FORCE_DIST": "1"})
     assert r["n_gpus"] == 1 and r["multi_gpu"]["backend"].startswith("nccl") and r["multi_gpu"]["world_size"] == 1
     assert r["multi_gpu"]["rows_per_rank"] == [600000]
+
+
+def test_bench_gpus_8_ragged_shards_equal_the_single_rank_result(cuda_device):
+    """The 8-rank path end to end before the first real 8-GPU run: `bench.py --gpus 8` on a bank whose row count is NOT
+    divisible by 8 (ragged shards, the last rank short), eight replicated label tables, a `parts = 8` packed merge fed by a
+    real all-gather (gloo here: the ranks share cuda:0) -- and the merged + aggregated result carries the same bits as the
+    1-rank run (`label_hat_checksum`: int64 sum of the fp32 bit patterns over all queries)."""
+    small = ["--rows", "600001", "--dim", "64", "--classes", "21", "--nq", "3001", "--steps", "2", "--warmup", "1",
+             "--no-cpu-baseline", "--no-traffic", "--checksum"]
+    one = _run_bench(["--gpus", "1"] + small, {})
+    eight = _run_bench(["--gpus", "8"] + small, {"HBIRD_BENCH_ONE_GPU": "1"}, timeout=1500)
+    assert eight["n_gpus"] == 8 and eight["config"]["parallelism"] == "bank-shard8"
+    mg = eight["multi_gpu"]
+    assert mg["world_size"] == 8 and len(mg["rows_per_rank"]) == 8 and sum(mg["rows_per_rank"]) == 600001
+    assert mg["rows_per_rank"] == [75001] * 7 + [74994] and len(set(mg["rows_per_rank"])) == 2
+    assert len(mg["knn_ms_per_rank"]) == 8 and all(x > 0 for x in mg["knn_ms_per_rank"])
+    assert mg["device_per_rank"] == [0] * 8                       # test mode; one rank per GPU reports 0..7
+    c1, c8 = one["label_hat_checksum"], eight["label_hat_checksum"]
+    assert sum(c8["rows_per_rank"]) == 3001 and len(c8["rows_per_rank"]) == 8
+    assert c1["bits"] == c8["bits"], (c1, c8)
+    assert abs(c1["sum"] - c8["sum"]) <= 1e-9 * abs(c1["sum"])
+    assert abs(c1["sum"] - 3001) < 1e-2                           # soft labels: every label_hat row sums to 1

@@ -63,6 +63,96 @@ def test_two_rank_sharded_evaluation(cuda_device, golden_dir, name):
     assert ret[0][1] == ret[1][1]          # every rank reports the same (all-reduced) mIoU
 
 
+def test_eight_rank_sharded_evaluation_with_empty_shards(cuda_device, golden_dir):
+    """World 8 on the `trim` fixture: 6 flat training batches (3 batches x 2 epochs) over 8 ranks leave ranks 6 and 7
+    with EMPTY shards, and 2 validation batches leave six ranks idle in the evaluation step -- the shapes the first real
+    8-GPU run meets at the tail of a bank.  Same bank slices, same neighbours, same mIoU as the reference fixture."""
+    world, port = 8, _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker8, args=(world, port, golden_dir, "trim", ret), nprocs=world, join=True)
+    assert all(ret[r][0] for r in range(world)), dict(ret)
+    assert len({ret[r][1] for r in range(world)}) == 1          # every rank reports the same (all-reduced) mIoU
+    rows = [ret[r][2] for r in range(world)]
+    g = np.load(f"{golden_dir}/g67_memory_evaluate.npz")
+    assert sum(rows) == g["feature_memory_trim"].shape[0] and rows[6] == rows[7] == 0 and all(r > 0 for r in rows[:6])
+
+
+def _worker8(rank, world, port, golden_dir, name, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "open-hummingbird-eval_amd"), os.path.join(root, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from helpers import IndexedReplayExtractor, golden_case_indexed
+    from hbird_mi.hbird_eval import HbirdEvaluation
+    g = np.load(f"{golden_dir}/g67_memory_evaluate.npz")
+    c = golden_case_indexed(g, name)
+    torch.set_rng_state(torch.from_numpy(g[f"rng_state_{name}"]))
+    if rank:
+        torch.rand(3 * rank)       # drifted CPU generators: the sharded build re-aligns them with rank 0's
+    ev = HbirdEvaluation(IndexedReplayExtractor(c["tokens_by_key"], c["S"], c["D"]), c["train"], num_classes=c["C"],
+                         n_neighbours=c["k"], augmentation_epoch=c["aug"], device="cuda:0", nn_method="faiss",
+                         nn_params={"idx_shard": True}, memory_size=c["mem"], dataset_size=c["nb"] * c["B"])
+    ok = ev.sharded and ev.total_rows == g[f"feature_memory_{name}"].shape[0]
+    fm = ev.feature_memory.numpy()
+    ref = g[f"feature_memory_{name}"][ev.id_base: ev.id_base + fm.shape[0]]
+    ok = ok and fm.shape == ref.shape and (fm.size == 0 or np.abs(fm - ref).max() <= 2.5e-7)
+    ok = ok and np.array_equal(ev.label_memory.numpy(), g[f"label_memory_{name}"][ev.id_base: ev.id_base + fm.shape[0]])
+    jac, det = ev.evaluate(c["val"], c["S"], return_knn_details=True, ignore_index=c["ign"])
+    ok = ok and abs(jac - float(g[f"jac_{name}"])) < 1e-4
+    B = c["B"]
+    if rank < 2:                   # validation batch `rank` (round-robin); the other six ranks have none
+        lh_ref = g[f"label_hat_{name}"][rank * B:(rank + 1) * B]
+        lh = det["knns_ca_labels"].numpy()
+        ok = ok and lh.shape == lh_ref.shape and (np.abs(lh - lh_ref) < 5e-5).mean() > 0.999
+        rs = g[f"knns_rowsum_{name}"][rank * B:(rank + 1) * B]
+        ok = ok and (np.abs(det["knns"].numpy().sum(-1) - rs) < 1e-4).mean() > 0.995
+    else:
+        ok = ok and det["knns"].numel() == 0
+    ret[rank] = (bool(ok), float(jac), int(fm.shape[0]))
+    td.destroy_process_group()
+
+
+def _replica_worker(rank, world, port, golden_dir, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "open-hummingbird-eval_amd"), os.path.join(root, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from helpers import IndexedReplayExtractor, golden_case_indexed
+    from hbird_mi.hbird_eval import HbirdEvaluation
+    g = np.load(f"{golden_dir}/g67_memory_evaluate.npz")
+    c = golden_case_indexed(g, "bnd")
+    torch.set_rng_state(torch.from_numpy(g["rng_state_bnd"]))
+    if rank == 1:
+        torch.manual_seed(1234 + rank)      # e.g. a launcher that seeds every rank differently
+    ev = HbirdEvaluation(IndexedReplayExtractor(c["tokens_by_key"], c["S"], c["D"]), c["train"], num_classes=c["C"],
+                         n_neighbours=c["k"], augmentation_epoch=c["aug"], device="cuda:0", nn_method="faiss",
+                         memory_size=c["mem"], dataset_size=c["nb"] * c["B"])
+    fm = ev.feature_memory.numpy()
+    ok = (not ev.sharded) and fm.shape == g["feature_memory_bnd"].shape and np.abs(fm - g["feature_memory_bnd"]).max() <= 2.5e-7
+    ok = ok and np.array_equal(ev.label_memory.numpy(), g["label_memory_bnd"])
+    jac = ev.evaluate(c["val"], c["S"], ignore_index=c["ign"])
+    ret[rank] = (bool(ok), float(jac), float(g["jac_bnd"]))
+    td.destroy_process_group()
+
+
+def test_two_rank_replicas_sample_the_same_bounded_bank(cuda_device, golden_dir):
+    """idx_shard=False (the reference's default) with a bounded memory: every rank builds its own replica, and the patch
+    sampling draws from torch's CPU generator (hbird_eval.py:500) -- ranks seeded differently must still build the SAME
+    bank (rank 0's stream is broadcast), or the all-reduced mIoU would belong to no single-process run."""
+    ret = mp.Manager().dict()
+    mp.spawn(_replica_worker, args=(2, _free_port(), golden_dir, ret), nprocs=2, join=True)
+    for r in (0, 1):
+        ok, jac, ref = ret[r]
+        assert ok and abs(jac - ref) < 1e-4, dict(ret)
+    assert ret[0][1] == ret[1][1]
+
+
 def _window_worker(rank, world, port, ret):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,10 +1,11 @@
 #!/bin/bash
 # usage: gpu_pmc_cluster.sh <outdir> <rows> <fp16> "<cfgs>"
 export TMPDIR=/tmp
-OUT=gpurun_out/$1; mkdir -p $OUT
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/$1; mkdir -p $OUT
 for pass in "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $pass | cut -d' ' -f1)
-  (cd /tmp && rocprofv3 --kernel-trace --pmc $pass --output-format csv -d /tmp/pmc_$tag -- python3 $GRAFT_REPO_ROOT/tools/pmc_cluster.py $2 $3 "$4" > /dev/null 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace --pmc $pass --output-format csv -d /tmp/pmc_$tag -- python3 $ROOT/tools/pmc_cluster.py $2 $3 "$4" > /dev/null 2>&1)
   find /tmp/pmc_$tag -name "*counter_collection.csv" -exec sh -c 'head -1 "$1" > "$2"; grep -E "knn_fused|knn_f16" "$1" >> "$2"' _ {} $OUT/pmc_$tag.csv \;
   rm -rf /tmp/pmc_$tag
 done
