@@ -85,7 +85,7 @@ extern "C" int hb_index_free(hb_index_t* ix) {
     (void)hipSetDevice(ix->device);
     (void)hipStreamSynchronize(ix->stream);
     void* ptrs[] = {ix->tiles, ix->binit, ix->bnorm, ix->labels, ix->q_tiles, ix->q_aux, ix->state, ix->sched_dev, ix->tmp,
-                    ix->tiles16, ix->q16, ix->cand, ix->bmax, ix->fb, ix->mtmp};
+                    ix->tiles16, ix->q16, ix->cand, ix->bmax, ix->fb, ix->mtmp, ix->f16_flag};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ix->ev0) (void)hipEventDestroy(ix->ev0);
     if (ix->ev1) (void)hipEventDestroy(ix->ev1);
@@ -246,7 +246,8 @@ extern "C" int hb_index_reset(hb_index_t* ix) {
         HB_HIP(hipStreamSynchronize(s));
     }
     HB_HIP(hipMemsetAsync(ix->bmax, 0, 4, s));
-    ix->ntotal = 0; ix->nlabels = 0; ix->f16_rows = 0;
+    ix->ntotal = 0; ix->nlabels = 0; ix->f16_rows = 0; ix->f16_overflow = 0;
+    if (ix->f16_flag) HB_HIP(hipMemsetAsync(ix->f16_flag, 0, 4, s));
     return 0;
 }
 

@@ -93,6 +93,7 @@ struct hb_index {
     // fp16 candidate mode (use_fp16): fp16 copies of the bank / query fragment tiles, candidate buffers
     int fp16 = 0, dp16 = 0;
     void* tiles16 = nullptr; int64_t f16_cap_rows = 0, f16_rows = 0;
+    int* f16_flag = nullptr; int f16_overflow = 0;       // a finite bank value overflowed fp16: the fp32 kernel serves this bank
     void* q16 = nullptr; size_t q16_bytes = 0;
     char* cand = nullptr; size_t cand_bytes = 0;
     float* bmax = nullptr;                               // device scalar: max bank-row norm
@@ -128,10 +129,11 @@ int hb_launch_query_aux(const float* q, int64_t nq, int d, float* qn2, float* qn
 int hb_launch_tiles_to_rows(const float* tiles, int g8, int d, const int64_t* ids, int64_t n, int64_t id_base,
                             float* out, hipStream_t s);
 int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t id_base, int64_t* out_idx, float* out_dist);
-int hb_launch_tiles_to_f16(const float* t32, int g8, _Float16* t16, int g16, int64_t n_row_tiles, int64_t rt0, hipStream_t s);
+int hb_launch_tiles_to_f16(const float* t32, int g8, _Float16* t16, int g16, int64_t n_row_tiles, int64_t rt0, int* overflow,
+                           hipStream_t s);
 int hb_launch_rerank(const float* tiles, const float* binit, int g8, int d, const float* q, const float* qn2,
                      const int64_t* cand, const float* cand_score, const float* qnorm, const float* bmax,
-                     unsigned char* certified, int kc, int64_t nq, int k, int64_t id_base, int metric, int out_metric, int64_t* out_idx,
+                     unsigned char* certified, int kc, int64_t nq, int k, int64_t id_base, int metric, int out_metric, int64_t ntotal, int64_t* out_idx,
                      float* out_dist, hipStream_t s);
 int hb_launch_bnorm_max(const float* bnorm, int64_t n, float* bmax, hipStream_t s);
 int hb_launch_scatter_rows(const int64_t* rows, int64_t n, int k, const int64_t* src_idx, const float* src_dist,

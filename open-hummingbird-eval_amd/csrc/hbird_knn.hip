@@ -661,7 +661,29 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // tiles, re-rank, a second merge, cold pools) scale with the queries like the search itself, so the crossover is a bank size:
     // same box, fp32 / use_fp16 ms: 50 k x 768 (nq 21,904) 13.1 / 13.0, 100 k 24.9 / 16.2; 100 k x 384 (nq 12,544) 8.3 / 10.9,
     // 200 k 15.1 / 11.0; 50 k x 768 (nq 1,369) 2.0 / 2.6, 200 k 4.8 / 3.8.  Same results either way.
-    const bool f16 = ix->fp16 != 0 && k <= 128 && (ix->fp16 == 1 || ix->ntotal >= 131072);
+    bool f16 = ix->fp16 != 0 && k <= 128 && (ix->fp16 == 1 || ix->ntotal >= 131072);
+    if (f16 && nq > 0 && ix->ntotal > 0) {
+        // bring the fp16 copy of the bank fragment tiles up to date.  A finite value beyond the fp16 range (|x| > 65504) turns
+        // into inf there and the scores into inf / NaN, which the exactness certificate cannot bound: such a bank stays on the
+        // fp32 kernel (every query counts as a fallback)
+        hipStream_t s0 = ix->stream;
+        if (!ix->f16_flag) { HB_HIP(hipMalloc((void**)&ix->f16_flag, 4)); HB_HIP(hipMemsetAsync(ix->f16_flag, 0, 4, s0)); }
+        if (ix->f16_cap_rows != ix->cap_rows) {
+            if (ix->tiles16) HB_HIP(hipFree(ix->tiles16));
+            ix->tiles16 = nullptr; ix->f16_rows = 0;
+            HB_HIP(hipMalloc(&ix->tiles16, (size_t)ix->cap_rows * ix->dp16 * 2));
+            HB_HIP(hipMemsetAsync(ix->tiles16, 0, (size_t)ix->cap_rows * ix->dp16 * 2, s0));
+            ix->f16_cap_rows = ix->cap_rows;
+        }
+        if (ix->f16_rows < ix->ntotal) {
+            const int64_t rt0 = ix->f16_rows / 32, need_rt = (ix->ntotal + 31) / 32;
+            if (hb_launch_tiles_to_f16(ix->tiles, ix->g8, (_Float16*)ix->tiles16, ix->dp16 / 16, need_rt - rt0, rt0, ix->f16_flag, s0)) return -1;
+            ix->f16_rows = ix->ntotal;
+            HB_HIP(hipMemcpyAsync(&ix->f16_overflow, ix->f16_flag, 4, hipMemcpyDeviceToHost, s0));
+            HB_HIP(hipStreamSynchronize(s0));
+        }
+        if (ix->f16_overflow) { f16 = false; ix->last_fp16_fallbacks = nq; }
+    }
     // fp16 mode: the fused kernel collects kc >= 2k candidates, the fp32 chain arithmetic re-ranks them
     const int kc = f16 ? std::min(256, std::max(64, (2 * k + 63) / 64 * 64)) : k;
     const bool wide = f16 || k > HB_KL;   // (pools for k <= 32 on small searches were tried: 8.1 vs 5.0 ms at 50,176 x 384)
@@ -757,23 +779,10 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     HB_HIP(hipMemsetAsync(a.prog, 0, prog_bytes, s));
 #endif
     if (f16) {
-        // bring the fp16 copies of the bank / query fragment tiles up to date
-        const int64_t need_rt = (ix->ntotal + 31) / 32;
-        if (ix->f16_cap_rows != ix->cap_rows) {
-            if (ix->tiles16) HB_HIP(hipFree(ix->tiles16));
-            ix->tiles16 = nullptr; ix->f16_rows = 0;
-            HB_HIP(hipMalloc(&ix->tiles16, (size_t)ix->cap_rows * ix->dp16 * 2));
-            HB_HIP(hipMemsetAsync(ix->tiles16, 0, (size_t)ix->cap_rows * ix->dp16 * 2, s));
-            ix->f16_cap_rows = ix->cap_rows;
-        }
-        if (ix->f16_rows < ix->ntotal) {
-            const int64_t rt0 = ix->f16_rows / 32;
-            if (hb_launch_tiles_to_f16(ix->tiles, ix->g8, (_Float16*)ix->tiles16, ix->dp16 / 16, need_rt - rt0, rt0, s)) return -1;
-            ix->f16_rows = ix->ntotal;
-        }
+        // fp16 copy of the query fragment tiles (the bank's is up to date: top of this function)
         const int64_t nqp = (int64_t)nqt * HB_QT;
         if (ensure_bytes((char**)&ix->q16, &ix->q16_bytes, (size_t)nqp * ix->dp16 * 2)) return -1;
-        if (hb_launch_tiles_to_f16(ix->q_tiles, ix->g8, (_Float16*)ix->q16, ix->dp16 / 16, nqp / 32, 0, s)) return -1;
+        if (hb_launch_tiles_to_f16(ix->q_tiles, ix->g8, (_Float16*)ix->q16, ix->dp16 / 16, nqp / 32, 0, nullptr, s)) return -1;
         if (ensure_bytes(&ix->cand, &ix->cand_bytes, (size_t)nq * kc * 12)) return -1;
         int64_t* cand_idx = reinterpret_cast<int64_t*>(ix->cand);
         float* cand_dist = reinterpret_cast<float*>(ix->cand + (size_t)nq * kc * 8);
@@ -791,7 +800,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         if (ensure_bytes(&ix->fb, &ix->fb_bytes, (size_t)nq + 64)) return -1;
         unsigned char* cert = reinterpret_cast<unsigned char*>(ix->fb);
         if (hb_launch_rerank(ix->tiles, ix->binit, ix->g8, ix->d, q_dev, ix->q_aux, cand_idx, cand_dist, ix->q_aux + nq, ix->bmax,
-                             cert, kc, nq, k, id_base, ix->metric, out_metric, out_idx, out_dist, s)) return -1;
+                             cert, kc, nq, k, id_base, ix->metric, out_metric, ix->ntotal, out_idx, out_dist, s)) return -1;
         if (ix->time_kernels) {
             HB_HIP(hipEventSynchronize(ix->ev1));
             float ms = 0.f;

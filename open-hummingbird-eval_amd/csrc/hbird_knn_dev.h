@@ -576,7 +576,16 @@ __device__ __forceinline__ void pool_end(const knn_args_pool_view& pv, int slot,
 // 32-round radix select on the monotone keys, and everything below it is filtered like any other score: about k
 // insertions per query remain.  Returns the float just below that k-th score (ties with it must still pass), or -inf
 // when the tile has fewer than k real rows (padding rows score -inf).
-__device__ __forceinline__ float cold_start_threshold(const f32x16 (&acc)[8], int k) {
+// NaN scores (a bank row of NaNs: a zero token through the reference's eps-free normalisation, hbird_eval.py:324; a query
+// with inf / NaN components) never enter a list -- every filter is a strict `score > threshold`, false for NaN, as in a
+// comparison-based k-select.  Here the order is a monotone KEY, where a positive NaN would outrank +inf and lift the
+// threshold over real neighbours: the tile's NaNs are replaced by -inf first (in place: for the filters after this call
+// -inf and NaN are the same thing).
+__device__ __forceinline__ float cold_start_threshold(f32x16 (&acc)[8], int k) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = (acc[t][r] == acc[t][r]) ? acc[t][r] : -INFINITY;
     unsigned prefix = 0;
     int kk = k;
     for (int b = 31; b >= 0; --b) {

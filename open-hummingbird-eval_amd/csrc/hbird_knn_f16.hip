@@ -30,8 +30,11 @@ static_assert(F16_LDS_TOTAL <= 160 * 1024, "LDS budget");
 // fp32 fragment tiles -> fp16 fragment tiles.  fp16 block(rt, g16) = 32 rows x 16 k = 1 KiB, element (i, kk) at half
 // index ((kk >> 3) * 32 + i) * 8 + (kk & 7): lane l = h*32 + i reads 8 halves = k = 16 g16 + 8h + 0..7, the A/B
 // operand of one 32x32x16 MFMA.  One thread per 8 output halves.
+// *overflow (optional) is raised when a FINITE fp32 value has no finite fp16 image (|x| > 65504): the candidate pass'
+// certificate assumes finite fp16 operands, so such a bank / query is served by the fp32 kernel.  (A NaN stays a NaN in
+// both precisions and is excluded by both kernels alike.)
 __global__ __launch_bounds__(256) void tiles_to_f16_kernel(const float* __restrict__ t32, int g8, _Float16* __restrict__ t16,
-                                                           int g16, int64_t n_row_tiles, int64_t rt0) {
+                                                           int g16, int64_t n_row_tiles, int64_t rt0, int* __restrict__ overflow) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one per (row tile, g16, h, i)
     const int64_t total = n_row_tiles * g16 * 64;
     if (gid >= total) return;
@@ -47,14 +50,16 @@ __global__ __launch_bounds__(256) void tiles_to_f16_kernel(const float* __restri
         float v = 0.0f;
         if (gg < g8) v = t32[((rt * g8) + gg) * HB_BLK + ((kk & 1) * 32 + i) * 4 + (kk >> 1)];
         out[j] = (_Float16)v;
+        if (overflow && fabsf(v) > 65504.0f && fabsf(v) < INFINITY) *overflow = 1;
     }
     reinterpret_cast<f16x8*>(t16)[(rt * g16 + g) * 64 + h * 32 + i] = out;
 }
 
-int hb_launch_tiles_to_f16(const float* t32, int g8, _Float16* t16, int g16, int64_t n_row_tiles, int64_t rt0, hipStream_t s) {
+int hb_launch_tiles_to_f16(const float* t32, int g8, _Float16* t16, int g16, int64_t n_row_tiles, int64_t rt0, int* overflow,
+                           hipStream_t s) {
     const int64_t total = n_row_tiles * g16 * 64;
     if (total == 0) return 0;
-    tiles_to_f16_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(t32, g8, t16, g16, n_row_tiles, rt0);
+    tiles_to_f16_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(t32, g8, t16, g16, n_row_tiles, rt0, overflow);
     HB_HIP(hipGetLastError());
     return 0;
 }
@@ -487,8 +492,8 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ t
                                                      const int64_t* __restrict__ cand, const float* __restrict__ cand_score,
                                                      const float* __restrict__ qnorm, const float* __restrict__ bmax,
                                                      unsigned char* __restrict__ certified, int kc, int64_t nq, int k,
-                                                     int64_t id_base, int metric, int out_metric, int64_t* __restrict__ out_idx,
-                                                     float* __restrict__ out_dist) {
+                                                     int64_t id_base, int metric, int out_metric, int64_t ntotal,
+                                                     int64_t* __restrict__ out_idx, float* __restrict__ out_dist) {
     __shared__ float s_sc[4][256];
     __shared__ int64_t s_id[4][256];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -533,9 +538,13 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ t
             // exact score <= that + E with E >= |fp16 score - exact score| (both inputs rounded to fp16: relative
             // 2^-10 per product, Cauchy-Schwarz over the row; fp32 accumulation: D * 2^-23).  If the exact k-th best
             // is strictly above that bound, no outside row can enter the top k: the answer IS the fp32 answer.
+            // The argument needs finite fp16 operands: a query with |q_i| > 65504 becomes inf in fp16 and its scores inf / NaN
+            // (||q|| <= 65504 rules that out; a NaN / inf norm fails the test too), and a candidate list that is not full
+            // although the bank has kc rows has lost rows to NaN / -inf fp16 scores that nothing bounds.
             const int64_t last = cand[qi * (int64_t)kc + kc - 1];
-            bool ok = last < 0;                       // fewer than kc rows exist: every row was a candidate
-            if (!ok && id >= 0) {
+            const bool finite_q = qnorm[qi] <= 65504.0f;
+            bool ok = last < 0 && ntotal < kc && finite_q;   // fewer than kc rows exist: every row was a candidate
+            if (last >= 0 && id >= 0 && finite_q) {
                 const float E = qnorm[qi] * bmax[0] * (1.05f / 1024.0f + (float)d * 2.4e-7f)
                                 + (qnorm[qi] + bmax[0]) * sqrtf((float)d) * 6e-8f                 // fp16 subnormal inputs
                                 + (metric == 1 ? (float)d * 1.2e-7f * 0.5f * bmax[0] * bmax[0] : 0.0f)  // |row init| in the sums
@@ -559,11 +568,11 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ t
 int hb_launch_rerank(const float* tiles, const float* binit, int g8, int d, const float* q, const float* qn2,
                      const int64_t* cand, const float* cand_score, const float* qnorm, const float* bmax,
                      unsigned char* certified, int kc, int64_t nq, int k, int64_t id_base, int metric, int out_metric,
-                     int64_t* out_idx, float* out_dist, hipStream_t s) {
+                     int64_t ntotal, int64_t* out_idx, float* out_dist, hipStream_t s) {
     if (nq == 0) return 0;
     if (kc > 256) return hb_fail("hb_index_search: too many candidates for the re-rank kernel");
     rerank_kernel<<<dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s>>>(tiles, binit, g8, d, q, qn2, cand, cand_score, qnorm, bmax,
-                                                                     certified, kc, nq, k, id_base, metric, out_metric, out_idx, out_dist);
+                                                                     certified, kc, nq, k, id_base, metric, out_metric, ntotal, out_idx, out_dist);
     HB_HIP(hipGetLastError());
     return 0;
 }

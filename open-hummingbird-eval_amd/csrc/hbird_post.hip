@@ -9,42 +9,159 @@
 
 // K6 -- reference hbird_eval.py:235-243: label_hat[B, S*S, C] -> reshape [B,S,S,C] -> permute
 // [B,C,S,S] -> F.interpolate(size=(h,w), mode="bilinear", align_corners=False) -> argmax(dim=1).
-// Fused: the [B,C,h,w] fp32 tensor (2.6 GB at cfg-3) is never materialised.  One thread per output
-// pixel; source index as ATen's area_pixel_compute_source_index: src = max(0, scale*(dst+0.5)-0.5),
-// scale = S/h in fp32; value = ly0*(lx0*v00 + lx1*v01) + ly1*(lx0*v10 + lx1*v11); ties -> lowest class.
+// Fused: the [B,C,h,w] fp32 tensor (2.6 GB at cfg-3) is never materialised.  Source index as ATen's
+// area_pixel_compute_source_index: src = max(0, scale*(dst+0.5)-0.5), scale = S/h in fp32;
+// value = ly0*(lx0*v00 + lx1*v01) + ly1*(lx0*v10 + lx1*v11); ties -> lowest class.
+//
+// Work decomposition.  All output rows whose upper source row is j (a "band": ~h/S rows) interpolate between the
+// same two source rows j and j+1, and `top` / `bot` of the formula depend on (source row, x, class) only.  One
+// workgroup = (image, band j, chunk of <= R rows of the band, 64..256 output columns); it stages the two source rows'
+// needed columns x C classes in LDS (25 KB at cfg-3), and each lane (= one output column) walks the classes once:
+// 4 LDS reads (broadcast-friendly: a wave's 64 columns touch ~6 source columns) + top/bot per class, then for each of its
+// rows v = ly0*top + ly1*bot and a running (best, argbest) in registers.  Same fp32 steps in the same order as the
+// per-pixel formula (contraction off), so the class maps are bit-identical to the one-thread-per-pixel kernel this
+// replaces (1.31 ms -> see profiles/r03 at the cfg-3 batch; 649 M class evaluations, 4 global loads each before).
+__device__ __forceinline__ int k6_src0(float scale, int dst, int S) {
+    const float f = fmaxf(scale * ((float)dst + 0.5f) - 0.5f, 0.0f);
+    return min((int)floorf(f), S - 1);
+}
+// first output index whose upper source index is >= j (bands are contiguous: the source index is monotone)
+__device__ __forceinline__ int k6_band_begin(float scale, int j, int S, int n) {
+    if (j <= 0) return 0;
+    if (j > S - 1) return n;
+    int g = (int)(((float)j + 0.5f) / scale - 0.5f);
+    g = max(0, min(g, n));
+    while (g > 0 && k6_src0(scale, g - 1, S) >= j) --g;
+    while (g < n && k6_src0(scale, g, S) < j) ++g;
+    return g;
+}
+
+template <int K6_R>
 __global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* __restrict__ lh, int S, int C, int h, int w,
-                                                              float sy, float sx, int64_t* __restrict__ out) {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    const int yy = blockIdx.y;
+                                                              float sy, float sx, int chunks, int cmax,
+                                                              int64_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float k6_sm[];
+    const int j = blockIdx.y / chunks, rc = blockIdx.y % chunks;
     const int64_t b = blockIdx.z;
-    if (x >= w) return;
-        float fy = fmaxf(sy * ((float)yy + 0.5f) - 0.5f, 0.0f);
-    float fx = fmaxf(sx * ((float)x + 0.5f) - 0.5f, 0.0f);
-    int y0 = min((int)floorf(fy), S - 1), x0 = min((int)floorf(fx), S - 1);
-    int y1 = min(y0 + 1, S - 1), x1 = min(x0 + 1, S - 1);
-    const float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
-    const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
-    const float* base = lh + b * (int64_t)S * S * C;
-    const float* p00 = base + ((int64_t)y0 * S + x0) * C;
-    const float* p01 = base + ((int64_t)y0 * S + x1) * C;
-    const float* p10 = base + ((int64_t)y1 * S + x0) * C;
-    const float* p11 = base + ((int64_t)y1 * S + x1) * C;
-    float best = -INFINITY;
-    int bi = 0;
-    for (int c = 0; c < C; ++c) {
-        const float top = lx0 * p00[c] + lx1 * p01[c];
-        const float bot = lx0 * p10[c] + lx1 * p11[c];
-        const float v = ly0 * top + ly1 * bot;
-        if (v > best || c == 0) { best = v; bi = c; }   // NaN-free inputs; first max wins
+    const int r0 = k6_band_begin(sy, j, S, h) + rc * K6_R;
+    const int r1 = min(k6_band_begin(sy, j + 1, S, h), r0 + K6_R);
+    if (r0 >= r1) return;                                   // block-uniform
+    const int bw = blockDim.x;                              // 64 .. 256 columns per block (whole waves)
+    const int xs = blockIdx.x * bw, xe = min(w, xs + bw) - 1;
+    const int cx_lo = k6_src0(sx, xs, S), cx_hi = min(k6_src0(sx, xe, S) + 1, S - 1);
+    const int ncols = cx_hi - cx_lo + 1;
+    const int j1 = min(j + 1, S - 1);
+    const int x = min(xs + (int)threadIdx.x, w - 1);        // lanes past the right border repeat the last column (no store)
+    const float fx = fmaxf(sx * ((float)x + 0.5f) - 0.5f, 0.0f);
+    const int x0 = min((int)floorf(fx), S - 1), x1 = min(x0 + 1, S - 1);
+    const float lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
+    float ly0[K6_R], ly1[K6_R], best[K6_R];
+    int arg[K6_R];
+#pragma unroll
+    for (int r = 0; r < K6_R; ++r) {
+        const int yy = min(r0 + r, r1 - 1);                 // rows past the chunk's end repeat its last row (no store)
+        const float fy = fmaxf(sy * ((float)yy + 0.5f) - 0.5f, 0.0f);
+        ly1[r] = fy - (float)j;                             // j = min(floor(fy), S - 1) for every row of the band
+        ly0[r] = 1.0f - ly1[r];
+        best[r] = 0.0f; arg[r] = 0;
     }
-    out[(b * h + yy) * (int64_t)w + x] = bi;
+    const float* base = lh + b * (int64_t)S * S * C;
+    for (int c0 = 0; c0 < C; c0 += cmax) {
+        const int cn = min(cmax, C - c0);
+        if (c0) __syncthreads();
+        // stage [2 source rows][ncols][cn]: for cn == C a source row's columns are one contiguous run in global memory
+        const int per_row = ncols * cn;
+        if (cn == C) {                                      // the columns of a source row are one contiguous run
+            const float* s0 = base + ((int64_t)j * S + cx_lo) * C;
+            const float* s1 = base + ((int64_t)j1 * S + cx_lo) * C;
+            for (int e = threadIdx.x; e < per_row; e += bw) { k6_sm[e] = s0[e]; k6_sm[per_row + e] = s1[e]; }
+        } else
+            for (int e = threadIdx.x; e < 2 * per_row; e += bw) {
+                const int row = e >= per_row, rem = e - row * per_row;
+                const int col = rem / cn, c = rem - col * cn;
+                k6_sm[e] = base[((int64_t)(row ? j1 : j) * S + cx_lo + col) * C + c0 + c];
+            }
+        __syncthreads();
+        if (xs + (int)(threadIdx.x & ~63u) >= w) continue;  // a wave with no column left of the border only helps staging
+        const float* p00 = k6_sm + (x0 - cx_lo) * cn;
+        const float* p01 = k6_sm + (x1 - cx_lo) * cn;
+        const float* p10 = p00 + per_row;
+        const float* p11 = p01 + per_row;
+        int c = 0;
+        if (c0 == 0) {                                      // class 0 starts every running maximum (first max wins)
+            const float top = lx0 * p00[0] + lx1 * p01[0];
+            const float bot = lx0 * p10[0] + lx1 * p11[0];
+#pragma unroll
+            for (int r = 0; r < K6_R; ++r) best[r] = ly0[r] * top + ly1[r] * bot;
+            c = 1;
+        }
+        for (; c < cn; ++c) {
+            const float top = lx0 * p00[c] + lx1 * p01[c];
+            const float bot = lx0 * p10[c] + lx1 * p11[c];
+#pragma unroll
+            for (int r = 0; r < K6_R; ++r) {
+                const float v = ly0[r] * top + ly1[r] * bot;
+                if (v > best[r]) { best[r] = v; arg[r] = c0 + c; }   // NaN-free inputs; first max wins
+            }
+        }
+    }
+    if (xs + (int)threadIdx.x < w) {
+#pragma unroll
+        for (int r = 0; r < K6_R; ++r)
+            if (r0 + r < r1) out[(b * h + (r0 + r)) * (int64_t)w + x] = arg[r];
+    }
 }
 
 int hb_launch_upsample_argmax(const float* label_hat, int64_t B, int S, int C, int h, int w, int64_t* out,
                               hipStream_t s) {
     if (B == 0) return 0;
+    if (S < 1 || C < 1 || h < 1 || w < 1) return hb_fail("hb_upsample_argmax: bad shape");
     const float sy = (float)S / (float)h, sx = (float)S / (float)w;
-    upsample_argmax_kernel<<<dim3((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)B), dim3(256), 0, s>>>(label_hat, S, C, h, w, sy, sx, out);
+    // tallest band (same fp32 arithmetic as the kernel: this file is compiled with contraction off on both sides)
+    int maxband = 1, run = 0, prev = -1;
+    for (int yy = 0; yy < h; ++yy) {
+        const float f = std::fmax(sy * ((float)yy + 0.5f) - 0.5f, 0.0f);
+        const int y0 = std::min((int)std::floor(f), S - 1);
+        run = y0 == prev ? run + 1 : 1;
+        prev = y0;
+        maxband = std::max(maxband, run);
+    }
+    // rows per chunk: the instantiation that computes the fewest padded rows over all bands (h = 14 S: bands of 14 -> R = 14)
+    static const int r_opts[] = {16, 14, 12, 10, 8};
+    int R = 16;
+    long long best_cost = -1;
+    for (int r : r_opts) {
+        long long cost = 0;
+        int n = 0, pv = -1;
+        for (int yy = 0; yy <= h; ++yy) {
+            int y0 = -2;
+            if (yy < h) {
+                const float f = std::fmax(sy * ((float)yy + 0.5f) - 0.5f, 0.0f);
+                y0 = std::min((int)std::floor(f), S - 1);
+            }
+            if (y0 != pv) { cost += (long long)((n + r - 1) / r) * (r + 1); n = 0; pv = y0; }   // + 1: per-chunk overhead (top / bot, staging)
+            ++n;
+        }
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; R = r; }
+    }
+    const int chunks = (maxband + R - 1) / R;
+    if ((long long)S * chunks > 65535 || B > 65535) return hb_fail("hb_upsample_argmax: grid too large");
+    // whole waves of 64 columns, dealt evenly to blocks of at most four (w = 518: 9 waves -> 3 blocks of 3, none idle)
+    const int waves = (w + 63) / 64, blocks_x = (waves + 3) / 4, bw = (waves + blocks_x - 1) / blocks_x * 64;
+    // widest column window of a block, and the classes per LDS pass that keep it within 64 KiB
+    const int ncols = std::min(S, (int)std::ceil((double)bw * S / w) + 2);
+    const int cmax = std::max(1, std::min(C, (64 * 1024) / (2 * ncols * 4)));
+    const size_t lds = (size_t)2 * ncols * cmax * 4;
+    const dim3 grid((unsigned)blocks_x, (unsigned)(S * chunks), (unsigned)B);
+#define K6_LAUNCH(RR) upsample_argmax_kernel<RR><<<grid, dim3(bw), lds, s>>>(label_hat, S, C, h, w, sy, sx, chunks, cmax, out)
+    switch (R) {
+        case 8: K6_LAUNCH(8); break;
+        case 10: K6_LAUNCH(10); break;
+        case 12: K6_LAUNCH(12); break;
+        case 14: K6_LAUNCH(14); break;
+        default: K6_LAUNCH(16); break;
+    }
+#undef K6_LAUNCH
     HB_HIP(hipGetLastError());
     return 0;
 }

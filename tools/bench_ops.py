@@ -58,5 +58,12 @@ for name, (B, S, ps, D, C, k) in {"cfg2": (64, 14, 16, 384, 21, 30), "cfg3": (16
     conf = torch.zeros((C, C), dtype=torch.int64, device=dev)
     ms = timeit(lambda: ops.confusion_update(conf, y, pred, 255)); res.append((name, "K7 confusion", ms, 16 * H * H * B))
     del bank, ix
+rows = []
 for name, op, ms, nbytes in res:
-    print(f"{name}  {op:30s} {ms:8.3f} ms  {nbytes / 1e6:9.1f} MB algorithmic  {nbytes / ms / 1e6:8.1f} GB/s")
+    print(f"{name}  {op:30s} {ms:8.3f} ms  {nbytes / 1e6:9.1f} MB algorithmic  {nbytes / ms / 1e6:8.1f} GB/s  "
+          f"{nbytes / ms / 1e6 / 8000:6.3f} of 8 TB/s")
+    rows.append({"shape": name, "kernel": op, "ms": round(ms, 4), "algorithmic_MB": round(nbytes / 1e6, 2),
+                 "GBps": round(nbytes / ms / 1e6, 1), "frac_of_hbm_8TBps": round(nbytes / ms / 1e6 / 8000, 4)})
+if len(sys.argv) > 1:      # tools/bench_ops.py <out.json>: the table behind DESIGN.md section 4 (kept under profiles/<round>/)
+    json.dump({"device": torch.cuda.get_device_name(0), "timing": "torch.cuda.Event over 5 calls after one warm-up",
+               "rows": rows}, open(sys.argv[1], "w"), indent=1)
