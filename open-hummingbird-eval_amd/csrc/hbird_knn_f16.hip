@@ -267,6 +267,11 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
 #define F2_SCRATCH (F2_BINIT + 2048)
 #define F2_PCNT (F2_SCRATCH + 8192)
 #define F2_CLWORDS (F2_PCNT + 1024)                    // landing zone of the cluster progress poll
+#define F2_TO4()
+#define F2_FROM4()
+#if defined(F2_MFMA16) && !(defined(F16_ABL) && (F16_ABL & 1))
+#error "F2_MFMA16 is a timing-only build of the stage loop: combine it with F16_ABL=1 (no epilogue)"
+#endif
 #define F2_LDS_TOTAL (F2_CLWORDS + 64)
 static_assert(F2_LDS_TOTAL <= 160 * 1024, "LDS budget");
 
@@ -297,7 +302,11 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
         float thr = pool_begin(pv, seg.slot, seg.first, pcnt, myq, lane);
         thr = fmaxf(thr, floor_load(a.gthr, seg.q_tile * HB_QT + myq));
         const int total = seg.n_tiles * NS, clock0 = seg.tile0 * NS;
+#ifdef F2_MFMA16
+        f32x4 acc4[32];
+#else
         f32x16 acc[8];
+#endif
         f16x8 fa[8];        // bank fragments of the current group (one set)
         f16x8 bq[4][2];     // query fragments of four stages, two k16 groups each
 
@@ -357,6 +366,13 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
 #if defined(F16_ABL) && (F16_ABL & 256)
 #define F2_INIT_TILE() { _Pragma("unroll") for (int t = 0; t < 8; ++t) asm volatile("" : "+v"(acc[t])); }   // timing only: no init
 #else
+#ifdef F2_MFMA16
+#define F2_INIT_TILE()                                                                                                       \
+        {                                                                                                                    \
+            const f32x4* bi = reinterpret_cast<const f32x4*>(smem + F2_BINIT + cpar * 1024);                                 \
+            _Pragma("unroll") for (int t = 0; t < 16; ++t) { acc4[2 * t] = bi[4 * t + (lane >> 4)]; acc4[2 * t + 1] = acc4[2 * t]; } \
+        }
+#else
 #define F2_INIT_TILE()                                                                                                       \
         {                                                                                                                    \
             const f32x4* bi = reinterpret_cast<const f32x4*>(smem + F2_BINIT + cpar * 1024);                                 \
@@ -367,12 +383,14 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
                 }                                                                                                            \
         }
 #endif
+#endif
         {
             const f16x8* A = reinterpret_cast<const f16x8*>(smem) + lane;
 #pragma unroll
             for (int t = 0; t < 8; ++t) fa[t] = A[(t * 2) * 64];
         }
         F2_INIT_TILE()
+        F2_TO4()
 #ifdef F2_STAMPS   // diagnostic build (make var NAME=stamps EXTRA=-DF2_STAMPS): where a tile boundary spends its cycles; never timed
 #define F2_STAMP(T) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
         unsigned long long ts_a = 0, ts_m = 0, ts_b = 0, ts_c = 0, ts_s = 0, ts_e = 0;
@@ -385,7 +403,13 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
 #define F2_STAMP_STAGE_BEGIN(U)
 #define F2_STAMP_STAGE_BARRIER(U)
 #endif
-#define F2_MM(T, B) acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[T], B, acc[T], 0, 0, 0);
+#ifdef F2_MFMA16   /* timing only (results are garbage): the same FLOPs issued as two v_mfma_f32_16x16x32_f16 per 32x32x16 */
+#define F2_MM(T, B, G)                                                                                                       \
+        acc4[4 * (T) + 2 * (G)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[T], B, acc4[4 * (T) + 2 * (G)], 0, 0, 0);       \
+        acc4[4 * (T) + 2 * (G) + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[T], B, acc4[4 * (T) + 2 * (G) + 1], 0, 0, 0);
+#else
+#define F2_MM(T, B, G) acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[T], B, acc[T], 0, 0, 0);
+#endif
 #define F2_STAGE(U)                                                                                                          \
         {                                                                                                                    \
             const f16x8* Ac = reinterpret_cast<const f16x8*>(smem + slot_c * F2_SLOT) + lane;                                \
@@ -393,14 +417,14 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
             const f16x8* An = reinterpret_cast<const f16x8*>(smem + slot_n * F2_SLOT) + lane;                                \
             F2_STAMP_STAGE_BEGIN(U)                                                                                          \
             /* group 0; filler after MFMA t: fragment t of group 1; B1 of the stage three ahead */                           \
-            KN_FENCE F2_MM(0, bq[U][0]) KN_FENCE F2_RD(fa[0], Ac[(0 * 2 + 1) * 64]) F2_BL(bq[(U + 3) & 3][1], qsrc_b1, 1024, 0)  \
-            KN_FENCE F2_MM(1, bq[U][0]) KN_FENCE F2_RD(fa[1], Ac[(1 * 2 + 1) * 64])                                          \
-            KN_FENCE F2_MM(2, bq[U][0]) KN_FENCE F2_RD(fa[2], Ac[(2 * 2 + 1) * 64])                                          \
-            KN_FENCE F2_MM(3, bq[U][0]) KN_FENCE F2_RD(fa[3], Ac[(3 * 2 + 1) * 64])                                          \
-            KN_FENCE F2_MM(4, bq[U][0]) KN_FENCE F2_RD(fa[4], Ac[(4 * 2 + 1) * 64]) F2_BL(bq[(U + 3) & 3][1], qsrc_b1, 1024, 1)  \
-            KN_FENCE F2_MM(5, bq[U][0]) KN_FENCE F2_RD(fa[5], Ac[(5 * 2 + 1) * 64])                                          \
-            KN_FENCE F2_MM(6, bq[U][0]) KN_FENCE F2_RD(fa[6], Ac[(6 * 2 + 1) * 64])                                          \
-            KN_FENCE F2_MM(7, bq[U][0]) KN_FENCE F2_RD(fa[7], Ac[(7 * 2 + 1) * 64])                                          \
+            KN_FENCE F2_MM(0, bq[U][0], 0) KN_FENCE F2_RD(fa[0], Ac[(0 * 2 + 1) * 64]) F2_BL(bq[(U + 3) & 3][1], qsrc_b1, 1024, 0)  \
+            KN_FENCE F2_MM(1, bq[U][0], 0) KN_FENCE F2_RD(fa[1], Ac[(1 * 2 + 1) * 64])                                          \
+            KN_FENCE F2_MM(2, bq[U][0], 0) KN_FENCE F2_RD(fa[2], Ac[(2 * 2 + 1) * 64])                                          \
+            KN_FENCE F2_MM(3, bq[U][0], 0) KN_FENCE F2_RD(fa[3], Ac[(3 * 2 + 1) * 64])                                          \
+            KN_FENCE F2_MM(4, bq[U][0], 0) KN_FENCE F2_RD(fa[4], Ac[(4 * 2 + 1) * 64]) F2_BL(bq[(U + 3) & 3][1], qsrc_b1, 1024, 1)  \
+            KN_FENCE F2_MM(5, bq[U][0], 0) KN_FENCE F2_RD(fa[5], Ac[(5 * 2 + 1) * 64])                                          \
+            KN_FENCE F2_MM(6, bq[U][0], 0) KN_FENCE F2_RD(fa[6], Ac[(6 * 2 + 1) * 64])                                          \
+            KN_FENCE F2_MM(7, bq[U][0], 0) KN_FENCE F2_RD(fa[7], Ac[(7 * 2 + 1) * 64])                                          \
             KN_FENCE                                                                                                         \
             /* the next stage has landed: my requests (and my query fragments of it), then everyone's */                    \
             asm volatile("s_waitcnt vmcnt(8)" : "+v"(bq[(U + 1) & 3][0]), "+v"(bq[(U + 1) & 3][1]), "+v"(bq[U][1]) :: "memory"); \
@@ -408,14 +432,14 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
             F2_STAMP_STAGE_BARRIER(U)                                                                                        \
             /* group 1; filler after MFMA t: fragment t of the next stage's group 0; B0 C0 C1 of the stage four ahead */     \
             if (w == 0) cl_tick(cs, clock0 + st + (U), lane);   /* cluster soft sync, ahead of the stage's requests */       \
-            KN_FENCE F2_MM(0, bq[U][1]) KN_FENCE F2_RD(fa[0], An[(0 * 2) * 64]) F2_BL(bq[U][0], F2_QSRC(), 0, 0)             \
-            KN_FENCE F2_MM(1, bq[U][1]) KN_FENCE F2_RD(fa[1], An[(1 * 2) * 64]) F2_BL(bq[U][0], F2_QSRC(), 0, 1)             \
-            KN_FENCE F2_MM(2, bq[U][1]) KN_FENCE F2_RD(fa[2], An[(2 * 2) * 64]) if (w < 4) F2_COPY(0)                        \
-            KN_FENCE F2_MM(3, bq[U][1]) KN_FENCE F2_RD(fa[3], An[(3 * 2) * 64]) if (w >= 4) F2_COPY(0)                       \
-            KN_FENCE F2_MM(4, bq[U][1]) KN_FENCE F2_RD(fa[4], An[(4 * 2) * 64]) if (w < 4) F2_COPY(1)                        \
-            KN_FENCE F2_MM(5, bq[U][1]) KN_FENCE F2_RD(fa[5], An[(5 * 2) * 64]) if (w >= 4) F2_COPY(1)                       \
-            KN_FENCE F2_MM(6, bq[U][1]) KN_FENCE F2_RD(fa[6], An[(6 * 2) * 64])                                              \
-            KN_FENCE F2_MM(7, bq[U][1]) KN_FENCE F2_RD(fa[7], An[(7 * 2) * 64])                                              \
+            KN_FENCE F2_MM(0, bq[U][1], 1) KN_FENCE F2_RD(fa[0], An[(0 * 2) * 64]) F2_BL(bq[U][0], F2_QSRC(), 0, 0)             \
+            KN_FENCE F2_MM(1, bq[U][1], 1) KN_FENCE F2_RD(fa[1], An[(1 * 2) * 64]) F2_BL(bq[U][0], F2_QSRC(), 0, 1)             \
+            KN_FENCE F2_MM(2, bq[U][1], 1) KN_FENCE F2_RD(fa[2], An[(2 * 2) * 64]) if (w < 4) F2_COPY(0)                        \
+            KN_FENCE F2_MM(3, bq[U][1], 1) KN_FENCE F2_RD(fa[3], An[(3 * 2) * 64]) if (w >= 4) F2_COPY(0)                       \
+            KN_FENCE F2_MM(4, bq[U][1], 1) KN_FENCE F2_RD(fa[4], An[(4 * 2) * 64]) if (w < 4) F2_COPY(1)                        \
+            KN_FENCE F2_MM(5, bq[U][1], 1) KN_FENCE F2_RD(fa[5], An[(5 * 2) * 64]) if (w >= 4) F2_COPY(1)                       \
+            KN_FENCE F2_MM(6, bq[U][1], 1) KN_FENCE F2_RD(fa[6], An[(6 * 2) * 64])                                              \
+            KN_FENCE F2_MM(7, bq[U][1], 1) KN_FENCE F2_RD(fa[7], An[(7 * 2) * 64])                                              \
             KN_FENCE                                                                                                         \
             F2_ADVANCE()                                                                                                     \
             KN_FENCE                                                                                                         \
@@ -425,7 +449,11 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
             F2_STAGE(0) F2_STAGE(1) F2_STAGE(2) F2_STAGE(3)
             ks += 4;
             if (ks == NS) {
-#if defined(F16_ABL) && (F16_ABL & 1)
+                F2_FROM4()
+#if defined(F2_MFMA16)
+#pragma unroll
+                for (int t = 0; t < 32; ++t) asm volatile("" :: "v"(acc4[t]));   // timing only: no epilogue
+#elif defined(F16_ABL) && (F16_ABL & 1)
 #pragma unroll
                 for (int t = 0; t < 8; ++t) asm volatile("" :: "v"(acc[t]));   // timing only: no epilogue
 #elif defined(F2_STAMPS)
@@ -447,6 +475,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
 #pragma unroll
                     for (int t = 0; t < 8; ++t) fa[t] = A[(t * 2) * 64];
                 }
+                F2_TO4()
 #ifdef F2_STAMPS
                 F2_STAMP(ts_c)
                 sum_init += ts_c - ts_b;
