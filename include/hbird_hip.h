@@ -10,8 +10,8 @@
  *
  * Conventions: every function returns 0 on success and a negative status on failure, in which case
  * hb_last_error() (thread-local) describes it.  All matrices are dense row-major fp32 / int64.  One
- * index handle lives on ONE GPU (one process per GPU; shards and replicas are composed above this ABI
- * with RCCL).  Calls on one handle must be serialised by the caller; work is
+ * index handle (hb_index_t) lives on ONE GPU; one process per GPU composes shards and replicas above this ABI
+ * with RCCL, one process with several GPUs uses an hb_multi_t, declared below.  Calls on one handle must be serialised by the caller; work is
  * enqueued on the handle's stream (hb_index_set_stream) and host-pointer variants synchronise it.
  * `*_on_device` = 1 means the pointer is device memory of the handle's GPU, 0 means host memory.
  */
@@ -98,6 +98,26 @@ int hb_merge_topk(const float* dist_parts, const int64_t* idx_parts, int parts, 
 int64_t hb_packed_list_bytes(int64_t nq, int k);
 int hb_merge_topk_packed(const void* packed_parts, int64_t part_bytes, int parts, int64_t nq, int k, int metric,
                          int64_t* out_idx, float* out_dist, void* hip_stream);
+
+/* ---- several GPUs behind one handle ------------------------------------------------------------------ */
+/* faiss.index_cpu_to_gpu_multiple_py(resources, index_cpu, gpus=gpu_ids) with co.shard = idx_shard, search_faiss.py:50-76:
+ * one hb_index_t per entry of gpu_ids (an id may repeat) driven by one host thread each (faiss `threaded = True`, 57).
+ * shard = 1: faiss.IndexShards (53-63) -- contiguous row ranges with successive ids, every GPU searches all queries, the
+ * [nq, k] lists are merged by (ordering score descending, id ascending) and converted to the metric's distances as the
+ * single-index search converts them: the single-index result bit for bit.  shard = 0: faiss.IndexReplicas (65-74) -- every
+ * GPU holds all rows, the queries are split.  All buffers are HOST memory (the reference hands numpy arrays, 80-81, 88).
+ * hb_multi_reserve plans the row count (shards: equal contiguous ranges; rows beyond the plan go to the last shard; without a
+ * plan everything goes to the first).  hb_multi_shard_rows: rows held by the first n entries.  hb_multi_set_fp16 as
+ * hb_index_set_fp16.  Host composition of the entries above; in Python the same is hbird_mi.nn.search_hip.HipMultiIndex. */
+typedef struct hb_multi hb_multi_t;
+int hb_multi_create(int d, int metric, const int* gpu_ids, int n_gpus, int shard, hb_multi_t** out);
+int hb_multi_free(hb_multi_t* m);
+int hb_multi_reserve(hb_multi_t* m, int64_t n_rows);
+int hb_multi_add(hb_multi_t* m, const float* x, int64_t n, int normalize);
+int64_t hb_multi_ntotal(const hb_multi_t* m);
+int hb_multi_shard_rows(const hb_multi_t* m, int64_t* rows, int n);
+int hb_multi_set_fp16(hb_multi_t* m, int enable);
+int hb_multi_search(hb_multi_t* m, const float* q, int64_t nq, int k, int64_t* out_idx, float* out_dist);
 
 /* ---- bank build (device pointers, enqueued on hip_stream) -------------------------------------- */
 /* features / torch.norm(features, dim=-1, keepdim=True), hbird_eval.py:324, 335. */

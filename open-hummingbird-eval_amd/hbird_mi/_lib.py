@@ -42,6 +42,14 @@ SIGNATURES = {
     "hb_merge_topk": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "hb_packed_list_bytes": (c_int64, [c_int64, c_int]),
     "hb_merge_topk_packed": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "hb_multi_create": (c_int, [c_int, c_int, POINTER(c_int), c_int, c_int, POINTER(c_void_p)]),
+    "hb_multi_free": (c_int, [c_void_p]),
+    "hb_multi_reserve": (c_int, [c_void_p, c_int64]),
+    "hb_multi_add": (c_int, [c_void_p, c_void_p, c_int64, c_int]),
+    "hb_multi_ntotal": (c_int64, [c_void_p]),
+    "hb_multi_shard_rows": (c_int, [c_void_p, POINTER(c_int64), c_int]),
+    "hb_multi_set_fp16": (c_int, [c_void_p, c_int]),
+    "hb_multi_search": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "hb_normalize_rows": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "hb_patch_label_hist": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "hb_patch_scores": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -150,3 +150,41 @@ def test_bench_gpus_8_ragged_shards_equal_the_single_rank_result(cuda_device):
     assert c1["bits"] == c8["bits"], (c1, c8)
     assert abs(c1["sum"] - c8["sum"]) <= 1e-9 * abs(c1["sum"])
     assert abs(c1["sum"] - 3001) < 1e-2                           # soft labels: every label_hat row sums to 1
+
+
+@pytest.mark.parametrize("metric,shard,fp16", [("dot_product", 1, False), ("l2", 1, False), ("l2", 0, False), ("dot_product", 1, True)])
+def test_c_abi_multi_gpu_handle(cuda_device, metric, shard, fp16):
+    """hb_multi_*: shards / replicas over several GPUs behind ONE handle of the C ABI (what a non-Python host binds instead of
+    redoing the composition; search_faiss.py:50-76), host buffers in and out like the reference's numpy arrays.  cuda:0 listed
+    three times: the single-index bits, ties across the shard boundaries included, rows appended in ragged pieces."""
+    import ctypes
+    L = _lib.lib()
+    M, D, nq, k = 50_001, 64, 777, 30
+    bank = gi.unit_bank(M, D, seed=7)
+    bank[40_000:40_005] = bank[9]; bank[25_000] = bank[9]
+    q = gi.vit_like_queries(nq, D, seed=8); q[:5] = 3.0 * bank[9]
+    m = 0 if metric == "dot_product" else 1
+    h = ctypes.c_void_p()
+    ids = (ctypes.c_int * 3)(0, 0, 0)
+    bad = (ctypes.c_int * 2)(0, 99)
+    assert L.hb_multi_create(D, m, bad, 2, shard, ctypes.byref(h)) != 0 and b"invalid GPU id" in L.hb_last_error()
+    _lib.check(L.hb_multi_create(D, m, ids, 3, shard, ctypes.byref(h)))
+    try:
+        _lib.check(L.hb_multi_set_fp16(h, 1 if fp16 else 0))
+        _lib.check(L.hb_multi_reserve(h, M))
+        for a, b in ((0, 10_000), (10_000, 33_333), (33_333, M)):            # pieces that straddle the shard boundaries
+            piece = np.ascontiguousarray(bank[a:b])
+            _lib.check(L.hb_multi_add(h, piece.ctypes.data_as(ctypes.c_void_p), b - a, 0))
+        rows = (ctypes.c_int64 * 3)()
+        _lib.check(L.hb_multi_shard_rows(h, rows, 3))
+        assert L.hb_multi_ntotal(h) == M
+        assert list(rows) == ([16667, 16667, 16667] if shard else [M, M, M])
+        idx = np.empty((nq, k), np.int64); dist = np.empty((nq, k), np.float32)
+        _lib.check(L.hb_multi_search(h, q.ctypes.data_as(ctypes.c_void_p), nq, k, idx.ctypes.data_as(ctypes.c_void_p),
+                                     dist.ctypes.data_as(ctypes.c_void_p)))
+        ridx, rdist = oracle.knn_chain_f32(q, bank, k, metric)
+        assert np.array_equal(idx, ridx) and np.array_equal(dist.view(np.uint32), rdist.view(np.uint32))
+        assert L.hb_multi_search(h, q.ctypes.data_as(ctypes.c_void_p), nq, 0, idx.ctypes.data_as(ctypes.c_void_p),
+                                 dist.ctypes.data_as(ctypes.c_void_p)) != 0
+    finally:
+        L.hb_multi_free(h)

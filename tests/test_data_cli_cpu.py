@@ -265,6 +265,13 @@ def test_c_abi_rejects_a_null_handle_without_a_gpu():
     taking_ix = {n for n, (_, a) in _lib.SIGNATURES.items() if n.startswith("hb_index_") and n != "hb_index_create"}
     assert taking_ix == set(calls) | {"hb_index_add", "hb_index_search", "hb_index_set_fp16", "hb_index_ntotal",
                                       "hb_index_nlabels", "hb_index_free"}, "an hb_index_* entry is not covered above"
+    # the multi-GPU handle: NULL is an error (or -1 rows), a bad GPU list fails before any device is touched
+    h = ctypes.c_void_p()
+    assert L.hb_multi_create(8, 0, None, 0, 1, ctypes.byref(h)) != 0 and b"at least one GPU" in L.hb_last_error()
+    for name, args in {"hb_multi_reserve": (None, 10), "hb_multi_add": (None, None, 1, 0), "hb_multi_set_fp16": (None, 1),
+                       "hb_multi_search": (None, None, 1, 1, None, None), "hb_multi_shard_rows": (None, None, 0)}.items():
+        assert getattr(L, name)(*args) != 0 and b"NULL" in L.hb_last_error(), name
+    assert L.hb_multi_ntotal(None) == -1 and L.hb_multi_free(None) == 0
     # the packed-list helpers validate their arguments too
     assert L.hb_packed_list_bytes(21904, 30) == (21904 * 30 * 12 + 15) // 16 * 16
     assert L.hb_merge_topk_packed(None, 64, 2, 4, 1, 0, None, None, None) != 0
