@@ -93,6 +93,7 @@ struct hb_index {
     // fp16 candidate mode (use_fp16): fp16 copies of the bank / query fragment tiles, candidate buffers
     int fp16 = 0, dp16 = 0;
     void* tiles16 = nullptr; int64_t f16_cap_rows = 0, f16_rows = 0;
+    int f16_layout = 0;                                  // block shape of tiles16: 0 = 32 rows x 16 k (first / second design), 1 = 16 rows x 32 k (third)
     int* f16_flag = nullptr; int f16_overflow = 0;       // a finite bank value overflowed fp16: the fp32 kernel serves this bank
     void* q16 = nullptr; size_t q16_bytes = 0;
     char* cand = nullptr; size_t cand_bytes = 0;
@@ -140,6 +141,10 @@ int hb_launch_scatter_rows(const int64_t* rows, int64_t n, int k, const int64_t*
                            int64_t* out_idx, float* out_dist, hipStream_t s);
 struct knn16_args;
 int hb_knn_f16_launch(const knn16_args& args, int grid, int design, hipStream_t s);
+// third design (hbird_knn_f16s.hip): v_mfma_f32_16x16x32_f16 on fp16 blocks of 16 rows x 32 k (their own conversion kernel)
+int hb_knn_f16s_launch(const knn16_args& args, int grid, hipStream_t s);
+int hb_launch_tiles_to_f16s(const float* t32, int g8, _Float16* t16, int g32, int64_t n_row_tiles, int64_t rt0, int* overflow,
+                            hipStream_t s);
 int hb_launch_aggregate(const hb_index* ix, const float* qnorm, const int64_t* idx, const float* dist, int64_t nq,
                         int k, int64_t id_base, float beta, float* out, hipStream_t s);
 int hb_launch_merge_parts(const float* dist_parts, const int64_t* idx_parts, int parts, int64_t nq, int k, int metric,

@@ -662,6 +662,13 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // same box, fp32 / use_fp16 ms: 50 k x 768 (nq 21,904) 13.1 / 13.0, 100 k 24.9 / 16.2; 100 k x 384 (nq 12,544) 8.3 / 10.9,
     // 200 k 15.1 / 11.0; 50 k x 768 (nq 1,369) 2.0 / 2.6, 200 k 4.8 / 3.8.  Same results either way.
     bool f16 = ix->fp16 != 0 && k <= 128 && (ix->fp16 == 1 || ix->ntotal >= 131072);
+    // which candidate kernel: 2 = the second design (32x32x16 MFMA, register-resident query fragments: the default wherever its pools
+    // fit, k' <= 128, i.e. k <= 64), 1 = the first design (variant 2, and pools beyond 256 entries), 3 = the third design on
+    // v_mfma_f32_16x16x32_f16 (variant 5: same bits, not faster -- hbird_knn_f16s.hip)
+    const int kc_f16 = std::min(256, std::max(64, (2 * k + 63) / 64 * 64));
+    const int klw_f16 = std::min(HB_POOL_MAX, (std::max(2 * kc_f16, kc_f16 + 128) + 63) / 64 * 64);
+    const int f16_design = (ix->variant == 2 || klw_f16 > 256) ? 1 : (ix->variant == 5 ? 3 : 2);
+    const int f16_layout = f16_design == 3 ? 1 : 0;
     if (f16 && nq > 0 && ix->ntotal > 0) {
         // bring the fp16 copy of the bank fragment tiles up to date.  A finite value beyond the fp16 range (|x| > 65504) turns
         // into inf there and the scores into inf / NaN, which the exactness certificate cannot bound: such a bank stays on the
@@ -675,9 +682,11 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
             HB_HIP(hipMemsetAsync(ix->tiles16, 0, (size_t)ix->cap_rows * ix->dp16 * 2, s0));
             ix->f16_cap_rows = ix->cap_rows;
         }
+        if (ix->f16_layout != f16_layout) { ix->f16_rows = 0; ix->f16_layout = f16_layout; }   // the other kernel's block shape: convert again
         if (ix->f16_rows < ix->ntotal) {
             const int64_t rt0 = ix->f16_rows / 32, need_rt = (ix->ntotal + 31) / 32;
-            if (hb_launch_tiles_to_f16(ix->tiles, ix->g8, (_Float16*)ix->tiles16, ix->dp16 / 16, need_rt - rt0, rt0, ix->f16_flag, s0)) return -1;
+            if (f16_layout ? hb_launch_tiles_to_f16s(ix->tiles, ix->g8, (_Float16*)ix->tiles16, ix->dp16 / 32, need_rt - rt0, rt0, ix->f16_flag, s0)
+                           : hb_launch_tiles_to_f16(ix->tiles, ix->g8, (_Float16*)ix->tiles16, ix->dp16 / 16, need_rt - rt0, rt0, ix->f16_flag, s0)) return -1;
             ix->f16_rows = ix->ntotal;
             HB_HIP(hipMemcpyAsync(&ix->f16_overflow, ix->f16_flag, 4, hipMemcpyDeviceToHost, s0));
             HB_HIP(hipStreamSynchronize(s0));
@@ -714,7 +723,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // does not know strided segments.
     int cq = 1, cb = 1;
     if (ix->force_cq > 0 && ix->force_cb > 0) { cq = ix->force_cq; cb = ix->force_cb; }
-    else if (f16 && ix->variant == 0 && ix->force_cq == 0) hb_default_cluster(nqt, nbt, G, false, &cq, &cb);   // fp16 second design: -8 %
+    else if (f16 && (ix->variant == 0 || ix->variant == 5) && ix->force_cq == 0) hb_default_cluster(nqt, nbt, G, false, &cq, &cb);   // fp16 second design: -8 %
     // fp32: only beside the kernel with register-resident query fragments (its sync is free of spills), and only for the
     // biggest searches: 2 x 4 clusters cut the fabric reads by 60 % (10 M x 768: 4.79 -> 1.93 TB per search, L2 hit rate
     // 10 % -> 63 %) but the kernel is bound by the matrix pipe, so all they can do for the time is cost little -- measured
@@ -782,7 +791,8 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         // fp16 copy of the query fragment tiles (the bank's is up to date: top of this function)
         const int64_t nqp = (int64_t)nqt * HB_QT;
         if (ensure_bytes((char**)&ix->q16, &ix->q16_bytes, (size_t)nqp * ix->dp16 * 2)) return -1;
-        if (hb_launch_tiles_to_f16(ix->q_tiles, ix->g8, (_Float16*)ix->q16, ix->dp16 / 16, nqp / 32, 0, nullptr, s)) return -1;
+        if (f16_layout ? hb_launch_tiles_to_f16s(ix->q_tiles, ix->g8, (_Float16*)ix->q16, ix->dp16 / 32, nqp / 32, 0, nullptr, s)
+                       : hb_launch_tiles_to_f16(ix->q_tiles, ix->g8, (_Float16*)ix->q16, ix->dp16 / 16, nqp / 32, 0, nullptr, s)) return -1;
         if (ensure_bytes(&ix->cand, &ix->cand_bytes, (size_t)nq * kc * 12)) return -1;
         int64_t* cand_idx = reinterpret_cast<int64_t*>(ix->cand);
         float* cand_dist = reinterpret_cast<float*>(ix->cand + (size_t)nq * kc * 8);
@@ -792,7 +802,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         h.state_cnt = a.state_cnt; h.state_thr = a.state_thr; h.gthr = a.gthr;
         h.wg_member = a.wg_member; h.prog = a.prog; h.cl = a.cl; h.lag = a.lag; h.cl_stats = a.cl_stats;
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev0, s));
-        if (hb_knn_f16_launch(h, sc.G, ix->variant == 2 ? 1 : 2, s)) return -1;   // variant 2 = the first design, for A/B
+        if (f16_design == 3 ? hb_knn_f16s_launch(h, sc.G, s) : hb_knn_f16_launch(h, sc.G, f16_design, s)) return -1;
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
         if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, pool_cnt ? a.state_thr : nullptr, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
                          reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, kc, klw, 0, 0, nullptr,

@@ -108,7 +108,7 @@ def test_cluster_soft_sync_holds_the_members_together(cuda_device):
     ix = HipFlatIndex(D, 0, 0)
     ix.add(bank)
     ref = ix.search(q, k)
-    for variant, fp16 in ((0, False), (4, False), (0, True)):
+    for variant, fp16 in ((0, False), (4, False), (0, True), (5, True)):
         ix.set_variant(variant); ix.set_fp16(fp16)
         for shape in ((2, 2, 16), (4, 1, 16), (2, 4, 16), (8, 1, 16)):
             ix.set_cluster(*shape)
@@ -486,6 +486,13 @@ def test_use_fp16_candidate_pass_with_exact_rerank(cuda_device, M, D, nq, k, met
     ix.add(bank[:100] * 0.5)                    # appending after a search re-converts the touched tiles
     idx, dist = ix.search(q, k)
     _check_exact(idx, dist, q, np.concatenate([bank, bank[:100] * 0.5]), k, metric)
+    # the other candidate kernels (2: first design, 5: 16x16x32 MFMA on its own fp16 block shape -- switching re-converts the
+    # bank copy) and back: the same bits
+    for variant in (5, 2, 5, 0):
+        ix.set_variant(variant)
+        ix.set_tuning(0 if variant else 6, 0)
+        idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
+        _check_exact(idx, dist, q, np.concatenate([bank, bank[:100] * 0.5]), k, metric)
 
 
 def test_use_fp16_certificate_and_exact_fallback(cuda_device):
