@@ -167,12 +167,17 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
 #define BD_REQ_Y1(U) issue_a(fbt, fks, slot_f); BD_BLOAD(bq[((U) + 3) & 3])
 #define BD_REQ_Y2 advance_fetch();
 #endif
+#ifdef BD_FLOOR_LATE   /* experiment: the floors requested in the tile's LAST four stages (one tile fresher) instead of its first */
+#define BD_FLOOR_KS (g8 - 4)
+#else
+#define BD_FLOOR_KS 0
+#endif
 #define BD_STAGE(U)                                                                                                     \
         {                                                                                                               \
             BD_WAIT(3, 1, bq[((U) + 1) & 3])   /* stage st + 1 has landed for me (st + 2 in flight) ... */              \
             __builtin_amdgcn_s_barrier();      /* ... and for everyone; the slot of stage st - 1 is free for st + 3 */   \
             /* small searches: this tile's floors, requested HERE so that they are older than the stage's own requests */ \
-            if constexpr (COLD && (U) == 0) { if (ks == 0) small_floor_request(HB_KARG(knn_args, qfl), HB_KARG(knn_args, gthr), seg, w, lane, qf, sc); } \
+            if constexpr (COLD && (U) == 0) { if (ks == BD_FLOOR_KS) small_floor_request(HB_KARG(knn_args, qfl), HB_KARG(knn_args, gthr), seg, w, lane, qf, sc); } \
             int slot_n = slot_c + 1; if (slot_n == BD_RING) slot_n = 0;                                                 \
             const f32x4* Ac = reinterpret_cast<const f32x4*>(smem + slot_c * BD_SLOT) + lane;                           \
             const f32x4* An = reinterpret_cast<const f32x4*>(smem + slot_n * BD_SLOT) + lane;                           \

@@ -4,7 +4,7 @@
 set -x
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$ROOT/gpurun_out/prof_${1:-r2}
+OUT=$ROOT/gpurun_out/prof_${1:-r3}
 mkdir -p $OUT
 cd /tmp
 B="python3 $ROOT/bench.py --no-cpu-baseline --no-traffic"
