@@ -144,10 +144,11 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
             int slot_n = slot_c + 1; if (slot_n == KN_RING) slot_n = 0;
             const f32x4* Ac = reinterpret_cast<const f32x4*>(smem + slot_c * KN_SLOT_BYTES) + lane;
             const f32x4* An = reinterpret_cast<const f32x4*>(smem + slot_n * KN_SLOT_BYTES) + lane;
+            // small searches: the floors of this tile come in by LDS-DMA during its last four stages (older than the stage's copies:
+            // the hand-counted vmcnt still holds; four stages of counted waits cover them) and are read at its end -- requested at
+            // the tile's START they were one tile staler: 50,176 x 384 4.62 -> 4.53 ms on the kernel with register-resident fragments
+            if constexpr ((ABL & 512) && !WIDE) { if (ks == (g8 > 4 ? g8 - 4 : 0)) small_floor_request(a.qfl, a.gthr, seg, w, lane, qf, sc); }
             if (ks == 0) {
-                // small searches: the floors of this tile come in by LDS-DMA while it is computed (older than the stage's copies:
-                // the hand-counted vmcnt still holds) and are read at its end
-                if constexpr ((ABL & 512) && !WIDE) small_floor_request(a.qfl, a.gthr, seg, w, lane, qf, sc);
                 const f32x4* bi = reinterpret_cast<const f32x4*>(smem + KN_BINIT + (CL ? cpar : (bt & 1)) * 1024);
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
@@ -202,8 +203,9 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
                     else {
                         if constexpr (ABL & 512) {   // small searches: radix-select cold start (separate instantiation, see launcher)
                             if (seg.first && bt == seg.b_tile0) thr = fmaxf(thr, cold_start_threshold(acc, k));
-                            // the floors requested at the tile's start (waves 4-7 have nothing else in flight; waves 0-3 have
-                            // passed dozens of counted waits since)
+                            // the floors requested four stages ago (waves 4-7 have nothing else in flight; waves 0-3 have passed
+                            // counted waits that cover them -- except in a one-stage tile, D <= 8)
+                            if (g8 < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 .Lfl_%=\n\ts_waitcnt vmcnt(0)\n.Lfl_%=:" :: "s"(w) : "memory", "scc");
                             thr = fmaxf(thr, small_floor_read(seg, qf, sc, lane));
                         }

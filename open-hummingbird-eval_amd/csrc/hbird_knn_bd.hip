@@ -167,10 +167,13 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
 #define BD_REQ_Y1(U) issue_a(fbt, fks, slot_f); BD_BLOAD(bq[((U) + 3) & 3])
 #define BD_REQ_Y2 advance_fetch();
 #endif
-#ifdef BD_FLOOR_LATE   /* experiment: the floors requested in the tile's LAST four stages (one tile fresher) instead of its first */
-#define BD_FLOOR_KS (g8 - 4)
-#else
+// small searches: the floors are requested in the tile's LAST four stages (at its start they were one tile staler: 50,176 x 384
+// 4.62 -> 4.53 ms, 200 k x 384 15.12 -> 14.98; -DBD_FLOOR_EARLY for the A/B).  Four stages of counted waits cover the request for
+// waves 0-3, waves 4-7 wait for it explicitly before they read.
+#ifdef BD_FLOOR_EARLY
 #define BD_FLOOR_KS 0
+#else
+#define BD_FLOOR_KS (g8 - 4)
 #endif
 #define BD_STAGE(U)                                                                                                     \
         {                                                                                                               \
