@@ -65,6 +65,13 @@ int hb_index_search_aggregate(hb_index_t* ix, const float* q, int64_t nq, int k,
  * idx are global ids; q, idx, dist, out are device pointers (io_on_device must be 1). */
 int hb_index_aggregate(hb_index_t* ix, const float* q, int64_t nq, const int64_t* idx, const float* dist, int k,
                        int64_t id_base, float beta, float* out_label_hat, int io_on_device);
+/* Label-sharded aggregation (multi-GPU without replicating label_memory: 6.2 GB at cfg-3, 16.7 GB for the full ADE20K bank): the
+ * bank-row norms of ALL rows are replicated (norms_all[n_all], global ids from 0: 4 B per row), the label rows stay with their
+ * owners.  Every rank calls this with the same merged neighbours and gets the softmax-weighted sum over the neighbours IT owns
+ * (global ids [id_base, id_base + ntotal)); the sum of the ranks' out_partial[nq, c] (an all-reduce) is label_hat.  The weights are
+ * computed identically everywhere; only the order of the fp32 sum differs from hb_index_aggregate (within 1e-6).  Device pointers. */
+int hb_index_aggregate_partial(hb_index_t* ix, const float* q, int64_t nq, const int64_t* idx, const float* dist, int k,
+                               int64_t id_base, float beta, const float* norms_all, int64_t n_all, float* out_partial);
 /* feature_memory.index_select(0, idx) (hbird_eval.py:632) for return_knn_details; out[n, d]. */
 int hb_index_reconstruct(hb_index_t* ix, const int64_t* ids, int64_t n, int64_t id_base, float* out,
                          int io_on_device);

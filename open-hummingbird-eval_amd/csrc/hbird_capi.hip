@@ -397,6 +397,23 @@ extern "C" int hb_index_aggregate(hb_index_t* ix, const float* q, int64_t nq, co
     return hb_launch_aggregate(ix, ix->q_aux + nq, idx, dist, nq, k, id_base, beta, out_label_hat, ix->stream);
 }
 
+extern "C" int hb_index_aggregate_partial(hb_index_t* ix, const float* q, int64_t nq, const int64_t* idx, const float* dist, int k,
+                                          int64_t id_base, float beta, const float* norms_all, int64_t n_all, float* out_partial) {
+    if (!ix) return hb_fail("hb_index_aggregate_partial: NULL index handle");
+    if (nq == 0) return 0;
+    if (!q || !idx || !dist || !norms_all || !out_partial) return hb_fail("hb_index_aggregate_partial: NULL pointer");
+    if (!(beta > 0.f)) return hb_fail("hb_index_aggregate_partial: beta must be positive");
+    hb_range range("hbird:aggregate_partial");
+    HB_HIP(hipSetDevice(ix->device));
+    if (ix->ntotal == 0) {   // an empty shard owns no neighbour: its partial sums are zero
+        HB_HIP(hipMemsetAsync(out_partial, 0, (size_t)nq * ix->c * 4, ix->stream));
+        return 0;
+    }
+    if (grow((void**)&ix->q_aux, &ix->q_aux_bytes, (size_t)nq * 2 * 4)) return -1;
+    if (hb_launch_query_aux(q, nq, ix->d, ix->q_aux, ix->q_aux + nq, ix->stream)) return -1;
+    return hb_launch_aggregate(ix, ix->q_aux + nq, idx, dist, nq, k, id_base, beta, out_partial, ix->stream, norms_all, n_all);
+}
+
 static int gather_impl(hb_index* ix, const int64_t* ids, int64_t n, int64_t id_base, float* out, int io_on_device,
                        bool labels) {
     if (n == 0) return 0;

@@ -146,7 +146,7 @@ int hb_knn_f16s_launch(const knn16_args& args, int grid, hipStream_t s);
 int hb_launch_tiles_to_f16s(const float* t32, int g8, _Float16* t16, int g32, int64_t n_row_tiles, int64_t rt0, int* overflow,
                             hipStream_t s);
 int hb_launch_aggregate(const hb_index* ix, const float* qnorm, const int64_t* idx, const float* dist, int64_t nq,
-                        int k, int64_t id_base, float beta, float* out, hipStream_t s);
+                        int k, int64_t id_base, float beta, float* out, hipStream_t s, const float* norms_all = nullptr, int64_t n_all = 0);
 int hb_launch_merge_parts(const float* dist_parts, const int64_t* idx_parts, int parts, int64_t nq, int k, int metric,
                           int64_t dist_stride, int64_t idx_stride, int64_t* out_idx, float* out_dist, hipStream_t s);
 int hb_launch_patch_label_hist(const int64_t* y, int64_t B, int H, int W, int ps, int C, int map255, float* out,

@@ -33,6 +33,8 @@ SIGNATURES = {
                                           c_void_p, c_int]),
     "hb_index_aggregate": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64, c_float,
                                    c_void_p, c_int]),
+    "hb_index_aggregate_partial": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64, c_float, c_void_p, c_int64,
+                                           c_void_p]),
     "hb_index_reconstruct": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int]),
     "hb_index_gather_labels": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int]),
     "hb_index_set_label_table": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64]),

@@ -116,6 +116,10 @@ class HbirdEvaluation:
         # replica per rank and data-parallel validation batches (faiss.IndexReplicas, 65-74); idx_shard=True row-shards
         # the bank over the ranks (faiss.IndexShards, 53-63) -- the mode for banks that should not be built N times
         self.sharded = self.world > 1 and bool(nn_params.get("idx_shard", False))
+        # label_shard (with idx_shard under torch.distributed; not in the reference): label_memory stays sharded with the bank instead of
+        # being replicated on every rank (6.2 GB at BASELINE cfg-3, 16.7 GB for the full ADE20K bank); only the bank-row norms are
+        # replicated (4 B per row) and every search ends in one more all-reduce of [queries, classes] partial sums
+        self.label_shard = self.sharded and bool(nn_params.get("label_shard", False))
         if self.world > 1:
             logger.warning("torch.distributed world of %d ranks: bank %s (nn_params['idx_shard']=%s)", self.world,
                            "row-sharded over the ranks" if self.sharded else "replicated on every rank", self.sharded)
@@ -253,12 +257,15 @@ class HbirdEvaluation:
         self.id_base = sum(counts[:self.rank])
         self.total_rows = sum(counts)
         self.index.use_current_stream()
+        nrm_all, _ = hdist.allgather_rows(self.index.copy_norms())
+        norms = torch.cat([nrm_all[r, :counts[r]] for r in range(self.world)]).contiguous()
+        if self.label_shard:
+            self._label_table = (None, norms)          # label rows stay with their owners
+            return
         lab_local = (self.index.gather_labels(torch.arange(n_local, device=self.gpu_device)) if n_local
                      else torch.zeros((0, self.num_classes), device=self.gpu_device))
         lab_all, _ = hdist.allgather_rows(lab_local)
-        nrm_all, _ = hdist.allgather_rows(self.index.copy_norms())
         labels = torch.cat([lab_all[r, :counts[r]] for r in range(self.world)]).contiguous()
-        norms = torch.cat([nrm_all[r, :counts[r]] for r in range(self.world)]).contiguous()
         self._label_table = (labels, norms)
         self.index.set_label_table(labels, norms, 0)
 
@@ -475,8 +482,15 @@ class HbirdEvaluation:
                 mx = qall.shape[1]
                 if mx == 0:
                     continue
-                idx, dist = self.find_neighbours(qall.view(self.world * mx, D), k)   # collective inside
-                kf_all = None
+                q_flat_all = qall.view(self.world * mx, D)
+                idx, dist = self.find_neighbours(q_flat_all, k)   # collective inside
+                lh_all = None
+                if self.label_shard:
+                    # every rank: the weights of the full lists, the label sum over the neighbours it owns; the all-reduce completes it
+                    self.index.use_current_stream()
+                    lh_all = self.index.aggregate_partial(q_flat_all, idx, dist, self._label_table[1], beta=0.02, id_base=self.id_base)
+                    torch.distributed.all_reduce(lh_all)
+                kf_all, kl_all = None, None
                 if want_details:
                     # neighbour features live on their owning shard: every rank fills in its own rows, the
                     # all-reduce (sum with zeros) completes them -- a collective, so all ranks take part
@@ -486,14 +500,24 @@ class HbirdEvaluation:
                                                     id_base=self.id_base)
                     torch.distributed.all_reduce(kf_all)
                     kf_all = kf_all.view(self.world * mx, k, D)
+                    if self.label_shard:       # neighbour label rows the same way (ids outside this shard come back as zero rows)
+                        local = torch.where(own, flat - self.id_base, torch.full_like(flat, -1))
+                        kl_all = (self.index.gather_labels(local) if self.index.ntotal
+                                  else torch.zeros((flat.numel(), self.num_classes), device=self.gpu_device))
+                        torch.distributed.all_reduce(kl_all)
+                        kl_all = kl_all.view(self.world * mx, k, -1)
                 if mine is None:
                     continue
                 lo = self.rank * mx
                 my_idx, my_dist = idx[lo:lo + q.shape[0]].contiguous(), dist[lo:lo + q.shape[0]].contiguous()
                 self.index.use_current_stream()
-                label_hat = self.index.aggregate(q.contiguous(), my_idx, my_dist, beta=0.02).view(B, N, -1)
+                if self.label_shard:
+                    label_hat = lh_all[lo:lo + q.shape[0]].contiguous().view(B, N, -1)
+                else:
+                    label_hat = self.index.aggregate(q.contiguous(), my_idx, my_dist, beta=0.02).view(B, N, -1)
                 if want_details:
-                    kl = ops.gather_rows(self._label_table[0], my_idx.reshape(-1)).view(B, N, k, -1)
+                    kl = (kl_all[lo:lo + q.shape[0]].reshape(B, N, k, -1) if self.label_shard
+                          else ops.gather_rows(self._label_table[0], my_idx.reshape(-1)).view(B, N, k, -1))
                     knns.append(kf_all[lo:lo + q.shape[0]].reshape(B, N, k, D).cpu())
                     knns_labels.append(kl.cpu())
                     knns_ca_labels.append(label_hat.cpu())

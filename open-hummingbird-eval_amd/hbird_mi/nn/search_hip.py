@@ -153,6 +153,19 @@ class HipFlatIndex:
                                                   int(id_base), float(beta), _ptr(out), 1))
         return out
 
+    def aggregate_partial(self, q, idx, dist, norms_all: torch.Tensor, beta: float = 0.02, id_base: int = 0):
+        """Label-sharded aggregation: the softmax-weighted label sum over the neighbours THIS index owns (global ids id_base ..),
+        with the weights of the full neighbour list (norms_all: the bank-row norms of all rows, global ids from 0).  The sum
+        over the shards (an all-reduce) is label_hat."""
+        assert q.is_cuda and idx.is_cuda and dist.is_cuda and norms_all.is_cuda
+        q = q.contiguous().float(); idx = idx.contiguous(); dist = dist.contiguous(); norms_all = norms_all.contiguous().float()
+        if self.ntotal == 0:                 # an empty shard owns no neighbour
+            return torch.zeros((q.shape[0], self.num_classes), dtype=torch.float32, device=q.device)
+        out = torch.empty((q.shape[0], self.num_classes), dtype=torch.float32, device=q.device)
+        _lib.check(_lib.lib().hb_index_aggregate_partial(self._h, _ptr(q), q.shape[0], _ptr(idx), _ptr(dist), idx.shape[1], int(id_base),
+                                                         float(beta), _ptr(norms_all), norms_all.shape[0], _ptr(out)))
+        return out
+
     @property
     def num_classes(self) -> int:
         return int(self._c) if hasattr(self, "_c") else self._query_c()

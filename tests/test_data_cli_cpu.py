@@ -249,6 +249,7 @@ def test_c_abi_rejects_a_null_handle_without_a_gpu():
         "hb_index_set_stream": (None, None), "hb_index_reserve": (None, 10), "hb_index_add_labels": (None, None, 1, 3, 0),
         "hb_index_reset": (None,), "hb_index_search_aggregate": (None, None, 1, 1, 0, 0.02, None, None, None, 0),
         "hb_index_aggregate": (None, None, 1, None, None, 1, 0, 0.02, None, 1),
+        "hb_index_aggregate_partial": (None, None, 1, None, None, 1, 0, 0.02, None, 0, None),
         "hb_index_reconstruct": (None, None, 1, 0, None, 0), "hb_index_gather_labels": (None, None, 1, 0, None, 0),
         "hb_index_set_label_table": (None, None, None, 0, 0, 0), "hb_index_copy_norms": (None, None, 0),
         "hb_index_set_score_output": (None, 1), "hb_index_distances_from_scores": (None, None, 1, 1, None),

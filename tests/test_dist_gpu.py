@@ -17,7 +17,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, golden_dir, name, ret):
+def _worker(rank, world, port, golden_dir, name, ret, label_shard=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [root, os.path.join(root, "open-hummingbird-eval_amd"), os.path.join(root, "tests")]
@@ -34,8 +34,9 @@ def _worker(rank, world, port, golden_dir, name, ret):
         torch.rand(17)       # a rank whose CPU generator has drifted: the sharded build re-aligns it with rank 0's
     ev = HbirdEvaluation(IndexedReplayExtractor(c["tokens_by_key"], c["S"], c["D"]), c["train"], num_classes=c["C"],
                          n_neighbours=c["k"], augmentation_epoch=c["aug"], device="cuda:0", nn_method="faiss",
-                         nn_params={"idx_shard": True}, memory_size=c["mem"], dataset_size=c["nb"] * c["B"])
+                         nn_params={"idx_shard": True, "label_shard": label_shard}, memory_size=c["mem"], dataset_size=c["nb"] * c["B"])
     assert ev.sharded and ev.total_rows == g[f"feature_memory_{name}"].shape[0]
+    assert ev.label_shard == label_shard and (ev._label_table[0] is None) == label_shard
     # this rank's rows are a contiguous slice of the reference bank, in the reference's order
     fm = ev.feature_memory.numpy()
     ref = g[f"feature_memory_{name}"][ev.id_base: ev.id_base + fm.shape[0]]
@@ -50,26 +51,32 @@ def _worker(rank, world, port, golden_dir, name, ret):
     ok = ok and lh.shape == lh_ref.shape and (np.abs(lh - lh_ref) < 5e-5).mean() > 0.999
     rs = g[f"knns_rowsum_{name}"][rank * B:(rank + 1) * B]
     ok = ok and (np.abs(det["knns"].numpy().sum(-1) - rs) < 1e-4).mean() > 0.995
+    same = (det["knns_labels"].numpy() == g[f"knns_labels_{name}"][rank * B:(rank + 1) * B]).all(axis=-1)
+    ok = ok and same.mean() > 0.995
     ret[rank] = (bool(ok), float(jac))
     td.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["unb", "trim"])
-def test_two_rank_sharded_evaluation(cuda_device, golden_dir, name):
+@pytest.mark.parametrize("name,label_shard", [("unb", False), ("trim", False), ("unb", True), ("ade", True)])
+def test_two_rank_sharded_evaluation(cuda_device, golden_dir, name, label_shard):
+    """label_shard=True: label_memory is NOT replicated -- every rank sums the label rows of the neighbours it owns with the
+    weights of the full lists (hb_index_aggregate_partial), one all-reduce completes label_hat; the neighbour label rows of
+    return_knn_details travel the same way."""
     world, port = 2, _free_port()
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(world, port, golden_dir, name, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, golden_dir, name, ret, label_shard), nprocs=world, join=True)
     assert ret[0][0] and ret[1][0], dict(ret)
     assert ret[0][1] == ret[1][1]          # every rank reports the same (all-reduced) mIoU
 
 
-def test_eight_rank_sharded_evaluation_with_empty_shards(cuda_device, golden_dir):
+@pytest.mark.parametrize("label_shard", [False, True])
+def test_eight_rank_sharded_evaluation_with_empty_shards(cuda_device, golden_dir, label_shard):
     """World 8 on the `trim` fixture: 6 flat training batches (3 batches x 2 epochs) over 8 ranks leave ranks 6 and 7
     with EMPTY shards, and 2 validation batches leave six ranks idle in the evaluation step -- the shapes the first real
     8-GPU run meets at the tail of a bank.  Same bank slices, same neighbours, same mIoU as the reference fixture."""
     world, port = 8, _free_port()
     ret = mp.Manager().dict()
-    mp.spawn(_worker8, args=(world, port, golden_dir, "trim", ret), nprocs=world, join=True)
+    mp.spawn(_worker8, args=(world, port, golden_dir, "trim", ret, label_shard), nprocs=world, join=True)
     assert all(ret[r][0] for r in range(world)), dict(ret)
     assert len({ret[r][1] for r in range(world)}) == 1          # every rank reports the same (all-reduced) mIoU
     rows = [ret[r][2] for r in range(world)]
@@ -77,7 +84,7 @@ def test_eight_rank_sharded_evaluation_with_empty_shards(cuda_device, golden_dir
     assert sum(rows) == g["feature_memory_trim"].shape[0] and rows[6] == rows[7] == 0 and all(r > 0 for r in rows[:6])
 
 
-def _worker8(rank, world, port, golden_dir, name, ret):
+def _worker8(rank, world, port, golden_dir, name, ret, label_shard=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [root, os.path.join(root, "open-hummingbird-eval_amd"), os.path.join(root, "tests")]
@@ -94,7 +101,8 @@ def _worker8(rank, world, port, golden_dir, name, ret):
         torch.rand(3 * rank)       # drifted CPU generators: the sharded build re-aligns them with rank 0's
     ev = HbirdEvaluation(IndexedReplayExtractor(c["tokens_by_key"], c["S"], c["D"]), c["train"], num_classes=c["C"],
                          n_neighbours=c["k"], augmentation_epoch=c["aug"], device="cuda:0", nn_method="faiss",
-                         nn_params={"idx_shard": True}, memory_size=c["mem"], dataset_size=c["nb"] * c["B"])
+                         nn_params={"idx_shard": True, "label_shard": label_shard}, memory_size=c["mem"],
+                         dataset_size=c["nb"] * c["B"])
     ok = ev.sharded and ev.total_rows == g[f"feature_memory_{name}"].shape[0]
     fm = ev.feature_memory.numpy()
     ref = g[f"feature_memory_{name}"][ev.id_base: ev.id_base + fm.shape[0]]

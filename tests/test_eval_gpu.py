@@ -305,18 +305,18 @@ def test_use_fp16_through_the_evaluator_only_where_it_pays(cuda_device):
     train = [(torch.zeros(B, 3, 16 * S, 16 * S), torch.randint(0, C, (B, 1, 16 * S, 16 * S)).float() / 255) for _ in range(4)]
     val_tok = torch.randn(B, S * S, D)
     res = {}
+    q = val_tok.reshape(-1, D).cuda()
     for fp16 in (False, True):
         ev = HbirdEvaluation(ReplayExtractor([t.numpy() for t in tok], S, D), train, num_classes=C, device="cuda",
                              nn_method="faiss", nn_params={"use_fp16": fp16})
         assert ev.index.ntotal == 50176
-        q = val_tok.reshape(-1, D).cuda()
         ev.index.use_current_stream()
         lh = ev.index.search_aggregate(q, 30)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            lh = ev.index.search_aggregate(q, 30)
-        torch.cuda.synchronize()
-        res[fp16] = (lh, (time.perf_counter() - t0) / 5, ev.index.schedule_info())
+        res[fp16] = [lh, [], ev]
+    for _ in range(7):                                   # kernel time by HIP events, interleaved, best of seven: immune to host load
+        for fp16 in (False, True):
+            ix = res[fp16][2].index
+            ix.set_timing(True); ix.search_aggregate(q, 30); res[fp16][1].append(ix.last_knn_ms()); ix.set_timing(False)
+    res = {f: (v[0], min(v[1])) for f, v in res.items()}
     assert torch.equal(res[False][0], res[True][0])
     assert res[True][1] < 1.25 * res[False][1], (res[True][1], res[False][1])       # mode 1 measured 1.7x slower here
