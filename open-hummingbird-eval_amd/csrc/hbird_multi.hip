@@ -143,29 +143,37 @@ extern "C" int hb_multi_search(hb_multi_t* m, const float* q, int64_t nq, int k,
             hb_index_set_score_output(m->ix[i], 0);
             return rc;
         })) return -1;
-    // k-way merge of the shards' sorted lists by (score descending, id ascending); missing entries (id -1) sort last
-    std::vector<int> pos(ng);
-    for (int64_t r = 0; r < nq; ++r) {
-        std::fill(pos.begin(), pos.end(), 0);
-        float qn2 = 0.0f;   // chain ||q||^2 of the L2 conversion (hbird_layout.hip: query_aux_kernel)
-        if (m->metric == HB_METRIC_L2)
-            for (int c = 0; c < m->d; ++c) qn2 = std::fmaf(q[r * (int64_t)m->d + c], q[r * (int64_t)m->d + c], qn2);
-        for (int j = 0; j < k; ++j) {
-            int best = -1;
-            for (int i = 0; i < ng; ++i) {
-                if (pos[i] >= k || pi[i][r * k + pos[i]] < 0) continue;
-                if (best < 0) { best = i; continue; }
-                const float s = ps[i][r * k + pos[i]], sb = ps[best][r * k + pos[best]];
-                if (s > sb || (s == sb && pi[i][r * k + pos[i]] < pi[best][r * k + pos[best]])) best = i;
+    // k-way merge of the shards' sorted lists by (score descending, id ascending); missing entries (id -1) sort last.  Rows are
+    // independent: a few host threads share them (21,904 x 30 x 8 shards is 5 M steps per search)
+    auto merge_rows = [&](int64_t r0, int64_t r1) {
+        std::vector<int> pos(ng);
+        for (int64_t r = r0; r < r1; ++r) {
+            std::fill(pos.begin(), pos.end(), 0);
+            float qn2 = 0.0f;   // chain ||q||^2 of the L2 conversion (hbird_layout.hip: query_aux_kernel)
+            if (m->metric == HB_METRIC_L2)
+                for (int c = 0; c < m->d; ++c) qn2 = std::fmaf(q[r * (int64_t)m->d + c], q[r * (int64_t)m->d + c], qn2);
+            for (int j = 0; j < k; ++j) {
+                int best = -1;
+                for (int i = 0; i < ng; ++i) {
+                    if (pos[i] >= k || pi[i][r * k + pos[i]] < 0) continue;
+                    if (best < 0) { best = i; continue; }
+                    const float s = ps[i][r * k + pos[i]], sb = ps[best][r * k + pos[best]];
+                    if (s > sb || (s == sb && pi[i][r * k + pos[i]] < pi[best][r * k + pos[best]])) best = i;
+                }
+                const int64_t o = r * k + j;
+                if (best < 0) { out_idx[o] = -1; out_dist[o] = m->metric == HB_METRIC_L2 ? INFINITY : -INFINITY; continue; }
+                const float s = ps[best][r * k + pos[best]];
+                out_idx[o] = pi[best][r * k + pos[best]];
+                ++pos[best];
+                if (m->metric == HB_METRIC_L2) { const float d2 = std::fmaf(-2.0f, s, qn2); out_dist[o] = d2 > 0.0f ? d2 : 0.0f; }
+                else out_dist[o] = s;
             }
-            const int64_t o = r * k + j;
-            if (best < 0) { out_idx[o] = -1; out_dist[o] = m->metric == HB_METRIC_L2 ? INFINITY : -INFINITY; continue; }
-            const float s = ps[best][r * k + pos[best]];
-            out_idx[o] = pi[best][r * k + pos[best]];
-            ++pos[best];
-            if (m->metric == HB_METRIC_L2) { const float d2 = std::fmaf(-2.0f, s, qn2); out_dist[o] = d2 > 0.0f ? d2 : 0.0f; }
-            else out_dist[o] = s;
         }
-    }
+    };
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), (int64_t)16, nq / 256}));
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(merge_rows, nq * t / nt, nq * (t + 1) / nt);
+    merge_rows(0, nq / nt);
+    for (auto& t : th) t.join();
     return 0;
 }

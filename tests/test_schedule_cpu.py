@@ -153,3 +153,46 @@ def test_automatic_cluster_shape():
 def test_headline_clustered_plan_numbers():
     _, st = plan(86, 39063, 256, 0, cluster=(2, 2))
     assert st["cluster"] == (2, 2) and st["panel_tiles"] == 128 and st["slots"] <= 440 and st["max_slots_per_qtile"] <= 8
+
+
+def test_multi_index_row_planning_without_a_gpu(monkeypatch):
+    """Host logic of HipMultiIndex (one process, several GPUs): reserve() plans equal contiguous row ranges, add() fills the shards
+    one after the other and splits a batch that straddles a boundary, rows beyond the plan go to the last shard, replicas get
+    every row; shard_bases are the successive-id offsets (faiss.IndexShards, search_faiss.py:56-63)."""
+    import numpy as np
+    from hbird_mi.nn import search_hip
+
+    class FakeIndex:
+        def __init__(self, d, metric, device):
+            self.d, self.metric, self.device, self.rows, self.reserved = d, metric, device, [], 0
+        ntotal = property(lambda self: sum(len(r) for r in self.rows))
+        def reserve(self, n): self.reserved = n
+        def add(self, x, normalize=False): self.rows.append(np.asarray(x)[:, 0].copy())
+        def use_current_stream(self): pass
+        def set_fp16(self, e): self.fp16 = e
+        def close(self): pass
+
+    class NoDevice:
+        def __init__(self, *a): pass
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+
+    monkeypatch.setattr(search_hip, "HipFlatIndex", FakeIndex)
+    monkeypatch.setattr(search_hip.torch.cuda, "device", NoDevice)
+    m = search_hip.HipMultiIndex(4, 0, [0, 1, 2], shard=True)
+    m.reserve(100)                                            # 34 + 34 + 32 planned
+    assert [ix.reserved for ix in m.indexes] == [34, 34, 34]
+    rows = np.arange(130, dtype=np.float32)[:, None].repeat(4, 1)
+    for a, b in ((0, 20), (20, 50), (50, 51), (51, 130)):     # 20..50 straddles the first boundary, 51..130 overruns the plan
+        m.add(rows[a:b])
+    assert m.shard_rows == [34, 34, 62] and m.shard_bases == [0, 34, 68] and m.ntotal == 130
+    got = np.concatenate([np.concatenate(ix.rows) for ix in m.indexes])
+    assert np.array_equal(got, np.arange(130))                # successive ids in the order the rows arrived
+    r = search_hip.HipMultiIndex(4, 0, [0, 0], shard=False)
+    r.reserve(10); r.add(rows[:7]); r.add(rows[7:10])
+    assert r.shard_rows == [10, 10] and r.shard_bases == [0, 0] and r.ntotal == 10
+    u = search_hip.HipMultiIndex(4, 0, [0, 1], shard=True)    # no plan: everything into the first shard
+    u.add(rows[:9])
+    assert u.shard_rows == [9, 0]
+    m.set_fp16(2)
+    assert all(ix.fp16 == 2 for ix in m.indexes)
