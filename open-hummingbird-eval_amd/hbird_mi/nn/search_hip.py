@@ -495,8 +495,10 @@ class HipMultiIndex:
                 fb = index.last_fp16_fallbacks()
                 torch.cuda.current_stream(dev).synchronize()
                 idx, d = idx.to(self.home), d.to(self.home)         # peer copy of the [nq, k] lists (xGMI)
-                # the copy was enqueued on THIS thread's current stream of the home device, the caller merges on its own:
-                # the lists must have landed before the worker hands them over
+                # the copy was enqueued on THIS thread's current streams (torch runs a peer copy on the source device's stream and
+                # makes the destination's wait for it), the caller merges on its own: the lists must have landed before the
+                # worker hands them over
+                torch.cuda.current_stream(dev).synchronize()
                 torch.cuda.current_stream(self.home).synchronize()
                 return idx, d, fb
 
@@ -569,7 +571,9 @@ class HipMultiIndex:
                     ix.use_current_stream()
                     part = ix.reconstruct(mine, lo)                 # rows of other shards (id -1) come back as zeros
                     torch.cuda.current_stream(dev).synchronize()
-                out += part.to(self.home)
+                    part = part.to(self.home)
+                    torch.cuda.current_stream(dev).synchronize()
+                out += part
         return out.cpu().numpy() if host else out
 
     def gather_labels(self, ids):
