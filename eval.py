@@ -80,6 +80,11 @@ def parse_nn_params(kv_list: List[str]) -> Dict[str, Any]:
                     continue
             else:
                 out[k] = v
+        # a comma-separated list of GPU ids (`gpu_ids=0,1,2,3`; a single id has become an int above): the reference's parser has no
+        # list form, its Faiss class iterates over whatever it gets (search_faiss.py:22)
+        if k == "gpu_ids":
+            val = out[k]
+            out[k] = [val] if isinstance(val, int) else [int(t) for t in str(val).strip("[]").split(",") if t.strip()]
     return out
 
 

@@ -69,7 +69,9 @@ def test_cli_parsing():
     spec = importlib.util.spec_from_file_location("hb_cli", os.path.join(ROOT, "eval.py"))
     cli = importlib.util.module_from_spec(spec); spec.loader.exec_module(cli)
     assert cli.parse_nn_params(["idx_shard=true", "gpu_ids=3", "beta=0.5", "distance_measure=l2"]) == \
-        {"idx_shard": True, "gpu_ids": 3, "beta": 0.5, "distance_measure": "l2"}
+        {"idx_shard": True, "gpu_ids": [3], "beta": 0.5, "distance_measure": "l2"}
+    assert cli.parse_nn_params(["gpu_ids=0,1, 2", "label_shard=True"]) == {"gpu_ids": [0, 1, 2], "label_shard": True}
+    assert cli.parse_nn_params(["gpu_ids=[4,5]"]) == {"gpu_ids": [4, 5]}
     a = cli.build_parser().parse_args(["--dataset-name", "voc*0.2", "--data-dir", "/x", "--d-model", "384",
                                        "--patch-size", "16", "--nn-method", "faiss", "--nn-param", "use_fp16=false"])
     assert a.n_neighbours == 30 and a.batch_size == 64 and a.input_size == 224 and a.seed == 123
