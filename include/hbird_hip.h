@@ -173,7 +173,8 @@ int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_tiles);
  * returned indices / distances are those of the fp32 search.  Every query carries a certificate (exact k-th score >
  * k'-th fp16 score + rounding bound); queries that fail it are searched again with the fp32 kernel, so the result is
  * ALWAYS the fp32 result.  Applies to k <= 128; larger k use the fp32 kernel.  2 = the same, but only for banks of at
- * least 131,072 rows -- below that the fp32 kernel is the faster way to the same result (what the plugin's use_fp16 sets). */
+ * least 32,768 rows with rows x queries >= 2^27 -- below that the fp32 kernel is the faster way to the same result (what the
+ * plugin's use_fp16 sets). */
 int hb_index_set_fp16(hb_index_t* ix, int enable);
 /* Number of queries of the last fp16-mode search that needed the exact fp32 re-search. */
 int hb_index_last_fp16_fallbacks(const hb_index_t* ix, int64_t* n);
@@ -205,6 +206,12 @@ int hb_index_cluster_stats(hb_index_t* ix, int64_t out[4]);
  * progress word of the block (-1: no cluster)}; stats as hb_index_schedule_info. */
 int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b, int* segs_out,
                      int64_t max_segs, int64_t stats[8]);
+/* The work list of a PHASED search (pools: k > 32 and the fp16 candidate pass): launched in phases of growing size, between
+ * which the k-th best of all rows seen so far becomes every partial pool's floor.  Every block's segments are cut at the same
+ * clocks: clocks_out receives up to max_cuts of them (*n_cuts: how many there are), bounds_out [cut][block] the position,
+ * within the block's own segments, of the first segment of the next phase. */
+int hb_schedule_plan_phased(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b, int* segs_out,
+                            int64_t max_segs, int64_t stats[8], int* clocks_out, int max_cuts, int* n_cuts, int* bounds_out);
 
 #ifdef __cplusplus
 }

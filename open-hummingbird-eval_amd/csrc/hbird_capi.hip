@@ -137,8 +137,8 @@ extern "C" int hb_index_last_fp16_fallbacks(const hb_index_t* ix, int64_t* n) {
 
 // Host-only: build the kNN work list for a (query tiles x bank tiles) grid without touching a GPU, for inspection
 // and tests.  segs_out receives up to max_segs rows of {block, q_tile, b_tile0, n_tiles, slot, first}.
-extern "C" int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b,
-                                int* segs_out, int64_t max_segs, int64_t stats[8]) {
+static int schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b, bool phased,
+                         int* segs_out, int64_t max_segs, int64_t stats[8], hb_schedule& sc) {
     if (!stats) return hb_fail("hb_schedule_plan: stats is NULL");
     if (nqt <= 0 || nbt <= 0 || workgroups <= 0 || d <= 0) return hb_fail("hb_schedule_plan: bad arguments");
     const int dp = (d + HB_KC - 1) / HB_KC * HB_KC;
@@ -147,8 +147,7 @@ extern "C" int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tile
     if (cq < 0 || cb < 0) hb_default_cluster(nqt, nbt, G, cq == -2, &cq, &cb);  // negative: the automatic shape (-1 fp16, -2 fp32 kernel)
     if (cq < 1 || cb < 1 || (long long)nqt * nbt < workgroups || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
     const int panel = panel_tiles > 0 ? panel_tiles : hb_default_panel(nqt, G, (size_t)HB_BT * dp * 4, cq, cb);
-    hb_schedule sc;
-    hb_build_schedule(nqt, nbt, workgroups, panel, sc, cq, cb);
+    hb_build_schedule(nqt, nbt, workgroups, panel, sc, cq, cb, phased);
     stats[0] = sc.G; stats[1] = (int64_t)sc.segs.size(); stats[2] = sc.n_slots; stats[3] = sc.panel;
     stats[4] = sc.max_slots_per_qt; stats[5] = sc.nqt; stats[6] = sc.nbt; stats[7] = sc.cq * 16 + sc.cb;
     if (segs_out) {
@@ -160,6 +159,29 @@ extern "C" int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tile
                 o[0] = b; o[1] = g.q_tile; o[2] = g.b_tile0; o[3] = g.n_tiles; o[4] = g.slot; o[5] = g.first;
                 o[6] = g.stride; o[7] = g.tile0; o[8] = g.next_tile0; o[9] = sc.wg_member[b];
             }
+    }
+    return 0;
+}
+
+extern "C" int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b,
+                                int* segs_out, int64_t max_segs, int64_t stats[8]) {
+    hb_schedule sc;
+    return schedule_plan(nqt, nbt, workgroups, panel_tiles, d, cluster_q, cluster_b, false, segs_out, max_segs, stats, sc);
+}
+
+// The same for a PHASED search (pools: k > 32 and the fp16 candidate pass): the work list with its segments cut at the phase
+// clocks, the clocks, and per cut and block the position (within the block's own segments) of the first segment of the next phase.
+extern "C" int hb_schedule_plan_phased(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b,
+                                       int* segs_out, int64_t max_segs, int64_t stats[8], int* clocks_out, int max_cuts, int* n_cuts,
+                                       int* bounds_out) {
+    if (!n_cuts) return hb_fail("hb_schedule_plan_phased: n_cuts is NULL");
+    hb_schedule sc;
+    if (schedule_plan(nqt, nbt, workgroups, panel_tiles, d, cluster_q, cluster_b, true, segs_out, max_segs, stats, sc)) return -1;
+    *n_cuts = (int)sc.phase_clock.size();
+    for (int p = 0; p < *n_cuts && p < max_cuts; ++p) {
+        if (clocks_out) clocks_out[p] = sc.phase_clock[p];
+        if (bounds_out)
+            for (int b = 0; b < sc.G; ++b) bounds_out[(size_t)p * sc.G + b] = sc.phase_bounds[(size_t)p * sc.G + b] - sc.wg_off[b];
     }
     return 0;
 }

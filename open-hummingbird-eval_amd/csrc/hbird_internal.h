@@ -45,6 +45,7 @@ struct hb_seg {
     int nsl;
 };
 
+#define HB_PHASE_CUTS 24      // most phase boundaries of a pool search (hb_build_schedule: clocks 2, 6, 14, ..., 254, then x 4)
 #define HB_CLUSTER_MAX 8      // workgroups per L2-sharing cluster
 #define HB_CLUSTER_LINE 32    // ints per cluster in the progress array (one 128-B line)
 
@@ -54,6 +55,9 @@ struct hb_schedule {
     std::vector<hb_seg> segs;        // grouped by workgroup
     std::vector<int> wg_off;         // G+1 offsets into segs
     std::vector<int> wg_member;      // per block: cluster * HB_CLUSTER_LINE + member (progress word of the block)
+    bool phased = false;             // pool searches: the segment lists are cut at phase_clock (hb_finish_schedule) ...
+    std::vector<int> phase_clock;    // ... clock values (tiles dealt per workgroup) where a phase ends ...
+    std::vector<int> phase_bounds;   // ... [cuts][G]: per block the first segment at or beyond each of them
     std::vector<int> qt_off;         // nqt+1 offsets into qt_slots
     std::vector<int> qt_slots;       // slots that hold partial lists of each query tile
     int n_slots = 0;
@@ -61,7 +65,7 @@ struct hb_schedule {
     int n_clusters = 0;
 };
 
-void hb_build_schedule(int nqt, int nbt, int G, int panel_tiles, hb_schedule& out, int cq = 1, int cb = 1);
+void hb_build_schedule(int nqt, int nbt, int G, int panel_tiles, hb_schedule& out, int cq = 1, int cb = 1, bool phased = false);
 int hb_default_panel(int nqt, int G, size_t tile_bytes, int cq = 1, int cb = 1);
 // automatic cluster shape for a search (1 x 1 when clusters do not apply)
 void hb_default_cluster(int nqt, int nbt, int G, bool fp32_kernel, int* cq, int* cb);

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
     cl_sync cs;
     if constexpr (CL) cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + KN_CLWORDS);
 
-    const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
+    const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_end[blockIdx.x];   // this launch's share of the block's segments (phases: hb_launch_knn)
 #ifdef KN_STAMPS
     int kn_dbg[2] = {0, 0}, kn_tiles = 0; unsigned long long kn_epi = 0, kn_t0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kn_t0) :: "memory");
@@ -527,6 +527,33 @@ void hb_default_cluster(int nqt, int nbt, int G, bool fp32_kernel, int* cq, int*
 static void hb_finish_schedule(hb_schedule& out, std::vector<std::vector<hb_seg>>& per_wg, const std::vector<int>& logical_of_block,
                                const std::vector<std::vector<int>>& slots_of_qt) {
     const int G = out.G;
+    // Phased searches (hb_build_schedule): every workgroup's segment list is cut at the same CLOCK values (tiles dealt), so that all
+    // workgroups work in every phase and the members of a cluster stay on their common clock; a segment that straddles a cut is
+    // split (same slot, the second piece continues it)
+    const int n_cuts = (int)out.phase_clock.size();
+    std::vector<std::vector<int>> rel(n_cuts, std::vector<int>(G, 0));   // per cut and logical workgroup: index of the first segment at or beyond it
+    if (n_cuts) {
+        for (int w = 0; w < G; ++w) {
+            std::vector<hb_seg> v;
+            v.reserve(per_wg[w].size() + n_cuts);
+            for (hb_seg sg : per_wg[w]) {
+                for (int t : out.phase_clock)
+                    if (t > sg.tile0 && t < sg.tile0 + sg.n_tiles) {
+                        hb_seg head = sg;
+                        head.n_tiles = t - sg.tile0;
+                        v.push_back(head);
+                        sg.b_tile0 += sg.stride * head.n_tiles; sg.tile0 = t; sg.n_tiles -= head.n_tiles; sg.first = 0;
+                    }
+                v.push_back(sg);
+            }
+            per_wg[w].swap(v);
+            for (int p = 0; p < n_cuts; ++p) {
+                int i = 0;
+                while (i < (int)per_wg[w].size() && per_wg[w][i].tile0 < out.phase_clock[p]) ++i;
+                rel[p][w] = i;
+            }
+        }
+    }
     std::map<int, std::pair<int, int>> ord_of;   // slot -> (ordinal among its query tile's slots, their number)
     for (const auto& sl : slots_of_qt)
         for (size_t i = 0; i < sl.size(); ++i) ord_of[sl[i]] = {(int)i, (int)sl.size()};
@@ -536,10 +563,12 @@ static void hb_finish_schedule(hb_schedule& out, std::vector<std::vector<hb_seg>
             v[i].ord = ord_of[v[i].slot].first; v[i].nsl = ord_of[v[i].slot].second;
         }
     out.wg_off.assign(G + 1, 0);
+    out.phase_bounds.assign((size_t)n_cuts * G, 0);
     for (int b = 0; b < G; ++b) {
         const int w = logical_of_block[b];
         out.wg_off[b + 1] = out.wg_off[b] + (int)per_wg[w].size();
         out.segs.insert(out.segs.end(), per_wg[w].begin(), per_wg[w].end());
+        for (int p = 0; p < n_cuts; ++p) out.phase_bounds[(size_t)p * G + b] = out.wg_off[b] + rel[p][w];
     }
     out.qt_off.assign(out.nqt + 1, 0);
     for (int q = 0; q < out.nqt; ++q) {
@@ -599,12 +628,28 @@ static void hb_build_clustered(int nqt, int nbt, int G, int panel, int cq, int c
     hb_finish_schedule(out, per_wg, logical_of_block, slots_of_qt);
 }
 
-void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out, int cq, int cb) {
+void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out, int cq, int cb, bool phased) {
     out = hb_schedule();
-    out.nqt = nqt; out.nbt = nbt; out.panel = panel;
+    out.nqt = nqt; out.nbt = nbt; out.panel = panel; out.phased = phased;
     const long long total_pairs = (long long)nqt * nbt;
     if (total_pairs < G) G = (int)std::max<long long>(1, total_pairs);
     out.G = G;
+    if (phased) {
+        // Cut clocks (tiles dealt per workgroup): 1, 3, 6, 10, 16, 25, ... -- phases that grow by half, twofold beyond 128 tiles;
+        // the last phase keeps at least half of the work.  With the floor fixed during a phase, a phase that multiplies the rows seen
+        // by g appends about k (g - 1) candidates per query, k (g - 1) / ln g per e-fold: g = 2 is 1.44 x the continuous
+        // bound k ln(N / n0), g = 1.5 1.23 x.  Measured (kernel ms, 2,074,072 x 384 fp16): first cut at 1 / 2 / 4 / 8 tiles
+        // 23.6 / 24.0 / 24.0 / 24.4, growth 1.5 / 2 / 3 flat within 0.3; at 50,176 x 384 the first cut is what matters (fp32 k = 90:
+        // 7.85 with cuts from 2 tiles, 6.2 from 1).
+        const long long per_wg_tiles = total_pairs / G;
+        long long t = 0, step = 1;
+        while (out.phase_clock.size() < HB_PHASE_CUTS) {
+            t += step;
+            if (t * 2 > per_wg_tiles) break;
+            out.phase_clock.push_back((int)t);
+            step = std::max<long long>(step + 1, step < 128 ? step * 3 / 2 : step * 2);
+        }
+    }
     if (cq < 1 || cb < 1 || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
     if (cq * cb > 1) { hb_build_clustered(nqt, nbt, G, panel, cq, cb, out); return; }
     std::vector<std::vector<hb_seg>> per_wg(G);
@@ -656,14 +701,35 @@ void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out, int
 }
 
 
+// Phased searches (pools: k > HB_KL and the fp16 candidate pass).  A pool's threshold is the k-th best of ONE slot's share of the rows
+// and only rises when the pool is compacted: with S slots per query tile every slot re-discovers what the others already know, and
+// what the pools' epilogue costs is the candidates it appends, not the test (measured with perfect floors -- a repeated search that
+// starts from the previous one's final floors: fp16 candidate kernel 29.2 -> 19.4 ms at 2,074,072 x 384, 317 -> 300 ms at 10 M x 768;
+// 18.1 ms without any epilogue).  So the search is launched in PHASES of growing size -- every workgroup's segment list cut at the
+// same clocks (hb_build_schedule; whole segments per phase left most workgroups idle in the small phases and was slower than no
+// phases at all) -- and between two phases the slots' pools are merged (the merge kernel of the final result) and the k-th best of
+// ALL rows seen so far becomes every slot's floor: exactly the union's k-th best, so the results keep their bits.  Same box, kernel
+// ms without / with phases: fp16 k = 30: 50,176 x 384 4.62 / 2.30, 300 k x 768 12.35 / 8.45, 1 M x 1024 (4,096 queries) 12.9 /
+// 8.95, 2,074,072 x 384 29.6 / 25.3, 10 M x 768 321.6 / 317; fp32: k = 90 50,176 x 384 9.75 / 6.2, k = 64 300 k x 768 51.2 / 44.8,
+// k = 90 2,074,072 x 384 161.4 / 146.1.  The LDS lists (k <= 32) stay unphased: their slots already exchange floors every tile
+// (small_floor_*) and phases only added launches (50,176 x 384: 4.72 -> 4.86-5.19 ms).
+__global__ __launch_bounds__(256) void seed_floors_kernel(const int64_t* __restrict__ idx, const float* __restrict__ score, int64_t nq, int kk,
+                                                         unsigned* __restrict__ gthr) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    if (idx[q * kk + kk - 1] >= 0) atomicMax(gthr + q, pool_key(score[q * kk + kk - 1]));   // kk rows reach this score: a floor (ties pass)
+}
+
 // q_tiles / q_aux must already be prepared by the caller (hb_index_search).
 int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t id_base, int64_t* out_idx, float* out_dist) {
     if (k < 1 || k > 256) return hb_fail("hb_index_search: k must be in [1, 256]");
-    // fp16 mode 2 (what the plugin's use_fp16=True selects): the candidate pass only where it pays.  Its fixed costs (fp16 query
-    // tiles, re-rank, a second merge, cold pools) scale with the queries like the search itself, so the crossover is a bank size:
-    // same box, fp32 / use_fp16 ms: 50 k x 768 (nq 21,904) 13.1 / 13.0, 100 k 24.9 / 16.2; 100 k x 384 (nq 12,544) 8.3 / 10.9,
-    // 200 k 15.1 / 11.0; 50 k x 768 (nq 1,369) 2.0 / 2.6, 200 k 4.8 / 3.8.  Same results either way.
-    bool f16 = ix->fp16 != 0 && k <= 128 && (ix->fp16 == 1 || ix->ntotal >= 131072);
+    // fp16 mode 2 (what the plugin's use_fp16=True selects): the candidate pass only where it pays.  Its fixed costs are per query
+    // (fp16 query tiles, re-rank, a second merge) and per search (the phases' launches and merges), so the crossover is a bank
+    // size that grows as the queries get few: at least 32,768 rows and rows x queries >= 2^27.  Same box, whole search, fp32 /
+    // use_fp16 ms (phased pools): 12,544 x 384 queries: 16 k rows 2.09 / 2.23, 32 k 3.36 / 3.02, 50 k 4.63 / 3.45, 131 k 10.28 / 5.22;
+    // 21,904 x 768: 32 k 8.79 / 8.97, 50 k 12.85 / 10.66, 131 k 31.4 / 14.6; 784 x 384: 131 k 1.72 / 1.87, 400 k 3.50 / 2.37;
+    // 2,048 x 1024: 16 k 1.25 / 1.22, 50 k 2.64 / 1.72.  Same results either way.
+    bool f16 = ix->fp16 != 0 && k <= 128 && (ix->fp16 == 1 || (ix->ntotal >= 32768 && ix->ntotal * nq >= ((int64_t)1 << 27)));
     // which candidate kernel: 2 = the second design (32x32x16 MFMA, register-resident query fragments: the default wherever its pools
     // fit, k' <= 128, i.e. k <= 64), 1 = the first design (variant 2, and pools beyond 256 entries), 3 = the third design on
     // v_mfma_f32_16x16x32_f16 (variant 5: same bits, not faster -- hbird_knn_f16s.hip)
@@ -725,7 +791,13 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // does not know strided segments.
     int cq = 1, cb = 1;
     if (ix->force_cq > 0 && ix->force_cb > 0) { cq = ix->force_cq; cb = ix->force_cb; }
-    else if (f16 && (ix->variant == 0 || ix->variant == 5) && ix->force_cq == 0) hb_default_cluster(nqt, nbt, G, false, &cq, &cb);   // fp16 second design: -8 %
+    // fp16 candidate kernel: from 400 k stages per workgroup up.  Same box, kernel ms (phased), none vs automatic: 20 M x 384 323.7 /
+    // 314.5, 10 M x 768 324.3 / 307 (21,904 queries, 630 k stages; 359 k with 12,544 queries: 183.7 / 184.7), 7 M x 768 (441 k) 227 / 221.5, 5 M x 1024
+    // 213.7 / 208.9 -- but 5 M x 768 x 12,544 queries (179 k stages) 92.8 / 94.6 and 2,074,072 x 384 (37 k) 22.7 / 24.8: more
+    // slots, shorter segments
+    else if (f16 && (ix->variant == 0 || ix->variant == 5) && ix->force_cq == 0) {
+        if ((long long)nqt * nbt / std::max(1, G) * (ix->dp16 / 16) >= 400000) hb_default_cluster(nqt, nbt, G, false, &cq, &cb);
+    }
     // fp32: only beside the kernel with register-resident query fragments (its sync is free of spills), and only for the
     // biggest searches: 2 x 4 clusters cut the fabric reads by 60 % (10 M x 768: 4.79 -> 1.93 TB per search, L2 hit rate
     // 10 % -> 63 %) but the kernel is bound by the matrix pipe, so all they can do for the time is cost little -- measured
@@ -739,14 +811,19 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     const int panel = ix->force_panel > 0 ? ix->force_panel
                                           : hb_default_panel(nqt, std::min<long long>(G, (long long)nqt * nbt), tile_bytes, cq, cb);
     hb_schedule& sc = ix->sched;
-    const bool rebuilt = !(sc.nqt == nqt && sc.nbt == nbt && sc.panel == panel && sc.cq == cq && sc.cb == cb &&
+    // phased searches (pools only: seed_floors_kernel above); HBIRD_PHASES=0 turns them off (A/B)
+    static const bool phases_on = !(getenv("HBIRD_PHASES") && atoi(getenv("HBIRD_PHASES")) == 0);
+    const bool phased = wide && phases_on && ix->variant != 1;
+    const bool rebuilt = !(sc.nqt == nqt && sc.nbt == nbt && sc.panel == panel && sc.cq == cq && sc.cb == cb && sc.phased == phased &&
                            (sc.G == G || (long long)nqt * nbt < G));
-    if (rebuilt) hb_build_schedule(nqt, nbt, G, panel, sc, cq, cb);
+    if (rebuilt) hb_build_schedule(nqt, nbt, G, panel, sc, cq, cb, phased);
     // device copy of the work list: [segs][wg_off][qt_off][qt_slots][wg_member]
     const size_t b_segs = sc.segs.size() * sizeof(hb_seg), b_wg = sc.wg_off.size() * 4, b_qo = sc.qt_off.size() * 4,
                  b_qs = sc.qt_slots.size() * 4, b_wm = sc.wg_member.size() * 4;
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-    const size_t o_wg = al(b_segs), o_qo = o_wg + al(b_wg), o_qs = o_qo + al(b_qo), o_wm = o_qs + al(b_qs), tot = o_wm + al(b_wm);
+    const size_t b_pb = sc.phase_bounds.size() * 4;
+    const size_t o_wg = al(b_segs), o_qo = o_wg + al(b_wg), o_qs = o_qo + al(b_qo), o_wm = o_qs + al(b_qs), o_pb = o_wm + al(b_wm),
+                 tot = o_pb + al(b_pb);
     const bool need_upload = rebuilt || ix->sched_bytes < tot;
     if (ensure_bytes(&ix->sched_dev, &ix->sched_bytes, tot)) return -1;
     if (need_upload) {
@@ -755,6 +832,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         HB_HIP(hipMemcpyAsync(ix->sched_dev + o_qo, sc.qt_off.data(), b_qo, hipMemcpyHostToDevice, s));
         HB_HIP(hipMemcpyAsync(ix->sched_dev + o_qs, sc.qt_slots.data(), b_qs, hipMemcpyHostToDevice, s));
         HB_HIP(hipMemcpyAsync(ix->sched_dev + o_wm, sc.wg_member.data(), b_wm, hipMemcpyHostToDevice, s));
+        HB_HIP(hipMemcpyAsync(ix->sched_dev + o_pb, sc.phase_bounds.data(), b_pb, hipMemcpyHostToDevice, s));
         HB_HIP(hipStreamSynchronize(s));   // host vectors may be rebuilt by the next call
     }
     const size_t state_half = (size_t)sc.n_slots * HB_QT * klw * 4;
@@ -767,6 +845,12 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     a.bank_tiles = ix->tiles; a.binit = ix->binit; a.q_tiles = ix->q_tiles;
     a.segs = reinterpret_cast<const hb_seg*>(ix->sched_dev);
     a.wg_off = reinterpret_cast<const int*>(ix->sched_dev + o_wg);
+    a.wg_end = a.wg_off + 1;
+    // phases: pools only, and only where a phase is at least a panel's worth of tiles (HBIRD_PHASES=0 turns them off: A/B)
+    const int n_phases = (int)sc.phase_clock.size() + 1;   // 1: a single launch (lists; pools with too little work per workgroup)
+    const int* pb = reinterpret_cast<const int*>(ix->sched_dev + o_pb);
+    auto phase_begin = [&](int p) { return p == 0 ? reinterpret_cast<const int*>(ix->sched_dev + o_wg) : pb + (size_t)(p - 1) * sc.G; };
+    auto phase_end = [&](int p) { return p == n_phases - 1 ? reinterpret_cast<const int*>(ix->sched_dev + o_wg) + 1 : pb + (size_t)p * sc.G; };
     a.state_s = reinterpret_cast<float*>(ix->state);
     a.state_i = reinterpret_cast<unsigned*>(ix->state + state_half);
     a.g8 = ix->g8; a.k = k; a.klw = klw;
@@ -799,12 +883,27 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         int64_t* cand_idx = reinterpret_cast<int64_t*>(ix->cand);
         float* cand_dist = reinterpret_cast<float*>(ix->cand + (size_t)nq * kc * 8);
         knn16_args h;
-        h.bank16 = reinterpret_cast<const _Float16*>(ix->tiles16); h.binit = ix->binit; h.q16 = reinterpret_cast<const _Float16*>(ix->q16); h.segs = a.segs; h.wg_off = a.wg_off;
+        h.bank16 = reinterpret_cast<const _Float16*>(ix->tiles16); h.binit = ix->binit; h.q16 = reinterpret_cast<const _Float16*>(ix->q16); h.segs = a.segs; h.wg_off = a.wg_off; h.wg_end = a.wg_end;
         h.state_s = a.state_s; h.state_i = a.state_i; h.g16 = ix->dp16 / 16; h.k = kc; h.klw = klw;
         h.state_cnt = a.state_cnt; h.state_thr = a.state_thr; h.gthr = a.gthr;
         h.wg_member = a.wg_member; h.prog = a.prog; h.cl = a.cl; h.lag = a.lag; h.cl_stats = a.cl_stats;
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev0, s));
-        if (f16_design == 3 ? hb_knn_f16s_launch(h, sc.G, s) : hb_knn_f16_launch(h, sc.G, f16_design, s)) return -1;
+        if (n_phases > 1) {   // slots that start in a later phase must read as empty pools in the merges between the phases
+            HB_HIP(hipMemsetAsync(a.state_cnt, 0, state_aux, s));
+            HB_HIP(hipMemsetD32Async((hipDeviceptr_t)a.state_thr, 0xFF800000u, state_aux / 4, s));
+        }
+        for (int ph = 0; ph < n_phases; ++ph) {
+            h.wg_off = phase_begin(ph); h.wg_end = phase_end(ph);
+            if (f16_design == 3 ? hb_knn_f16s_launch(h, sc.G, s) : hb_knn_f16_launch(h, sc.G, f16_design, s)) return -1;
+            if (ph + 1 < n_phases) {   // the k'-th best of all rows seen so far -> every slot's floor
+                if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, a.state_thr, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
+                                 reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, kc, klw, 0, 0, nullptr,
+                                 cand_idx, cand_dist, s)) return -1;
+                seed_floors_kernel<<<dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s>>>(cand_idx, cand_dist, nq, kc, a.gthr);
+                HB_HIP(hipGetLastError());
+                if (a.cl > 1) HB_HIP(hipMemsetAsync(a.prog, 0, prog_bytes - HB_CLUSTER_LINE * 4, s));   // progress words (not the statistics)
+            }
+        }
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
         if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, pool_cnt ? a.state_thr : nullptr, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
                          reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, kc, klw, 0, 0, nullptr,
@@ -903,8 +1002,23 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     }
     if (hb_ensure_dyn_lds((const void*)fn, lds_bytes)) return -1;   // per (kernel, device)
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev0, s));
-    fn<<<dim3((unsigned)sc.G), dim3(threads), lds_bytes, s>>>(a);
-    HB_HIP(hipGetLastError());
+    if (n_phases > 1) {   // (pools only) slots that start in a later phase must read as empty pools in the merges between the phases
+        HB_HIP(hipMemsetAsync(a.state_cnt, 0, state_aux, s));
+        HB_HIP(hipMemsetD32Async((hipDeviceptr_t)a.state_thr, 0xFF800000u, state_aux / 4, s));
+    }
+    for (int ph = 0; ph < n_phases; ++ph) {
+        a.wg_off = phase_begin(ph); a.wg_end = phase_end(ph);
+        fn<<<dim3((unsigned)sc.G), dim3(threads), lds_bytes, s>>>(a);
+        HB_HIP(hipGetLastError());
+        if (ph + 1 < n_phases) {   // the k-th best ORDERING score of all rows seen so far -> every slot's floor (the outputs serve as scratch)
+            if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, pool_cnt ? a.state_thr : nullptr, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
+                             reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, k, klw, 0, 0, nullptr,
+                             out_idx, out_dist, s)) return -1;
+            seed_floors_kernel<<<dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s>>>(out_idx, out_dist, nq, k, a.gthr);
+            HB_HIP(hipGetLastError());
+            if (a.cl > 1) HB_HIP(hipMemsetAsync(a.prog, 0, prog_bytes - HB_CLUSTER_LINE * 4, s));
+        }
+    }
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
     const float* qn2 = ix->q_aux;   // [nq] chain ||q||^2 (valid for L2)
     if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, pool_cnt ? a.state_thr : nullptr, reinterpret_cast<const int*>(ix->sched_dev + o_qo),

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
 #elif defined(BD_PRIO) && BD_PRIO == 2
     if (w < 4) __builtin_amdgcn_s_setprio(1);    // ... or for the copy-issuing half
 #endif
-    const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
+    const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_end[blockIdx.x];   // this launch's share of the block's segments (phases: hb_launch_knn)
     // "everything before my first segment is done" (a member without any work: everything)
     if constexpr (CL) { if (w == 0) cl_publish(cs, seg_begin < seg_end ? a.segs[seg_begin].tile0 * g8 : 0x7FFFFFFF, lane); }
     for (int si = seg_begin; si < seg_end; ++si) {

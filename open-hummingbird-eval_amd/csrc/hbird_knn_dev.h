@@ -14,7 +14,8 @@ struct knn_args {
     const float* binit;
     const float* q_tiles;
     const hb_seg* segs;
-    const int* wg_off;
+    const int* wg_off;    // per block: first segment of this launch ...
+    const int* wg_end;    // ... and one past its last (one launch: the block's whole list; phased searches: a part of it)
     float* state_s;
     unsigned* state_i;
     int g8;   // Dp / 8
@@ -49,6 +50,7 @@ struct knn16_args {
     const _Float16* q16;      // fp16 copies of the query fragment tiles
     const hb_seg* segs;
     const int* wg_off;
+    const int* wg_end;
     float* state_s;
     unsigned* state_i;
     int g16;   // Dp16 / 16

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(W4_THREADS) void knn_fused_w4_kernel(knn_args a) {
     float* sc = reinterpret_cast<float*>(smem + KN_SCRATCH) + w * 512;
     const int g8 = a.g8, k = a.k, klw = a.klw;
 
-    const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_off[blockIdx.x + 1];
+    const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_end[blockIdx.x];   // this launch's share of the block's segments (phases: hb_launch_knn)
     for (int si = seg_begin; si < seg_end; ++si) {
         const hb_seg seg = a.segs[si];
         float* wl_s = a.state_s + (size_t)seg.slot * HB_QT * klw;

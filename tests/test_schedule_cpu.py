@@ -139,6 +139,81 @@ def test_clustered_work_list_invariants(nqt, nbt, G, panel, cq, cb):
             assert busy.max() - busy.min() <= 2 * npanels + 1
 
 
+def plan_phased(nqt, nbt, G, panel, d=384, cluster=(1, 1)):
+    """-> (rows as plan(), stats, cut clocks, bounds [cut][block] relative to the block's first segment)."""
+    L = _lib.lib()
+    stats = (ctypes.c_int64 * 8)()
+    n_cuts = ctypes.c_int(0)
+    _lib.check(L.hb_schedule_plan_phased(nqt, nbt, G, panel, d, cluster[0], cluster[1], None, 0, stats, None, 0, ctypes.byref(n_cuts), None))
+    nseg, nc, g = stats[1], n_cuts.value, stats[0]
+    buf = np.zeros((nseg, 10), dtype=np.int32)
+    clocks = np.zeros(max(nc, 1), dtype=np.int32)
+    bounds = np.zeros((max(nc, 1), g), dtype=np.int32)
+    _lib.check(L.hb_schedule_plan_phased(nqt, nbt, G, panel, d, cluster[0], cluster[1], buf.ctypes.data_as(ctypes.c_void_p), nseg, stats,
+                                         clocks.ctypes.data_as(ctypes.c_void_p), nc, ctypes.byref(n_cuts),
+                                         bounds.ctypes.data_as(ctypes.c_void_p)))
+    return buf, dict(workgroups=g, slots=stats[2], cluster=(int(stats[7]) // 16, int(stats[7]) % 16)), clocks[:nc], bounds[:nc]
+
+
+@pytest.mark.parametrize("nqt,nbt,G,panel,cq,cb", [
+    (98, 8102, 256, 0, 1, 1),       # cfg-2, fp16 / k > 32
+    (98, 196, 256, 0, 1, 1),        # cfg-1
+    (172, 39063, 256, 0, 2, 4),     # 10 M rows, clustered
+    (172, 39063, 256, 0, -1, -1),   # ... the automatic fp16 shape
+    (7, 40, 256, 0, 1, 1), (1, 3, 256, 0, 1, 1), (16, 500, 64, 7, 2, 2), (5, 7, 3, 2, 1, 1),
+])
+def test_phased_work_list_invariants(nqt, nbt, G, panel, cq, cb):
+    """Phased searches (pools): the same pairs as the unphased list, each once, with every block's segments cut at common clocks.
+    A phase is a contiguous range of every block's segments; all its segments lie between the phase's two clocks (so the
+    workgroups share every phase and the members of a cluster stay on one clock); a slot's `first` segment comes before its
+    continuations, phases included; the last phase holds at least half of the tiles."""
+    segs, st, clocks, bounds = plan_phased(nqt, nbt, G, panel, cluster=(cq, cb))
+    ref, st0 = plan(nqt, nbt, G, panel, d=384, cluster=(cq, cb))
+    g = st["workgroups"]
+    assert st["slots"] == st0["slots"] and st["cluster"] == st0["cluster"]
+    per_wg = (nqt * nbt) // g
+    assert list(clocks) == sorted(set(clocks.tolist())) and all(2 * c <= per_wg for c in clocks)
+    if per_wg >= 2:
+        assert len(clocks) >= 1 and clocks[0] == 1
+    cover = np.zeros((nqt, nbt), dtype=np.int32)
+    started = {}
+    by_block = {}
+    for row in segs.tolist():
+        by_block.setdefault(row[0], []).append(row)
+    edges = [0] + clocks.tolist() + [2 ** 31 - 1]
+    tiles_in_phase = np.zeros(len(clocks) + 1, dtype=np.int64)
+    for blk in range(g):
+        rows = by_block.get(blk, [])
+        cuts = [0] + [int(bounds[p, blk]) for p in range(len(clocks))] + [len(rows)]
+        assert cuts == sorted(cuts)
+        for p in range(len(cuts) - 1):
+            for _, q, b0, n, slot, first, stride, tile0, next_tile0, member in rows[cuts[p]:cuts[p + 1]]:
+                assert edges[p] <= tile0 and tile0 + n <= edges[p + 1], "a segment lies inside its phase's clock range"
+                tiles_in_phase[p] += n
+                tiles = b0 + stride * np.arange(n)
+                cover[q, tiles] += 1
+                if first:
+                    assert slot not in started
+                    started[slot] = (p, blk, q, int(tiles[-1]))
+                else:
+                    p0, blk0, q0, last = started[slot]
+                    assert p0 <= p and blk0 == blk and q0 == q and b0 > last
+                    started[slot] = (p0, blk, q, int(tiles[-1]))
+    assert (cover == 1).all()
+    assert len(started) == st["slots"]
+    if len(clocks):
+        assert tiles_in_phase[-1] * 2 >= tiles_in_phase.sum() * 0.95
+        assert (tiles_in_phase[:-1] > 0).all()
+    # the same pairs per slot as the unphased list (only cut finer)
+    def pairs(rows):
+        out = {}
+        for _, q, b0, n, slot, first, stride, *_ in rows.tolist():
+            out.setdefault(slot, []).extend((q, b0 + stride * j) for j in range(n))
+        return out
+    if nqt * nbt <= 1_000_000:
+        assert pairs(segs) == pairs(ref)
+
+
 def test_automatic_cluster_shape():
     """The widest query way that idles at most 2.5 % of the pairs; none for small searches or unsuitable grids."""
     for nqt, nbt, G, want in ((86, 39063, 256, (8, 1)), (49, 8102, 256, (2, 2)), (48, 8102, 256, (8, 1)), (52, 8102, 256, (4, 2)),
