@@ -257,12 +257,56 @@ __device__ __forceinline__ float pool_compact(float* gs, unsigned* gi, int cap, 
     return kth;
 }
 
+// Append the register queues of a wave (at most four (score, row code) entries per lane; np = how many this lane holds) to the
+// pools of its 32 queries: queue entry i of every lane, one lane half at a time (the two halves hold different rows of the SAME
+// query and would race on its fill count; an LDS-atomic variant that drained both at once measured the same and needed a compaction
+// of partly filled pools).  A pool that fills up is compacted to its k best on the spot, which raises the query's threshold.
+template <int EMAX>
+__device__ __forceinline__ void pool_drain(int np, float q0v, float q1v, float q2v, float q3v, int q0c, int q1c, int q2c, int q3c, float& thr,
+                                           float* pool_s, unsigned* pool_i, int qb, int lane, int k, unsigned row0, int klw, int* cnt) {
+    const int myq = qb + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool has = np > i;
+        if (__ballot(has) == 0ull) break;
+        const float v = i == 0 ? q0v : i == 1 ? q1v : i == 2 ? q2v : q3v;
+        const int code = i == 0 ? q0c : i == 1 ? q1c : i == 2 ? q2c : q3c;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const bool pass = has && (lane >> 5) == hh;
+            if (__ballot(pass) == 0ull) continue;
+            int c = 0;
+            if (pass) {
+                c = cnt[myq];
+                pool_s[(size_t)myq * klw + c] = v;
+                pool_i[(size_t)myq * klw + c] = row0 + (unsigned)code;
+                cnt[myq] = c + 1;
+            }
+            unsigned long long full = __ballot(pass && c + 1 == klw);
+            while (full) {
+                const int n = __builtin_ctzll(full) & 31;
+                full &= full - 1;
+                const size_t off = (size_t)(qb + n) * klw;
+                const float kth = pool_compact<EMAX>(pool_s + off, pool_i + off, klw, k, lane);
+                if (lane == 0) cnt[qb + n] = k;
+                if ((lane & 31) == n) thr = fmaxf(thr, kth);
+            }
+        }
+    }
+}
+
 // dump the 4 registers of quarter Q (rows 8Q .. 8Q+7 of the 32-row tile) of accumulator tile T
 #define HB_DUMP_CASE(T, Q)                                                                  \
     case (4 * (T) + (Q)):                                                                   \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) sc[r * 64 + lane] = acc[T][4 * (Q) + r]; \
         break;
 #define HB_DUMP_TILE(T) HB_DUMP_CASE(T, 0) HB_DUMP_CASE(T, 1) HB_DUMP_CASE(T, 2) HB_DUMP_CASE(T, 3)
+// ... or pick them into four scalars-per-lane (pools)
+#define HB_PICK_CASE(T, Q)                                                                  \
+    case (4 * (T) + (Q)):                                                                   \
+        r0 = acc[T][4 * (Q)]; r1 = acc[T][4 * (Q) + 1]; r2 = acc[T][4 * (Q) + 2]; r3 = acc[T][4 * (Q) + 3]; \
+        break;
+#define HB_PICK_TILE(T) HB_PICK_CASE(T, 0) HB_PICK_CASE(T, 1) HB_PICK_CASE(T, 2) HB_PICK_CASE(T, 3)
 
 // Epilogue of one (query tile, bank tile) pair for one wave: filter the wave's 256 x 32 scores against the
 // per-query thresholds (phase 1, always) and hand the rare survivors to the lists / pools (phase 2).
@@ -270,7 +314,7 @@ __device__ __forceinline__ float pool_compact(float* gs, unsigned* gi, int cap, 
 // WIDE = false: lst_s / lst_i are the sorted LDS lists.  WIDE = true: they are the slot's pools in global memory
 // (row stride klw = capacity) and `cnt` holds the fill counts of the workgroup's 256 queries in LDS.
 template <bool SLOW = true, bool WIDE = false, int EMAX = HB_POOL_MAX / 64>
-__device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, float* lst_s, unsigned* lst_i, float* sc,
+__device__ __forceinline__ int tile_epilogue(f32x16 (&acc)[8], float& thr, float* lst_s, unsigned* lst_i, float* sc,
                                               int qb, int lane, int k, unsigned bt, int klw = HB_KL, int* cnt = nullptr) {
     unsigned qmask = 0;   // bit 4t+q: quarter q (8 bank rows) of row tile t holds a score above its query's threshold
 #pragma unroll
@@ -280,7 +324,39 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, floa
             const bool any = (acc[t][4 * q] > thr) | (acc[t][4 * q + 1] > thr) | (acc[t][4 * q + 2] > thr) | (acc[t][4 * q + 3] > thr);
             if (__ballot(any) != 0ull) qmask |= 1u << (4 * t + q);
         }
-    if (!SLOW) { asm volatile("" :: "s"(qmask)); return; }
+    if (!SLOW) { asm volatile("" :: "s"(qmask)); return 0; }
+    const int flagged = __builtin_popcount(qmask);
+    if constexpr (WIDE) {
+        // pools: a flagged quarter's four registers (8 bank rows x 32 queries) are tested lane by lane, the survivors queued in registers
+        // and appended right away (pool_drain) -- so the queue cannot overflow and later quarters already see a threshold that a
+        // compaction raised.  (Until round 3 the quarter went through LDS and was walked row by row like the lists below: 256 serial
+        // steps for a slot's first tiles, where every quarter is flagged; fp16 candidate kernel, 50,176 x 384: 2.30 -> 2.04 ms.)
+        while (qmask) {
+            const int bit = __builtin_ctz(qmask);
+            qmask &= qmask - 1;
+            float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+            switch (bit) {
+                HB_PICK_TILE(0) HB_PICK_TILE(1) HB_PICK_TILE(2) HB_PICK_TILE(3)
+                HB_PICK_TILE(4) HB_PICK_TILE(5) HB_PICK_TILE(6) HB_PICK_TILE(7)
+            }
+            float q0v = 0.f, q1v = 0.f, q2v = 0.f, q3v = 0.f;
+            int np = 0;
+            if (r0 > thr) { q0v = r0; np = 1; }
+            if (r1 > thr) { q3v = q2v; q2v = q1v; q1v = q0v; q0v = r1; ++np; }
+            if (r2 > thr) { q3v = q2v; q2v = q1v; q1v = q0v; q0v = r2; ++np; }
+            if (r3 > thr) { q3v = q2v; q2v = q1v; q1v = q0v; q0v = r3; ++np; }
+            // the row codes follow from which registers passed: entry i (newest first) is the i-th highest set bit
+            const int pm = (r0 > thr ? 1 : 0) | (r1 > thr ? 2 : 0) | (r2 > thr ? 4 : 0) | (r3 > thr ? 8 : 0);
+            int m = pm;
+            const int q0c = m ? 31 - __builtin_clz(m) : 0; m &= ~(1 << q0c);
+            const int q1c = m ? 31 - __builtin_clz(m) : 0; m &= ~(1 << q1c);
+            const int q2c = m ? 31 - __builtin_clz(m) : 0; m &= ~(1 << q2c);
+            const int q3c = m ? 31 - __builtin_clz(m) : 0;
+            const unsigned row0 = bt * HB_BT + (bit >> 2) * 32 + (bit & 3) * 8 + 4u * (unsigned)(lane >> 5);
+            pool_drain<EMAX>(np, q0v, q1v, q2v, q3v, q0c, q1c, q2c, q3c, thr, lst_s, lst_i, qb, lane, k, row0, klw, cnt);
+        }
+        return flagged;
+    }
     while (qmask) {   // wave-uniform slow path; ascending bit order = ascending bank row
         const int bit = __builtin_ctz(qmask);
         qmask &= qmask - 1;
@@ -293,42 +369,20 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, floa
         for (int hh = 0; hh < 2; ++hh)
             for (int j = 0; j < 4; ++j) {
                 const float v = sc[j * 64 + lane];
-                if constexpr (WIDE) {
-                    // every passing lane appends to its own query's pool (one query per lane within a half)
-                    const bool pass = ((lane >> 5) == hh) && (v > thr);
-                    if (__ballot(pass) == 0ull) continue;
-                    const int myq = qb + (lane & 31);
-                    int c = 0;
-                    if (pass) {
-                        c = cnt[myq];
-                        lst_s[(size_t)myq * klw + c] = v;
-                        lst_i[(size_t)myq * klw + c] = row_base + hh * 4 + j;
-                        cnt[myq] = c + 1;
-                    }
-                    unsigned long long full = __ballot(pass && c + 1 == klw);
-                    while (full) {
-                        const int n = __builtin_ctzll(full) & 31;
-                        full &= full - 1;
-                        const size_t off = (size_t)(qb + n) * klw;
-                        const float kth = pool_compact<EMAX>(lst_s + off, lst_i + off, klw, k, lane);
-                        if (lane == 0) cnt[qb + n] = k;
-                        if ((lane & 31) == n) thr = fmaxf(thr, kth);
-                    }
-                } else {
-                    unsigned long long m = __ballot(v > thr);
-                    m &= hh ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
-                    while (m) {
-                        const int l = __builtin_ctzll(m);
-                        m &= m - 1;
-                        const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-                        const int n = l & 31;
-                        list_insert(lst_s, lst_i, qb + n, k, s, row_base + hh * 4 + j, lane);
-                        const float kth = lst_s[(qb + n) * HB_KL + (k - 1)];
-                        if ((lane & 31) == n) thr = fmaxf(thr, kth);
-                    }
+                unsigned long long m = __ballot(v > thr);
+                m &= hh ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
+                while (m) {
+                    const int l = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+                    const int n = l & 31;
+                    list_insert(lst_s, lst_i, qb + n, k, s, row_base + hh * 4 + j, lane);
+                    const float kth = lst_s[(qb + n) * HB_KL + (k - 1)];
+                    if ((lane & 31) == n) thr = fmaxf(thr, kth);
                 }
             }
     }
+    return flagged;
 }
 
 // ---- pool epilogue, second design: scan into a per-lane register queue, then drain ---------------------------------------
@@ -371,65 +425,44 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[8], float& thr, floa
     HB_SCAN_REG(T, 12) HB_SCAN_REG(T, 13) HB_SCAN_REG(T, 14) HB_SCAN_REG(T, 15)
 #endif
 
+// `bulk` (wave-uniform, kept by the caller across the tiles of a segment): the tile goes straight to tile_epilogue's quarter loop.
+// A slot's first tiles -- and the first tiles of every phase while the floors are loose -- have survivors in every quarter: the
+// unrolled scan would take its 128 out-of-line branches only to find a queue overflowing.  The mode ends when a tile flags at most
+// HB_BULK_QUADS of its 32 quarters and comes back when a queue overflows.  (The quarter loop for EVERY tile measured 1-5 % slower
+// at 50 k - 2 M rows and 0.5 % faster at 10 M x 768: its test is four compares per quarter against the scan's max tree.)
+#define HB_BULK_QUADS 12
 template <int EMAX>
 __device__ __forceinline__ void pool_epilogue_scan(f32x16 (&acc)[8], float& thr, float* pool_s, unsigned* pool_i, float* sc, int qb,
-                                                   int lane, int k, unsigned bt, int klw, int* cnt,
+                                                   int lane, int k, unsigned bt, int klw, int* cnt, bool& bulk,
                                                    unsigned long long* stamp_after_scan = nullptr /* diagnostic builds */) {
-    float q0v = 0.f, q1v = 0.f, q2v = 0.f, q3v = 0.f;
-    int q0c = 0, q1c = 0, q2c = 0, q3c = 0, np = 0;
-    HB_SCAN_TILE(0) HB_SCAN_TILE(1) HB_SCAN_TILE(2) HB_SCAN_TILE(3) HB_SCAN_TILE(4) HB_SCAN_TILE(5) HB_SCAN_TILE(6) HB_SCAN_TILE(7)
-    if (stamp_after_scan) {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(*stamp_after_scan) :: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (__ballot(np != 0) == 0ull) return;
-#if defined(F16_ABL) && (F16_ABL & 512)
-    asm volatile("" :: "v"(q0v), "v"(q1v), "v"(q2v), "v"(q3v), "v"(q0c), "v"(q1c), "v"(q2c), "v"(q3c));   // timing only: no drain
-    return;
-#endif
-    if (__ballot(np > 4) != 0ull) {   // a queue overflowed: the general path rescans the tile (nothing was appended yet)
-        // (the threshold goes through an opaque copy: otherwise the compiler keeps the scan's 128 compare masks alive, in
-        // spilled SGPRs, to reuse them in the general path's own compares)
-        float t2 = thr;
-        asm volatile("" : "+v"(t2));
-        tile_epilogue<true, true, EMAX>(acc, t2, pool_s, pool_i, sc, qb, lane, k, bt, klw, cnt);
-        thr = t2;
-        return;
-    }
-    const int myq = qb + (lane & 31);
-    const unsigned row0 = bt * HB_BT + 4u * (unsigned)(lane >> 5);
-    // Drain: queue entry i of every lane, one lane half at a time (the two halves hold different rows of the SAME query and
-    // would race on its fill count; an LDS-atomic variant that drained both at once measured the same and needed a
-    // compaction of partly filled pools).
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const bool has = np > i;
-        if (__ballot(has) == 0ull) break;
-        const float v = i == 0 ? q0v : i == 1 ? q1v : i == 2 ? q2v : q3v;
-        const int code = i == 0 ? q0c : i == 1 ? q1c : i == 2 ? q2c : q3c;
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const bool pass = has && (lane >> 5) == hh;
-            if (__ballot(pass) == 0ull) continue;
-            int c = 0;
-            if (pass) {
-                c = cnt[myq];
-                pool_s[(size_t)myq * klw + c] = v;
-                pool_i[(size_t)myq * klw + c] = row0 + (unsigned)code;
-                cnt[myq] = c + 1;
-            }
-            unsigned long long full = __ballot(pass && c + 1 == klw);
-            while (full) {
-                const int n = __builtin_ctzll(full) & 31;
-                full &= full - 1;
-                const size_t off = (size_t)(qb + n) * klw;
-                const float kth = pool_compact<EMAX>(pool_s + off, pool_i + off, klw, k, lane);
-                if (lane == 0) cnt[qb + n] = k;
-                if ((lane & 31) == n) thr = fmaxf(thr, kth);
-            }
+    if (!bulk) {
+        float q0v = 0.f, q1v = 0.f, q2v = 0.f, q3v = 0.f;
+        int q0c = 0, q1c = 0, q2c = 0, q3c = 0, np = 0;
+        HB_SCAN_TILE(0) HB_SCAN_TILE(1) HB_SCAN_TILE(2) HB_SCAN_TILE(3) HB_SCAN_TILE(4) HB_SCAN_TILE(5) HB_SCAN_TILE(6) HB_SCAN_TILE(7)
+        if (stamp_after_scan) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(*stamp_after_scan) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (__ballot(np != 0) == 0ull) return;
+#if defined(F16_ABL) && (F16_ABL & 512)
+        asm volatile("" :: "v"(q0v), "v"(q1v), "v"(q2v), "v"(q3v), "v"(q0c), "v"(q1c), "v"(q2c), "v"(q3c));   // timing only: no drain
+        return;
+#endif
+        if (__ballot(np > 4) == 0ull) {
+            pool_drain<EMAX>(np, q0v, q1v, q2v, q3v, q0c, q1c, q2c, q3c, thr, pool_s, pool_i, qb, lane, k,
+                             bt * HB_BT + 4u * (unsigned)(lane >> 5), klw, cnt);
+            return;
+        }
+        // a queue overflowed: the quarter loop rescans the tile (nothing was appended yet)
     }
+    // (the threshold goes through an opaque copy: otherwise the compiler keeps the scan's 128 compare masks alive, in
+    // spilled SGPRs, to reuse them in the quarter loop's own compares)
+    float t2 = thr;
+    asm volatile("" : "+v"(t2));
+    const int flagged = tile_epilogue<true, true, EMAX>(acc, t2, pool_s, pool_i, sc, qb, lane, k, bt, klw, cnt);
+    thr = t2;
+    bulk = flagged > HB_BULK_QUADS;
 }
 
 // The same scan for the sorted LDS lists (k <= HB_KL): a flagged quad's survivors (at most four per lane) go into the
@@ -572,43 +605,50 @@ __device__ __forceinline__ void pool_end(const knn_args_pool_view& pv, int slot,
     if (lane < 32) { pv.cnt[(size_t)slot * HB_QT + myq] = cnt[myq]; pv.thr[(size_t)slot * HB_QT + myq] = thr; }
 }
 
-// Cold start of a slot (LDS-list path): with no threshold yet, the first bank tile would insert all of its 256 rows into
-// every query's list one by one (8192 wave-cooperative insertions per wave).  Instead the k-th largest of the tile's
-// 256 scores of each query -- they sit in two lanes (lane, lane ^ 32) x 128 accumulator registers -- is found with a
-// 32-round radix select on the monotone keys, and everything below it is filtered like any other score: about k
-// insertions per query remain.  Returns the float just below that k-th score (ties with it must still pass), or -inf
-// when the tile has fewer than k real rows (padding rows score -inf).
+// Cold start of a slot: with no threshold yet, the first bank tile would insert all of its 256 rows into every query's list (or
+// pool) one by one.  Instead a score that at least k of the tile's 256 scores of each query EXCEED -- they sit in two lanes
+// (lane, lane ^ 32) x 128 accumulator registers -- is found by bisection between the smallest and the largest of them, and
+// everything at or below it is filtered like any other score: about k insertions per query remain.  Any such score is a valid
+// threshold; twelve halvings leave 256 / 4096 rows too many on average.  (Until round 3 this was an exact 32-round radix select
+// on monotone keys: 28 k vector instructions per wave, 108 us per cold start measured in the fp16 candidate kernel -- nine bank
+// tiles' worth -- against 4 k here.)  Returns -inf when the tile has fewer than k real rows (padding rows score -inf).
 // NaN scores (a bank row of NaNs: a zero token through the reference's eps-free normalisation, hbird_eval.py:324; a query
 // with inf / NaN components) never enter a list -- every filter is a strict `score > threshold`, false for NaN, as in a
-// comparison-based k-select.  Here the order is a monotone KEY, where a positive NaN would outrank +inf and lift the
-// threshold over real neighbours: the tile's NaNs are replaced by -inf first (in place: for the filters after this call
-// -inf and NaN are the same thing).
+// comparison-based k-select.  The tile's NaNs are replaced by -inf first (in place: for the filters after this call -inf and NaN
+// are the same thing), so that they count as "no row" here as well.
 __device__ __forceinline__ float cold_start_threshold(f32x16 (&acc)[8], int k) {
+    float hi = -INFINITY, mn = INFINITY;
+    int real = 0;
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = (acc[t][r] == acc[t][r]) ? acc[t][r] : -INFINITY;
-    unsigned prefix = 0;
-    int kk = k;
-    for (int b = 31; b >= 0; --b) {
-        const unsigned himask = ~((1u << b) - 1u), cand = prefix | (1u << b);
+        for (int r = 0; r < 16; ++r) {
+            const float v = (acc[t][r] == acc[t][r]) ? acc[t][r] : -INFINITY;
+            acc[t][r] = v;
+            hi = fmaxf(hi, v);
+            mn = fminf(mn, v > -INFINITY ? v : INFINITY);
+            real += v > -INFINITY ? 1 : 0;
+        }
+    hi = fmaxf(hi, __shfl_xor(hi, 32));
+    mn = fminf(mn, __shfl_xor(mn, 32));
+    real += __shfl_xor(real, 32);
+    hi = fminf(hi, 3.4028234664e38f);   // +inf scores are ordinary scores; the bisection needs finite ends
+    // lo: the float just below the smallest real score, so that every real row exceeds it
+    const unsigned mb = __builtin_bit_cast(unsigned, mn);
+    float lo = __builtin_bit_cast(float, mn > 0.f ? mb - 1u : (mn == 0.f ? 0x80000001u : mb + 1u));
+    if (real < k) { lo = -INFINITY; hi = -INFINITY; }   // fewer than k real rows: the answer stays -inf
+#pragma unroll 1
+    for (int it = 0; it < 12; ++it) {
+        const float mid = 0.5f * lo + 0.5f * hi;
         int c = 0;
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[t][r];
-                asm volatile("" : "+v"(v));   // keeps the 128 keys from being hoisted out of the bit loop (registers)
-                c += ((pool_key(v) & himask) == cand) ? 1 : 0;
-            }
+            for (int r = 0; r < 16; ++r) c += acc[t][r] > mid ? 1 : 0;
         c += __shfl_xor(c, 32);
-        if (c >= kk) prefix = cand; else kk -= c;
+        if (c >= k) lo = mid; else hi = mid;
     }
-    // prefix = key of the k-th largest score; one key below it (skipping -0.0) admits its ties
-    if (prefix <= 0x007FFFFFu) return -INFINITY;
-    unsigned g = prefix - 1u;
-    if (g == 0x7FFFFFFFu) g = 0x7FFFFFFEu;
-    return __builtin_bit_cast(float, (g & 0x80000000u) ? (g ^ 0x80000000u) : ~g);
+    return lo;
 }
 
 // LDS map shared by the variants (bytes): a 4-slot ring of k8 stages, two row-init buffers, the lists, the scratch

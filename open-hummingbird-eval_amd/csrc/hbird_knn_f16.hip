@@ -291,6 +291,13 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
     cl_sync cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + F2_CLWORDS);
 
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_end[blockIdx.x];   // this launch's share of the block's segments (phases: hb_launch_knn)
+#ifdef F2_TL   // diagnostic build (make var NAME=tl EXTRA=-DF2_TL): time line of a launch's first segment (s_memtime: 100 MHz), one wave
+#define F2_TLS(I) { if (si == seg_begin && tl_n < 16) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl[tl_n]) :: "memory"); tl_id[tl_n++] = (I); __builtin_amdgcn_sched_barrier(0); } }
+    unsigned long long tl[16]; int tl_id[16], tl_n = 0;
+    { const int si = seg_begin; F2_TLS(0) }
+#else
+#define F2_TLS(I)
+#endif
     // "everything before my first segment is done" (a member without any work: everything)
     if (w == 0) cl_publish(cs, seg_begin < seg_end ? a.segs[seg_begin].tile0 * NS : 0x7FFFFFFF, lane);
     for (int si = seg_begin; si < seg_end; ++si) {
@@ -301,6 +308,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
         const knn_args_pool_view pv{a.state_cnt, a.state_thr};
         float thr = pool_begin(pv, seg.slot, seg.first, pcnt, myq, lane);
         thr = fmaxf(thr, floor_load(a.gthr, seg.q_tile * HB_QT + myq));
+        F2_TLS(1)
         const int total = seg.n_tiles * NS, clock0 = seg.tile0 * NS;
 #ifdef F2_MFMA16
         f32x4 acc4[32];
@@ -362,7 +370,9 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
         // stage 0 (and B1 of it) has landed: eleven younger requests
         asm volatile("s_waitcnt vmcnt(11)" : "+v"(bq[0][0]), "+v"(bq[0][1]) :: "memory");
         __syncthreads();
+        F2_TLS(2)
         int slot_c = 0, ks = 0, bt = seg.b_tile0, cpar = 0;
+        bool bulk = seg.tile0 < 16;   // loose floors at the start of a search: the epilogue's quarter loop right away (pool_epilogue_scan)
 #if defined(F16_ABL) && (F16_ABL & 256)
 #define F2_INIT_TILE() { _Pragma("unroll") for (int t = 0; t < 8; ++t) asm volatile("" : "+v"(acc[t])); }   // timing only: no init
 #else
@@ -459,14 +469,17 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
 #elif defined(F2_STAMPS)
                 if (seg.first && bt == seg.b_tile0) thr = fmaxf(thr, cold_start_threshold(acc, k));
                 F2_STAMP(ts_a)
-                pool_epilogue_scan<EMAX>(acc, thr, wl_s, wl_i, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt, &ts_m);
+                pool_epilogue_scan<EMAX>(acc, thr, wl_s, wl_i, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt, bulk, &ts_m);
                 F2_STAMP(ts_b)
                 sum_scan += ts_m - ts_a; sum_drain += ts_b - ts_m; after_epi = 1;
 #else
                 // a slot's first tile: filter below the k'-th largest of its 256 scores (radix select over the accumulators)
                 // instead of appending all 256 rows of every query through the overflow path
+                F2_TLS(3)
                 if (seg.first && bt == seg.b_tile0) thr = fmaxf(thr, cold_start_threshold(acc, k));
-                pool_epilogue_scan<EMAX>(acc, thr, wl_s, wl_i, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
+                F2_TLS(4)
+                pool_epilogue_scan<EMAX>(acc, thr, wl_s, wl_i, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt, bulk);
+                F2_TLS(5)
 #endif
                 ks = 0; bt += bstride; cpar ^= 1;
                 F2_INIT_TILE()
@@ -505,13 +518,23 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
 #undef F2_BL_ALL
 #undef F2_QSRC
         if (w == 0) cl_publish(cs, seg.next_tile0 == 0x7FFFFFFF ? 0x7FFFFFFF : seg.next_tile0 * NS, lane);   // covers idle units
+        F2_TLS(6)
         pool_end(pv, seg.slot, pcnt, thr, myq, lane);
         if (lane < 32) floor_publish(a.gthr, seg.q_tile * HB_QT + myq, thr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        F2_TLS(7)
+#ifdef F2_TL
+        if (si == seg_begin && blockIdx.x == 7 && (tid == 0 || tid == 320)) {
+            printf("TL wave %d seg tiles %d first %d clock %d:", w, seg.n_tiles, seg.first, seg.tile0);
+            for (int i = 1; i < tl_n; ++i) printf(" [%d] +%llu", tl_id[i], (tl[i] - tl[i - 1]) / 100);
+            printf(" us\n");
+        }
+#endif
     }
     cl_finish(cs, a.cl_stats, w == 0, lane);
 }
+#undef F2_TLS
 
 // Exact re-rank: one wave per query; lane j scores candidates j, j+64, ... with the fp32 chain arithmetic of the fp32
 // kernel (acc = row init; acc = fmaf(q_k, b_k, acc) for k ascending over the fp32 fragment tiles), then the wave
