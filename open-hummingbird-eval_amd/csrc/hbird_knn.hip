@@ -720,6 +720,56 @@ __global__ __launch_bounds__(256) void seed_floors_kernel(const int64_t* __restr
     if (idx[q * kk + kk - 1] >= 0) atomicMax(gthr + q, pool_key(score[q * kk + kk - 1]));   // kk rows reach this score: a floor (ties pass)
 }
 
+// The same floor straight from the pools, without the merge: one wave per query gathers the scores of its slots' pools (those that
+// can matter: at or above the best threshold a full pool already has) into LDS and bisects for a score that at least kk of them
+// exceed -- 14 halvings between the smallest and the largest; any such score is a valid floor (cold_start_threshold,
+// hbird_knn_dev.h).  The merge kernel ranks its candidates by counting (quadratic) and writes int64 ids: 85-150 us per phase
+// boundary for 12,544 queries against 25-30 here.
+__global__ __launch_bounds__(256) void pool_floor_kernel(const float* __restrict__ state_s, const int* __restrict__ cnts,
+                                                        const float* __restrict__ pthr, const int* __restrict__ qt_off,
+                                                        const int* __restrict__ qt_slots, int64_t nq, int kk, int klw, int per_wave,
+                                                        unsigned* __restrict__ gthr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * 4 + w;
+    if (q >= nq) return;
+    float* cs = reinterpret_cast<float*>(smem) + (size_t)w * per_wave;
+    const int qt = (int)(q / HB_QT), ql = (int)(q % HB_QT);
+    const int s0 = qt_off[qt], ns = qt_off[qt + 1] - s0;
+    float tstar = -INFINITY;
+    for (int j = lane; j < ns; j += 64) {
+        const size_t oq = (size_t)qt_slots[s0 + j] * HB_QT + ql;
+        if (cnts[oq] >= kk) tstar = fmaxf(tstar, pthr[oq]);
+    }
+    for (int o = 32; o > 0; o >>= 1) tstar = fmaxf(tstar, __shfl_xor(tstar, o));
+    int n = 0;
+    float hi = -INFINITY, mn = INFINITY;
+    for (int j = 0; j < ns; ++j) {
+        const size_t oq = (size_t)qt_slots[s0 + j] * HB_QT + ql;
+        const int valid = min(klw, cnts[oq]);
+        for (int e0 = 0; e0 < valid; e0 += 64) {
+            const int e = e0 + lane;
+            const float v = e < valid ? state_s[oq * klw + e] : -INFINITY;
+            const bool keep = e < valid && (v >= tstar || tstar == -INFINITY);
+            const unsigned long long m = __ballot(keep);
+            if (keep) { cs[n + __popcll(m & ((1ull << lane) - 1ull))] = v; hi = fmaxf(hi, v); mn = fminf(mn, v); }
+            n += __popcll(m);
+        }
+    }
+    if (n < kk) return;   // fewer than kk rows seen so far: no floor yet
+    for (int o = 32; o > 0; o >>= 1) { hi = fmaxf(hi, __shfl_xor(hi, o)); mn = fminf(mn, __shfl_xor(mn, o)); }
+    hi = fminf(hi, 3.4028234664e38f);
+    const unsigned mb = __builtin_bit_cast(unsigned, mn);
+    float lo = __builtin_bit_cast(float, mn > 0.f ? mb - 1u : (mn == 0.f ? 0x80000001u : mb + 1u));   // all n exceed it
+    for (int it = 0; it < 14; ++it) {
+        const float mid = 0.5f * lo + 0.5f * hi;
+        int c = 0;
+        for (int base = 0; base < n; base += 64) c += __popcll(__ballot(base + lane < n && cs[base + lane] > mid));
+        if (c >= kk) lo = mid; else hi = mid;
+    }
+    if (lane == 0 && lo > -INFINITY) atomicMax(gthr + q, pool_key(lo));   // kk rows exceed lo
+}
+
 // q_tiles / q_aux must already be prepared by the caller (hb_index_search).
 int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t id_base, int64_t* out_idx, float* out_dist) {
     if (k < 1 || k > 256) return hb_fail("hb_index_search: k must be in [1, 256]");
@@ -873,6 +923,24 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     ix->cl_stats_dev = a.cl_stats;
     HB_HIP(hipMemsetAsync(a.prog, 0, prog_bytes, s));
 #endif
+    // between two phases of a pool search: the kk-th best of all rows seen so far becomes every slot's floor -- straight from the pools
+    // where a query tile's pools fit the floor kernel's LDS, else through the merge (few queries against a big bank: many slots)
+    auto seed_floors = [&](int kk, int64_t* scratch_idx, float* scratch_dist) -> int {
+        const int* qo = reinterpret_cast<const int*>(ix->sched_dev + o_qo);
+        const int* qs = reinterpret_cast<const int*>(ix->sched_dev + o_qs);
+        const size_t per_wave = (size_t)sc.max_slots_per_qt * klw;
+        if (per_wave * 16 <= 48 * 1024) {
+            pool_floor_kernel<<<dim3((unsigned)((nq + 3) / 4)), dim3(256), per_wave * 16, s>>>(a.state_s, a.state_cnt, a.state_thr, qo, qs, nq, kk,
+                                                                                               klw, (int)per_wave, a.gthr);
+            HB_HIP(hipGetLastError());
+            return 0;
+        }
+        if (launch_merge(ix, a.state_s, a.state_i, a.state_cnt, a.state_thr, qo, qs, sc.max_slots_per_qt, nqt, nq, kk, klw, 0, 0, nullptr,
+                         scratch_idx, scratch_dist, s)) return -1;
+        seed_floors_kernel<<<dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s>>>(scratch_idx, scratch_dist, nq, kk, a.gthr);
+        HB_HIP(hipGetLastError());
+        return 0;
+    };
     if (f16) {
         // fp16 copy of the query fragment tiles (the bank's is up to date: top of this function)
         const int64_t nqp = (int64_t)nqt * HB_QT;
@@ -896,11 +964,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
             h.wg_off = phase_begin(ph); h.wg_end = phase_end(ph);
             if (f16_design == 3 ? hb_knn_f16s_launch(h, sc.G, s) : hb_knn_f16_launch(h, sc.G, f16_design, s)) return -1;
             if (ph + 1 < n_phases) {   // the k'-th best of all rows seen so far -> every slot's floor
-                if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, a.state_thr, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
-                                 reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, kc, klw, 0, 0, nullptr,
-                                 cand_idx, cand_dist, s)) return -1;
-                seed_floors_kernel<<<dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s>>>(cand_idx, cand_dist, nq, kc, a.gthr);
-                HB_HIP(hipGetLastError());
+                if (seed_floors(kc, cand_idx, cand_dist)) return -1;
                 if (a.cl > 1) HB_HIP(hipMemsetAsync(a.prog, 0, prog_bytes - HB_CLUSTER_LINE * 4, s));   // progress words (not the statistics)
             }
         }
@@ -1011,11 +1075,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         fn<<<dim3((unsigned)sc.G), dim3(threads), lds_bytes, s>>>(a);
         HB_HIP(hipGetLastError());
         if (ph + 1 < n_phases) {   // the k-th best ORDERING score of all rows seen so far -> every slot's floor (the outputs serve as scratch)
-            if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, pool_cnt ? a.state_thr : nullptr, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
-                             reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, k, klw, 0, 0, nullptr,
-                             out_idx, out_dist, s)) return -1;
-            seed_floors_kernel<<<dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s>>>(out_idx, out_dist, nq, k, a.gthr);
-            HB_HIP(hipGetLastError());
+            if (seed_floors(k, out_idx, out_dist)) return -1;   // (the outputs serve as scratch)
             if (a.cl > 1) HB_HIP(hipMemsetAsync(a.prog, 0, prog_bytes - HB_CLUSTER_LINE * 4, s));
         }
     }
