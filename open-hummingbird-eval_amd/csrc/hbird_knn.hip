@@ -774,12 +774,13 @@ __global__ __launch_bounds__(256) void pool_floor_kernel(const float* __restrict
 int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t id_base, int64_t* out_idx, float* out_dist) {
     if (k < 1 || k > 256) return hb_fail("hb_index_search: k must be in [1, 256]");
     // fp16 mode 2 (what the plugin's use_fp16=True selects): the candidate pass only where it pays.  Its fixed costs are per query
-    // (fp16 query tiles, re-rank, a second merge) and per search (the phases' launches and merges), so the crossover is a bank
-    // size that grows as the queries get few: at least 32,768 rows and rows x queries >= 2^27.  Same box, whole search, fp32 /
-    // use_fp16 ms (phased pools): 12,544 x 384 queries: 16 k rows 2.09 / 2.23, 32 k 3.36 / 3.02, 50 k 4.63 / 3.45, 131 k 10.28 / 5.22;
-    // 21,904 x 768: 32 k 8.79 / 8.97, 50 k 12.85 / 10.66, 131 k 31.4 / 14.6; 784 x 384: 131 k 1.72 / 1.87, 400 k 3.50 / 2.37;
-    // 2,048 x 1024: 16 k 1.25 / 1.22, 50 k 2.64 / 1.72.  Same results either way.
-    bool f16 = ix->fp16 != 0 && k <= 128 && (ix->fp16 == 1 || (ix->ntotal >= 32768 && ix->ntotal * nq >= ((int64_t)1 << 27)));
+    // (fp16 query tiles, re-rank, a second merge) and per search (the phases' launches and floor kernels), so the crossover is a
+    // bank size that grows as the queries get few: at least 16,384 rows and rows x queries >= 2^27.  Same box, whole search, fp32 /
+    // use_fp16 ms (phased pools): 12,544 x 384 queries: 8 k rows 1.27 / 0.83, 16 k 2.04 / 1.08, 50 k 4.54 / 1.81, 131 k 10.13 / 2.88,
+    // 2,074,072 140.4 / 22.4; 21,904 x 768: 8 k 2.87 / 3.34, 16 k 4.89 / 4.41, 50 k 12.72 / 7.24, 131 k 31.3 / 11.1; 784 x 384: 100 k
+    // 1.51 / 1.67, 200 k 2.18 / 1.91; 1,369 x 768: 50 k 1.77 / 2.35, 100 k 2.81 / 2.67; 196 x 384: 200 k 1.33 / 1.37, 1 M 2.83 / 1.91.
+    // Same results either way.
+    bool f16 = ix->fp16 != 0 && k <= 128 && (ix->fp16 == 1 || (ix->ntotal >= 16384 && ix->ntotal * nq >= ((int64_t)1 << 27)));
     // which candidate kernel: 2 = the second design (32x32x16 MFMA, register-resident query fragments: the default wherever its pools
     // fit, k' <= 128, i.e. k <= 64), 1 = the first design (variant 2, and pools beyond 256 entries), 3 = the third design on
     // v_mfma_f32_16x16x32_f16 (variant 5: same bits, not faster -- hbird_knn_f16s.hip)
