@@ -814,7 +814,9 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     }
     // fp16 mode: the fused kernel collects kc >= 2k candidates, the fp32 chain arithmetic re-ranks them
     const int kc = f16 ? std::min(256, std::max(64, (2 * k + 63) / 64 * 64)) : k;
-    const bool wide = f16 || k > HB_KL;   // (pools for k <= 32 on small searches were tried: 8.1 vs 5.0 ms at 50,176 x 384)
+    // (pools for k <= 32: 8.1 vs 5.0 ms at 50,176 x 384 in round 2; with the phased pools of round 3 4.58 vs 4.75 ms there, 14.96 vs
+    // 15.39 at 200 k x 384, but 15.04 vs 13.15 at 50,176 x 768 x 21,904 queries: the lists stay)
+    const bool wide = f16 || k > HB_KL;
     // pools (k > HB_KL): capacity >= 2 kc so that a compaction is paid for by >= kc cheap appends
     // (smaller / larger pools measure the same on the fp16 candidate kernel: kc + 64, kc + 192)
     const int klw = wide ? std::min(HB_POOL_MAX, (std::max(2 * kc, kc + 128) + 63) / 64 * 64) : HB_KL;
