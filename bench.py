@@ -240,16 +240,17 @@ def measure_traffic(a, kernel):
                                 names[row["Dispatch_Id"]] = row["Kernel_Name"].split("(")[0].replace("void ", "")
             if not per_dispatch:
                 return None, f"rocprofv3 --pmc {ctr}: no {kernel} rows (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}"
-            # the child runs ONE search: its main launch is the dispatch that moved the most (a fallback or merge helper
-            # of the same family would be orders of magnitude below)
+            # the child runs ONE search: a pool search (use_fp16, k > 32, small banks) launches its kernel once per phase, so the
+            # search's traffic is the sum over the family's dispatches (the LDS-list searches are one launch); the name is the
+            # dispatch's that moved the most
             top = max(per_dispatch, key=per_dispatch.get)
-            vals[ctr], vals["kernel"] = per_dispatch[top], names[top]     # KiB per launch
+            vals[ctr], vals["kernel"], vals["launches"] = sum(per_dispatch.values()), names[top], len(per_dispatch)     # KiB per search
         except Exception as e:     # the measurement is optional evidence, never a reason to lose the bench line
             return None, f"rocprofv3 --pmc {ctr} failed: {e!r}"
         finally:
             shutil.rmtree(out, ignore_errors=True)
     return 2.0 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024, \
-        f"live: rocprofv3 --pmc on {vals['kernel']}: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE = {vals['FETCH_SIZE']:.0f} KiB x2 + {vals['WRITE_SIZE']:.0f} KiB"
+        f"live: rocprofv3 --pmc on {vals['kernel']} ({vals['launches']} launch(es) of one search): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE = {vals['FETCH_SIZE']:.0f} KiB x2 + {vals['WRITE_SIZE']:.0f} KiB"
 
 
 _JSON_FD = None

@@ -183,7 +183,8 @@ int hb_index_last_fp16_fallbacks(const hb_index_t* ix, int64_t* n);
  * through LDS); 3 = the fp32 kernel with register-resident query fragments wherever it applies (D padded to a
  * multiple of 32: what the default does too); 4 = never that kernel (both operands staged through LDS); 5 = the third design of
  * the fp16 candidate kernel (v_mfma_f32_16x16x32_f16 on fp16 blocks of 16 rows x 32 k; as fast as the default within the box-to-box
- * spread, kept for A/B).  The environment variable HBIRD_KNN_VARIANT presets it for new handles. */
+ * spread, kept for A/B); 6 = small fp32 searches with k <= 32 on sorted LDS lists as until round 3 (the default runs them on
+ * phased candidate pools).  The environment variable HBIRD_KNN_VARIANT presets it for new handles. */
 int hb_index_set_variant(hb_index_t* ix, int variant);
 /* Work-list statistics of the last search: out[0]=workgroups, [1]=segments, [2]=slots, [3]=panel tiles,
  * [4]=max slots per query tile, [5]=query tiles, [6]=bank tiles, [7]=cluster shape (query ways * 16 + bank ways). */

@@ -75,7 +75,7 @@ extern "C" int hb_index_create(int d, int metric, int device, hb_index_t** out) 
     HB_HIP(hipMemset(ix->bmax, 0, 4));
     HB_HIP(hipEventCreate(&ix->ev0));
     HB_HIP(hipEventCreate(&ix->ev1));
-    if (const char* v = getenv("HBIRD_KNN_VARIANT")) ix->variant = atoi(v) >= 0 && atoi(v) <= 5 ? atoi(v) : 0;   // A/B of kernel variants
+    if (const char* v = getenv("HBIRD_KNN_VARIANT")) ix->variant = atoi(v) >= 0 && atoi(v) <= 6 ? atoi(v) : 0;   // A/B of kernel variants
     *out = ix;
     return 0;
 }
@@ -208,7 +208,7 @@ extern "C" int hb_index_set_cluster(hb_index_t* ix, int cluster_q, int cluster_b
 
 extern "C" int hb_index_set_variant(hb_index_t* ix, int variant) {
     if (!ix) return hb_fail("hb_index_set_variant: NULL index handle");
-    if (variant < 0 || variant > 5) return hb_fail("hb_index_set_variant: unknown kernel variant");
+    if (variant < 0 || variant > 6) return hb_fail("hb_index_set_variant: unknown kernel variant");
     ix->variant = variant;
     return 0;
 }

@@ -814,9 +814,21 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     }
     // fp16 mode: the fused kernel collects kc >= 2k candidates, the fp32 chain arithmetic re-ranks them
     const int kc = f16 ? std::min(256, std::max(64, (2 * k + 63) / 64 * 64)) : k;
-    // (pools for k <= 32: 8.1 vs 5.0 ms at 50,176 x 384 in round 2; with the phased pools of round 3 4.58 vs 4.75 ms there, 14.96 vs
-    // 15.39 at 200 k x 384, but 15.04 vs 13.15 at 50,176 x 768 x 21,904 queries: the lists stay)
-    const bool wide = f16 || k > HB_KL;
+    // Small searches (few stages per workgroup) on the kernel with register-resident query fragments run on POOLS even for k <= 32:
+    // phased, with the bisection cold start and the scan epilogue (hbird_knn_bd.hip <WIDE, COLD>) a pool takes a tile's survivors in one
+    // drain, a sorted LDS list one wave-cooperative insertion each.  Same box, kernel ms, lists / pools, k = 30: 50,176 x 384 x 12,544
+    // queries 4.61 / 4.13 (k = 32: 4.50 / 3.84), x 21,904 queries 7.04 / 6.52, 50,176 x 768 12.47 / 12.16, 200 k x 384 14.76 / 13.89,
+    // 300 k x 768 40.6 / 39.9, 2,074,072 x 384 140.5 / 137.4, 600 k x 1024 105.8 / 105.3, 1.25 M x 768 286.0 / 286.7, 2.5 M x 768
+    // 573.5 / 571.5, 20 k x 384 x 784 queries 0.59 / 0.26, 100 k x 384 x 196 queries 0.61 / 0.26; k = 5 at 50,176 x 384 3.61 / 3.68 and
+    // k = 1 at 200 k x 384 13.47 / 13.54 (few insertions anyway) -> from k = 8.  (Round 2 measured pools at 8.1 vs 5.0 ms for the first
+    // of these: unphased, radix cold start, LDS walk.)  Variant 6 keeps the lists (A/B, tests).
+    static const long long small_limit = getenv("HBIRD_SMALL_LIMIT") ? atoll(getenv("HBIRD_SMALL_LIMIT")) : 400000;   // stages per workgroup
+    const int G0 = ix->force_G > 0 ? ix->force_G : ix->num_cu;
+    const long long pairs0 = (long long)((nq + HB_QT - 1) / HB_QT) * ((ix->ntotal + HB_BT - 1) / HB_BT);
+    const bool small_shape = pairs0 / std::max<long long>(1, std::min<long long>(G0, pairs0)) * ix->g8 < small_limit;
+    const bool bd_shape = ix->g8 % 4 == 0 && !ix->ablate && ix->variant != 4;
+    const bool small_pools = !f16 && k >= 8 && k <= HB_KL && small_shape && bd_shape && (ix->variant == 0 || ix->variant == 3) && ix->force_cq <= 1;
+    const bool wide = f16 || k > HB_KL || small_pools;
     // pools (k > HB_KL): capacity >= 2 kc so that a compaction is paid for by >= kc cheap appends
     // (smaller / larger pools measure the same on the fp16 candidate kernel: kc + 64, kc + 192)
     const int klw = wide ? std::min(HB_POOL_MAX, (std::max(2 * kc, kc + 128) + 63) / 64 * 64) : HB_KL;
@@ -913,6 +925,10 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     a.gthr = reinterpret_cast<unsigned*>(ix->state + 2 * state_half + 2 * state_aux);
     a.qfl = a.gthr + (size_t)nqt * HB_QT;
     HB_HIP(hipMemsetD32Async((hipDeviceptr_t)a.gthr, 0x007FFFFF, (size_t)nqt * HB_QT * 17, s));   // key(-inf)
+    // the padding queries of the last query tile (zero vectors: every row scores the same) start from key(+inf): nothing ever passes
+    // their threshold.  Without it a slot's first tile appended all 256 tied rows for each of them and compacted their pools on the spot
+    // (50,176 x 384 x 21,904 queries, 112 padding queries, pools: 943 us for a one-tile phase that takes 136 us with 21,760 queries)
+    if (nq < (int64_t)nqt * HB_QT) HB_HIP(hipMemsetD32Async((hipDeviceptr_t)(a.gthr + nq), 0xFF800000u, (size_t)((int64_t)nqt * HB_QT - nq), s));
     a.wg_member = reinterpret_cast<const int*>(ix->sched_dev + o_wm);
     a.prog = reinterpret_cast<int*>(ix->state + 2 * state_half + 2 * state_aux + floor_bytes);
     a.cl = sc.cq * sc.cb;
@@ -1048,10 +1064,8 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // stages per workgroup): 612.7 / 579.1 / 579.6 -> small below 400 k stages.  The big searches keep the plain
     // instantiations: at 10 M x 768 the extra code costs 0.3 % (same-box A/B).
     static const knn_fn cold_fn = knn_fused_kernel<512, false>;
-    const bool bd_shape = ix->g8 % 4 == 0 && !ix->ablate && ix->variant != 4;
-    static const long long small_limit = getenv("HBIRD_SMALL_LIMIT") ? atoll(getenv("HBIRD_SMALL_LIMIT")) : 400000;   // stages per workgroup
-    const bool small = !wide && a.cl == 1 && (long long)nqt * nbt / std::max(1, sc.G) * ix->g8 < small_limit;
-    if (small) fn = cold_fn;
+    const bool small = !f16 && a.cl == 1 && (long long)nqt * nbt / std::max(1, sc.G) * ix->g8 < small_limit;   // lists: cold_fn / <false, false, COLD>; pools: <WIDE, false, COLD>
+    if (small && !wide) fn = cold_fn;
     if (!wide && ix->ablate)
         for (size_t i = 0; i < sizeof(variants) / sizeof(variants[0]); ++i) if (variant_bits[i] == ix->ablate) fn = variants[i];
     int threads = HB_THREADS;
@@ -1063,9 +1077,9 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // The query fragments straight into registers (hbird_knn_bd.hip): -3.8 % kernel time at 10 M x 768 (0.895 -> 0.93 of the
     // fp32 MFMA peak), same bits.  Default for the big LDS-list searches whose stage count per tile is a multiple of four
     // (D = 384, 768, 1024, ...); variant 3 forces it wherever it applies (tests), variant 4 keeps the LDS-staged kernel.
-    if (bd_shape && (ix->variant == 0 || ix->variant == 3)) {
+    if (bd_shape && (ix->variant == 0 || ix->variant == 3 || ix->variant == 6)) {
         fn = hb_knn_bd_kernel(wide, a.cl > 1, small);
-        lds_bytes = hb_knn_bd_lds_bytes(small);
+        lds_bytes = hb_knn_bd_lds_bytes(small && !wide);
     }
     if (hb_ensure_dyn_lds((const void*)fn, lds_bytes)) return -1;   // per (kernel, device)
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev0, s));

@@ -100,6 +100,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
             thr = lst_s[myq * HB_KL + (k - 1)];
         }
         thr = fmaxf(thr, floor_load(HB_KARG(knn_args, gthr), seg.q_tile * HB_QT + myq));
+        [[maybe_unused]] bool bulk = seg.tile0 < 16;   // WIDE && COLD: loose floors at the start of a search (pool_epilogue_scan)
         const char* qsrc = reinterpret_cast<const char*>(a.q_tiles + ((size_t)(seg.q_tile * 8 + w) * g8) * HB_BLK);
         const int total = seg.n_tiles * g8;
         f32x16 acc[8];
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
             BD_WAIT(3, 1, bq[((U) + 1) & 3])   /* stage st + 1 has landed for me (st + 2 in flight) ... */              \
             __builtin_amdgcn_s_barrier();      /* ... and for everyone; the slot of stage st - 1 is free for st + 3 */   \
             /* small searches: this tile's floors, requested HERE so that they are older than the stage's own requests */ \
-            if constexpr (COLD && (U) == 0) { if (ks == BD_FLOOR_KS) small_floor_request(HB_KARG(knn_args, qfl), HB_KARG(knn_args, gthr), seg, w, lane, qf, sc); } \
+            if constexpr (COLD && !WIDE && (U) == 0) { if (ks == BD_FLOOR_KS) small_floor_request(HB_KARG(knn_args, qfl), HB_KARG(knn_args, gthr), seg, w, lane, qf, sc); } \
             int slot_n = slot_c + 1; if (slot_n == BD_RING) slot_n = 0;                                                 \
             const f32x4* Ac = reinterpret_cast<const f32x4*>(smem + slot_c * BD_SLOT) + lane;                           \
             const f32x4* An = reinterpret_cast<const f32x4*>(smem + slot_n * BD_SLOT) + lane;                           \
@@ -238,7 +239,12 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
                     const int klw = HB_KARG(knn_args, klw);
                     float* ps = HB_KARG(knn_args, state_s) + (size_t)slot_ * HB_QT * klw;
                     unsigned* pi = HB_KARG(knn_args, state_i) + (size_t)slot_ * HB_QT * klw;
-                    tile_epilogue<true, true>(acc, thr, ps, pi, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
+                    if constexpr (COLD) {
+                        // small searches: a slot sees few rows, so its first tiles and its appends are a visible share -- cold start,
+                        // then the fp16 candidate kernel's epilogue (register queue, one drain per tile; hbird_knn_dev.h)
+                        if (sp_->first && bt == sp_->b_tile0) thr = fmaxf(thr, cold_start_threshold(acc, k));
+                        pool_epilogue_scan<HB_POOL_MAX / 64>(acc, thr, ps, pi, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt, bulk);
+                    } else tile_epilogue<true, true>(acc, thr, ps, pi, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
                 } else if constexpr (COLD) {
                     if (seg.first && bt == seg.b_tile0) thr = fmaxf(thr, cold_start_threshold(acc, k));
                     // the floors requested at the tile's start (waves 4-7: behind their query fragments; waves 0-3 have passed
@@ -273,8 +279,8 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
 }
 
 hb_knn_fn hb_knn_bd_kernel(bool wide, bool clustered, bool small) {
-    if (small && !wide && !clustered) return knn_fused_bd_kernel<false, false, true>;
+    if (small && !clustered) return wide ? knn_fused_bd_kernel<true, false, true> : knn_fused_bd_kernel<false, false, true>;
     if (clustered) return wide ? knn_fused_bd_kernel<true, true> : knn_fused_bd_kernel<false, true>;
     return wide ? knn_fused_bd_kernel<true, false> : knn_fused_bd_kernel<false, false>;
 }
-int hb_knn_bd_lds_bytes(bool small) { return small ? BD_LDS_TOTAL_COLD : BD_LDS_TOTAL; }
+int hb_knn_bd_lds_bytes(bool small_lists) { return small_lists ? BD_LDS_TOTAL_COLD : BD_LDS_TOTAL; }

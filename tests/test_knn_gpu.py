@@ -369,7 +369,7 @@ def test_four_wave_kernel_variant_bit_exact(cuda_device, M, D, nq, k):
     _check_exact(idx, dist, q, bank, k, "dot_product")
 
 
-@pytest.mark.parametrize("variant", [3, 4])
+@pytest.mark.parametrize("variant", [3, 4, 6])   # 6: small searches on sorted LDS lists (the default runs them on pools since round 3)
 @pytest.mark.parametrize("M,D,nq,k,metric", [(5000, 64, 300, 30, "dot_product"), (20000, 384, 520, 30, "l2"), (7000, 96, 257, 5, "dot_product"),
                                               (3000, 32, 100, 90, "dot_product"), (9000, 128, 300, 200, "l2"), (4000, 40, 64, 30, "dot_product")])
 def test_register_resident_query_fragment_kernel_bit_exact(cuda_device, variant, M, D, nq, k, metric):
