@@ -825,7 +825,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     static const long long small_limit = getenv("HBIRD_SMALL_LIMIT") ? atoll(getenv("HBIRD_SMALL_LIMIT")) : 400000;   // stages per workgroup
     const int G0 = ix->force_G > 0 ? ix->force_G : ix->num_cu;
     const long long pairs0 = (long long)((nq + HB_QT - 1) / HB_QT) * ((ix->ntotal + HB_BT - 1) / HB_BT);
-    const bool small_shape = pairs0 / std::max<long long>(1, std::min<long long>(G0, pairs0)) * ix->g8 < small_limit;
+    const bool small_shape = pairs0 / std::max<long long>(1, std::min<long long>(G0, pairs0)) * ix->g8 < std::min<long long>(small_limit, 120000);   // no gain beyond (1.25 M x 768: 157 k stages)
     const bool bd_shape = ix->g8 % 4 == 0 && !ix->ablate && ix->variant != 4;
     const bool small_pools = !f16 && k >= 8 && k <= HB_KL && small_shape && bd_shape && (ix->variant == 0 || ix->variant == 3) && ix->force_cq <= 1;
     const bool wide = f16 || k > HB_KL || small_pools;
