@@ -1064,7 +1064,10 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // stages per workgroup): 612.7 / 579.1 / 579.6 -> small below 400 k stages.  The big searches keep the plain
     // instantiations: at 10 M x 768 the extra code costs 0.3 % (same-box A/B).
     static const knn_fn cold_fn = knn_fused_kernel<512, false>;
-    const bool small = !f16 && a.cl == 1 && (long long)nqt * nbt / std::max(1, sc.G) * ix->g8 < small_limit;   // lists: cold_fn / <false, false, COLD>; pools: <WIDE, false, COLD>
+    // lists: cold_fn / <false, false, COLD>; pools: <WIDE, false, COLD> -- for k > 32 only below 50 k stages (k = 90: 50,176 x 384 4.78 -> 4.45 ms,
+    // k = 64 at 300 k x 768 41.9 -> 40.3, but 2,074,072 x 384 (74 k stages) 142.0 -> 142.7)
+    const long long stages_per_wg = (long long)nqt * nbt / std::max(1, sc.G) * ix->g8;
+    const bool small = !f16 && a.cl == 1 && stages_per_wg < (k > HB_KL ? std::min<long long>(small_limit, 50000) : small_limit);
     if (small && !wide) fn = cold_fn;
     if (!wide && ix->ablate)
         for (size_t i = 0; i < sizeof(variants) / sizeof(variants[0]); ++i) if (variant_bits[i] == ix->ablate) fn = variants[i];
