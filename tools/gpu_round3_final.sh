@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $ROOT
-OUT=gpurun_out/r3final; mkdir -p $OUT
+OUT=gpurun_out/${R3OUT:-r3final}; mkdir -p $OUT
 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log
 python bench.py --steps 10 --warmup 3 > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
 python bench.py --steps 10 --warmup 3 --fp16 --no-cpu-baseline --no-traffic > $OUT/bench_fp16.json 2>/dev/null
@@ -18,9 +18,10 @@ for cfg in "cfg1 50176 384 21 12544 30" "cfg2 2074072 384 21 12544 30" "cfg4 203
   python bench.py --rows $2 --dim $3 --classes $4 --nq $5 --k $6 --steps 5 --warmup 2 --no-cpu-baseline --no-traffic > $OUT/bench_$1.json 2>/dev/null
 done
 python tools/bench_ops.py $OUT/bench_ops.json > $OUT/bench_ops.txt 2>&1
-python - <<'PY'
+R3OUT=${R3OUT:-r3final} python - <<'PY'
 import json, glob
-for f in sorted(glob.glob("gpurun_out/r3final/bench_*.json")):
+import os
+for f in sorted(glob.glob("gpurun_out/" + os.environ.get("R3OUT", "r3final") + "/bench_*.json")):
     if f.endswith("bench_ops.json"): continue
     try: r = json.load(open(f))
     except Exception as e: print(f, "unreadable", e); continue
@@ -30,4 +31,11 @@ for f in sorted(glob.glob("gpurun_out/r3final/bench_*.json")):
           r.get("multi_gpu", {}).get("rows_per_rank"), r.get("label_hat_checksum"))
 PY
 grep -i "nccl\|rccl" $OUT/bench_rccl_world1.err | head -3
+# pool searches: unphased / shipped, and small fp32 searches on lists (variant 6) / shipped
+S="50176 384 12544 30 f16 300000 768 12544 30 f16 2074072 384 12544 30 f16 50176 384 12544 90 f32 2074072 384 12544 90 f32"
+L="50176 384 12544 30 f32 50176 384 21904 30 f32 200000 384 12544 30 f32 2074072 384 12544 30 f32 20000 384 784 30 f32"
+{ HBIRD_PHASES=0 python tools/exp_phases.py $S 2>&1 | grep phases | sed 's/^/unphased /'; python tools/exp_phases.py $S 2>&1 | grep phases | sed 's/^/shipped  /';
+  HBIRD_KNN_VARIANT=6 python tools/exp_phases.py $L 2>&1 | grep phases | sed 's/^/lists    /'; python tools/exp_phases.py $L 2>&1 | grep phases | sed 's/^/shipped  /'; } > $OUT/pool_searches_ab.txt
+cat $OUT/pool_searches_ab.txt
+python tools/exp_fp16_crossover.py 384 12544 30 16384 50176 2074072 > $OUT/fp16_whole_search.txt 2>&1; python tools/exp_fp16_crossover.py 768 21904 30 50176 1250000 >> $OUT/fp16_whole_search.txt 2>&1; cat $OUT/fp16_whole_search.txt
 bash tools/gpu_profile.sh r3 > $OUT/profile.log 2>&1; tail -30 $OUT/profile.log
