@@ -876,7 +876,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     const int panel = ix->force_panel > 0 ? ix->force_panel
                                           : hb_default_panel(nqt, std::min<long long>(G, (long long)nqt * nbt), tile_bytes, cq, cb);
     hb_schedule& sc = ix->sched;
-    // phased searches (pools only: seed_floors_kernel above); HBIRD_PHASES=0 turns them off (A/B)
+    // phased searches (pools only: "Phased searches" above hb_launch_knn); HBIRD_PHASES=0 turns them off (A/B)
     static const bool phases_on = !(getenv("HBIRD_PHASES") && atoi(getenv("HBIRD_PHASES")) == 0);
     const bool phased = wide && phases_on && ix->variant != 1;
     const bool rebuilt = !(sc.nqt == nqt && sc.nbt == nbt && sc.panel == panel && sc.cq == cq && sc.cb == cb && sc.phased == phased &&
@@ -911,7 +911,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     a.segs = reinterpret_cast<const hb_seg*>(ix->sched_dev);
     a.wg_off = reinterpret_cast<const int*>(ix->sched_dev + o_wg);
     a.wg_end = a.wg_off + 1;
-    // phases: pools only, and only where a phase is at least a panel's worth of tiles (HBIRD_PHASES=0 turns them off: A/B)
+    // this launch's share of every block's segments: [phase_begin(p)[b], phase_end(p)[b]) of the block's list
     const int n_phases = (int)sc.phase_clock.size() + 1;   // 1: a single launch (lists; pools with too little work per workgroup)
     const int* pb = reinterpret_cast<const int*>(ix->sched_dev + o_pb);
     auto phase_begin = [&](int p) { return p == 0 ? reinterpret_cast<const int*>(ix->sched_dev + o_wg) : pb + (size_t)(p - 1) * sc.G; };

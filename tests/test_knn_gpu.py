@@ -583,3 +583,29 @@ def test_repeatable_and_invariant_under_1_2_4_8_way_sharding(cuda_device, metric
         assert torch.equal(ix.distances_from_scores(qd, s3.clone()).view(torch.int32), ref_d.view(torch.int32))
     i4, d4 = ix.search(qd, k)                              # the mode does not stick
     assert torch.equal(d4.view(torch.int32), ref_d.view(torch.int32))
+
+
+def test_phased_and_unphased_pool_searches_return_the_same_bits(cuda_device):
+    """Pool searches (k > 32, use_fp16, small fp32 searches) are launched in phases whose boundaries hand every pool the union's k-th best
+    as a floor (hb_launch_knn); HBIRD_PHASES=0 (read once per process) runs them in one launch, HBIRD_KNN_VARIANT=6 keeps small fp32
+    searches on the sorted LDS lists.  Same ids and distances, bit for bit, in all three."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch, hashlib\n"
+        f"sys.path[:0] = [{os.path.join(root, 'open-hummingbird-eval_amd')!r}, {os.path.join(root, 'tests')!r}]\n"
+        "import golden_inputs as gi\n"
+        "from hbird_mi.nn.search_hip import HipFlatIndex\n"
+        "bank = gi.unit_bank(70001, 64, seed=5); q = torch.from_numpy(gi.vit_like_queries(1301, 64, seed=6)).cuda()\n"
+        "h = hashlib.sha256()\n"
+        "for k, fp16 in ((30, False), (90, False), (30, True)):\n"
+        "    ix = HipFlatIndex(64, 0, 0); ix.add(torch.from_numpy(bank).cuda()); ix.set_fp16(fp16)\n"
+        "    i, d = ix.search(q, k); h.update(i.cpu().numpy().tobytes()); h.update(d.cpu().numpy().tobytes())\n"
+        "print('DIGEST', h.hexdigest())\n")
+    digests = []
+    for extra in ({}, {"HBIRD_PHASES": "0"}, {"HBIRD_KNN_VARIANT": "6"}):
+        env = dict(os.environ); env.update(extra)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append([l for l in out.stdout.splitlines() if l.startswith("DIGEST")][0])
+    assert digests[0] == digests[1] == digests[2]
