@@ -757,6 +757,8 @@ __global__ __launch_bounds__(256) void pool_floor_kernel(const float* __restrict
         }
     }
     if (n < kk) return;   // fewer than kk rows seen so far: no floor yet
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are visible to its lanes
+    __builtin_amdgcn_wave_barrier();
     for (int o = 32; o > 0; o >>= 1) { hi = fmaxf(hi, __shfl_xor(hi, o)); mn = fminf(mn, __shfl_xor(mn, o)); }
     hi = fminf(hi, 3.4028234664e38f);
     const unsigned mb = __builtin_bit_cast(unsigned, mn);

@@ -43,7 +43,9 @@ def _nan_bank(M, D, seed):
 
 # (M, D, nq, k, metric, fp16, workgroups, cluster): one case per kernel path
 _PATHS = [
-    (20_000, 64, 700, 30, "dot_product", False, 0, None),    # small search: B-direct COLD instantiation (radix cold start + scan)
+    (20_000, 64, 700, 30, "dot_product", False, 0, None),    # small search: phased pools, B-direct <WIDE, COLD> (bisection cold start + scan)
+    (20_000, 64, 700, 30, "dot_product", -6, 0, None),       # small search on the sorted LDS lists (variant 6): B-direct COLD instantiation
+    (20_000, 64, 700, 5, "dot_product", False, 0, None),     # ... which k < 8 takes by itself
     (20_000, 48, 700, 30, "dot_product", False, 0, None),    # small search: LDS-staged kernel (6 stages per tile)
     (20_000, 64, 700, 30, "l2", False, 0, None),             # L2: NaN row init (-0.5 |b|^2)
     (20_000, 64, 300, 90, "dot_product", False, 0, None),    # candidate pools (k > 32)
@@ -62,6 +64,8 @@ def test_nan_bank_rows_never_enter_a_list(cuda_device, M, D, nq, k, metric, fp16
     q = gi.vit_like_queries(nq, D, seed=9)
     ix = HipFlatIndex(D, 0 if metric == "dot_product" else 1, 0)
     ix.add(torch.from_numpy(bank).cuda())
+    if fp16 == -6:
+        ix.set_variant(6); fp16 = False
     ix.set_fp16(bool(fp16))
     if fp16 == 5:
         ix.set_variant(5)
