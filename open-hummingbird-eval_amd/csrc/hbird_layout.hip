@@ -128,14 +128,27 @@ int hb_launch_rows_to_tiles(const float* src, int64_t n_rows, int d, int dp, int
 
 // Per-query constants: qn2 = k-ascending fmaf chain of q_k^2 (L2 distances), qnorm = fp32 L2 norm
 // (double accumulation) used by the cosine aggregation (F.normalize(q), hbird_eval.py:594).
-__global__ __launch_bounds__(256) void query_aux_kernel(const float* __restrict__ q, int64_t nq, int d,
-                                                        float* __restrict__ qn2, float* __restrict__ qnorm) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// One thread per query keeps both sums in their sequential order (qn2 is part of the bit-exact L2 distances).  One WAVE per block:
+// the kernel is two dependent chains of d steps per thread, so what it needs is every CU busy (12,544 queries in blocks of 256 were 49
+// blocks: 57 us; staging the rows through LDS for coalesced reads made it 96 us -- more latency in the chain, not less), and 16 bytes
+// per load (a thread's row stays in its CU's L1 between the loads that share a cache line).
+__global__ __launch_bounds__(64) void query_aux_kernel(const float* __restrict__ q, int64_t nq, int d,
+                                                       float* __restrict__ qn2, float* __restrict__ qnorm) {
+    const int64_t r = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (r >= nq) return;
     const float* row = q + r * (int64_t)d;
     float acc = 0.0f;
     double a2 = 0.0;
-    for (int k = 0; k < d; ++k) { float v = row[k]; acc = fmaf(v, v, acc); a2 += (double)v * v; }
+    int k = 0;
+    if ((d & 3) == 0 && (reinterpret_cast<uintptr_t>(q) & 15) == 0) {
+#pragma unroll 4
+        for (; k < d; k += 4) {
+            const float4 v4 = *reinterpret_cast<const float4*>(row + k); const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc = fmaf(v[j], v[j], acc); a2 += (double)v[j] * v[j]; }
+        }
+    }
+    for (; k < d; ++k) { const float v = row[k]; acc = fmaf(v, v, acc); a2 += (double)v * v; }
     qn2[r] = acc;
     qnorm[r] = (float)sqrt(a2);
 }
@@ -161,7 +174,7 @@ int hb_launch_scores_to_l2(const float* qn2, int64_t nq, int k, float* dist_inou
 
 int hb_launch_query_aux(const float* q, int64_t nq, int d, float* qn2, float* qnorm, hipStream_t s) {
     if (nq == 0) return 0;
-    query_aux_kernel<<<dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s>>>(q, nq, d, qn2, qnorm);
+    query_aux_kernel<<<dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, s>>>(q, nq, d, qn2, qnorm);
     HB_HIP(hipGetLastError());
     return 0;
 }
