@@ -763,10 +763,13 @@ __global__ __launch_bounds__(256) void pool_floor_kernel(const float* __restrict
     hi = fminf(hi, 3.4028234664e38f);
     const unsigned mb = __builtin_bit_cast(unsigned, mn);
     float lo = __builtin_bit_cast(float, mn > 0.f ? mb - 1u : (mn == 0.f ? 0x80000001u : mb + 1u));   // all n exceed it
+    // the first 256 gathered scores in registers (usually all of them): a round is then compares and ballots only
+    const float r0 = lane < n ? cs[lane] : -INFINITY, r1 = 64 + lane < n ? cs[64 + lane] : -INFINITY;
+    const float r2 = 128 + lane < n ? cs[128 + lane] : -INFINITY, r3 = 192 + lane < n ? cs[192 + lane] : -INFINITY;
     for (int it = 0; it < 14; ++it) {
         const float mid = 0.5f * lo + 0.5f * hi;
-        int c = 0;
-        for (int base = 0; base < n; base += 64) c += __popcll(__ballot(base + lane < n && cs[base + lane] > mid));
+        int c = __popcll(__ballot(r0 > mid)) + __popcll(__ballot(r1 > mid)) + __popcll(__ballot(r2 > mid)) + __popcll(__ballot(r3 > mid));
+        for (int base = 256; base < n; base += 64) c += __popcll(__ballot(base + lane < n && cs[base + lane] > mid));
         if (c >= kk) lo = mid; else hi = mid;
     }
     if (lane == 0 && lo > -INFINITY) atomicMax(gthr + q, pool_key(lo));   // kk rows exceed lo
