@@ -45,7 +45,7 @@ struct hb_seg {
     int nsl;
 };
 
-#define HB_PHASE_CUTS 24      // most phase boundaries of a pool search (hb_build_schedule: clocks 2, 6, 14, ..., 254, then x 4)
+#define HB_PHASE_CUTS 24      // most phase boundaries of a pool search (hb_build_schedule: clocks 1, 3, 6, 10, 16, 25, ... growing by half, twofold beyond 128)
 #define HB_CLUSTER_MAX 8      // workgroups per L2-sharing cluster
 #define HB_CLUSTER_LINE 32    // ints per cluster in the progress array (one 128-B line)
 
