@@ -761,8 +761,7 @@ __global__ __launch_bounds__(256) void pool_floor_kernel(const float* __restrict
     __builtin_amdgcn_wave_barrier();
     for (int o = 32; o > 0; o >>= 1) { hi = fmaxf(hi, __shfl_xor(hi, o)); mn = fminf(mn, __shfl_xor(mn, o)); }
     hi = fminf(hi, 3.4028234664e38f);
-    const unsigned mb = __builtin_bit_cast(unsigned, mn);
-    float lo = __builtin_bit_cast(float, mn > 0.f ? mb - 1u : (mn == 0.f ? 0x80000001u : mb + 1u));   // all n exceed it
+    float lo = mn - fmaxf(fabsf(mn) * 1e-6f, 1.2e-38f);   // all n exceed it (cold_start_threshold, hbird_knn_dev.h)
     // the first 256 gathered scores in registers (usually all of them): a round is then compares and ballots only
     const float r0 = lane < n ? cs[lane] : -INFINITY, r1 = 64 + lane < n ? cs[64 + lane] : -INFINITY;
     const float r2 = 128 + lane < n ? cs[128 + lane] : -INFINITY, r3 = 192 + lane < n ? cs[192 + lane] : -INFINITY;

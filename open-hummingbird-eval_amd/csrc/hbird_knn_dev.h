@@ -633,9 +633,9 @@ __device__ __forceinline__ float cold_start_threshold(f32x16 (&acc)[8], int k) {
     mn = fminf(mn, __shfl_xor(mn, 32));
     real += __shfl_xor(real, 32);
     hi = fminf(hi, 3.4028234664e38f);   // +inf scores are ordinary scores; the bisection needs finite ends
-    // lo: the float just below the smallest real score, so that every real row exceeds it
-    const unsigned mb = __builtin_bit_cast(unsigned, mn);
-    float lo = __builtin_bit_cast(float, mn > 0.f ? mb - 1u : (mn == 0.f ? 0x80000001u : mb + 1u));
+    // lo: a float below the smallest real score, so that every real row exceeds it (by a NORMAL amount: nothing here may depend on
+    // how compares and adds treat denormals -- a zero query scores 0 against every row)
+    float lo = mn - fmaxf(fabsf(mn) * 1e-6f, 1.2e-38f);
     if (real < k) { lo = -INFINITY; hi = -INFINITY; }   // fewer than k real rows: the answer stays -inf
 #pragma unroll 1
     for (int it = 0; it < 12; ++it) {

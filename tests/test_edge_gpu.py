@@ -139,6 +139,30 @@ def test_non_finite_queries(cuda_device, fp16):
     assert np.abs(lh.cpu().numpy()[clean] - want).max() < 2e-5
 
 
+@pytest.mark.parametrize("k,fp16,variant", [(30, False, 0), (30, False, 6), (90, False, 0), (30, True, 0), (5, False, 0)])
+@pytest.mark.parametrize("metric", ["dot_product", "l2"])
+def test_zero_and_denormal_scale_queries(cuda_device, k, fp16, variant, metric):
+    """A zero query scores exactly 0 against every row, a 1e-42-scale query has denormal scores: every row ties (or nearly), the
+    threshold searches of the cold start / the phase floors (bisection between a tile's smallest and largest score) must not lean on how
+    the hardware treats denormals.  Ties resolve to the lowest ids, as everywhere."""
+    M, D, nq = 40_000, 64, 300
+    bank = gi.unit_bank(M, D, seed=21)
+    q = gi.vit_like_queries(nq, D, seed=22)
+    q[0] = 0.0
+    q[1] = 1e-42                      # denormal components
+    q[2] = -1e-42
+    q[150] = 0.0
+    q[299] = 1e-30 * q[298]
+    ix = HipFlatIndex(D, 0 if metric == "dot_product" else 1, 0)
+    ix.add(torch.from_numpy(bank).cuda())
+    ix.set_fp16(fp16)
+    ix.set_variant(variant)
+    idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
+    ridx, _ = _check_exact(idx, dist, q, bank, k, metric)
+    if metric == "dot_product":
+        assert (ridx[0] == np.arange(k)).all() and (ridx[150] == np.arange(k)).all()
+
+
 @pytest.mark.parametrize("metric", ["dot_product", "l2"])
 def test_fp16_overflow_falls_back_to_fp32(cuda_device, metric):
     """use_fp16 with fp32 values beyond the fp16 range (|x| > 65,504 -> inf in fp16): a query that overflows is reported
