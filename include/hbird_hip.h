@@ -196,6 +196,11 @@ int hb_index_schedule_info(const hb_index_t* ix, int64_t out[8]);
  * the matrix pipe, clusters cut its fabric reads by 60 % for under 1 % of time there and cost more on smaller searches,
  * DESIGN.md), 1 x 1 = off, q x b with q * b <= 8 otherwise.  sync_lag: stages a member may run ahead of the slowest one before it waits (-1 = 16, 0 = never). */
 int hb_index_set_cluster(hb_index_t* ix, int cluster_q, int cluster_b, int sync_lag);
+/* How a clustered work list is dealt (speed only): 2 = every run of one query group is split over ALL clusters of an XCD, so that
+ * the XCD's workgroups keep re-reading the same cluster_q query tiles -- they stay in its L2 instead of being streamed through the
+ * fabric once per pair (the clusters of an XCD need no sync among themselves for that); 1 = each cluster takes its own range of
+ * the q-major unit list; 0 = automatic. */
+int hb_index_set_cluster_sharing(hb_index_t* ix, int mode);
 /* Soft-sync statistics of the last clustered search (synchronises the stream): out[0] = progress checks, [1] = waits
  * (re-polls while a member was behind), [2] = members that gave up waiting (bounded spin); zeros without clusters. */
 int hb_index_cluster_stats(hb_index_t* ix, int64_t out[4]);
@@ -213,6 +218,10 @@ int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, i
  * within the block's own segments, of the first segment of the next phase. */
 int hb_schedule_plan_phased(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b, int* segs_out,
                             int64_t max_segs, int64_t stats[8], int* clocks_out, int max_cuts, int* n_cuts, int* bounds_out);
+
+/* hb_schedule_plan / _phased for the work list of hb_index_set_cluster_sharing(ix, 2). */
+int hb_schedule_plan_shared(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b, int phased,
+                            int* segs_out, int64_t max_segs, int64_t stats[8]);
 
 #ifdef __cplusplus
 }

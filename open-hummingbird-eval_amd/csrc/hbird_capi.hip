@@ -138,7 +138,7 @@ extern "C" int hb_index_last_fp16_fallbacks(const hb_index_t* ix, int64_t* n) {
 // Host-only: build the kNN work list for a (query tiles x bank tiles) grid without touching a GPU, for inspection
 // and tests.  segs_out receives up to max_segs rows of {block, q_tile, b_tile0, n_tiles, slot, first}.
 static int schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b, bool phased,
-                         int* segs_out, int64_t max_segs, int64_t stats[8], hb_schedule& sc) {
+                         int* segs_out, int64_t max_segs, int64_t stats[8], hb_schedule& sc, bool xcd_share = false) {
     if (!stats) return hb_fail("hb_schedule_plan: stats is NULL");
     if (nqt <= 0 || nbt <= 0 || workgroups <= 0 || d <= 0) return hb_fail("hb_schedule_plan: bad arguments");
     const int dp = (d + HB_KC - 1) / HB_KC * HB_KC;
@@ -147,7 +147,7 @@ static int schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int 
     if (cq < 0 || cb < 0) hb_default_cluster(nqt, nbt, G, cq == -2, &cq, &cb);  // negative: the automatic shape (-1 fp16, -2 fp32 kernel)
     if (cq < 1 || cb < 1 || (long long)nqt * nbt < workgroups || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
     const int panel = panel_tiles > 0 ? panel_tiles : hb_default_panel(nqt, G, (size_t)HB_BT * dp * 4, cq, cb);
-    hb_build_schedule(nqt, nbt, workgroups, panel, sc, cq, cb, phased);
+    hb_build_schedule(nqt, nbt, workgroups, panel, sc, cq, cb, phased, xcd_share && cq * cb > 1);
     stats[0] = sc.G; stats[1] = (int64_t)sc.segs.size(); stats[2] = sc.n_slots; stats[3] = sc.panel;
     stats[4] = sc.max_slots_per_qt; stats[5] = sc.nqt; stats[6] = sc.nbt; stats[7] = sc.cq * 16 + sc.cb;
     if (segs_out) {
@@ -183,6 +183,19 @@ extern "C" int hb_schedule_plan_phased(int nqt, int nbt, int workgroups, int pan
         if (bounds_out)
             for (int b = 0; b < sc.G; ++b) bounds_out[(size_t)p * sc.G + b] = sc.phase_bounds[(size_t)p * sc.G + b] - sc.wg_off[b];
     }
+    return 0;
+}
+
+extern "C" int hb_schedule_plan_shared(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b, int phased,
+                                       int* segs_out, int64_t max_segs, int64_t stats[8]) {
+    hb_schedule sc;
+    return schedule_plan(nqt, nbt, workgroups, panel_tiles, d, cluster_q, cluster_b, phased != 0, segs_out, max_segs, stats, sc, true);
+}
+
+extern "C" int hb_index_set_cluster_sharing(hb_index_t* ix, int mode) {
+    if (!ix) return hb_fail("hb_index_set_cluster_sharing: NULL index handle");
+    if (mode < 0 || mode > 2) return hb_fail("hb_index_set_cluster_sharing: mode must be 0 (automatic), 1 (off) or 2 (on)");
+    ix->xcd_share = mode; ix->sched = hb_schedule();
     return 0;
 }
 

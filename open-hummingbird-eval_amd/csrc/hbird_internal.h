@@ -52,6 +52,7 @@ struct hb_seg {
 struct hb_schedule {
     int nqt = 0, nbt = 0, G = 0, panel = 0;
     int cq = 1, cb = 1;              // cluster shape: cq query tiles x cb interleaved bank tiles (1 x 1: no clusters)
+    bool xcd_share = false;          // clusters: all clusters of an XCD walk the same query group (hb_build_clustered)
     std::vector<hb_seg> segs;        // grouped by workgroup
     std::vector<int> wg_off;         // G+1 offsets into segs
     std::vector<int> wg_member;      // per block: cluster * HB_CLUSTER_LINE + member (progress word of the block)
@@ -65,7 +66,8 @@ struct hb_schedule {
     int n_clusters = 0;
 };
 
-void hb_build_schedule(int nqt, int nbt, int G, int panel_tiles, hb_schedule& out, int cq = 1, int cb = 1, bool phased = false);
+void hb_build_schedule(int nqt, int nbt, int G, int panel_tiles, hb_schedule& out, int cq = 1, int cb = 1, bool phased = false,
+                       bool xcd_share = false);
 int hb_default_panel(int nqt, int G, size_t tile_bytes, int cq = 1, int cb = 1);
 // automatic cluster shape for a search (1 x 1 when clusters do not apply)
 void hb_default_cluster(int nqt, int nbt, int G, bool fp32_kernel, int* cq, int* cb);
@@ -93,6 +95,7 @@ struct hb_index {
     int force_G = 0, force_panel = 0;                    // test/tuning overrides
     int force_cq = 0, force_cb = 0;                      // cluster shape override (0 = automatic)
     int sync_lag = -1;                                   // soft-sync lag in stages (-1 = automatic, 0 = no sync)
+    int xcd_share = 0;                                   // clustered work lists: 0 = automatic, 1 = off, 2 = on (hb_index_set_cluster_sharing)
     const int* cl_stats_dev = nullptr;                   // {checks, spins, timeouts} of the last clustered launch (in `state`)
     // fp16 candidate mode (use_fp16): fp16 copies of the bank / query fragment tiles, candidate buffers
     int fp16 = 0, dp16 = 0;

@@ -578,39 +578,67 @@ static void hb_finish_schedule(hb_schedule& out, std::vector<std::vector<hb_seg>
     }
 }
 
-static void hb_build_clustered(int nqt, int nbt, int G, int panel, int cq, int cb, hb_schedule& out) {
+static void hb_build_clustered(int nqt, int nbt, int G, int panel, int cq, int cb, hb_schedule& out, bool xcd_share) {
     const int CS = cq * cb, NC = G / CS, NQG = (nqt + cq - 1) / cq;
-    out.cq = cq; out.cb = cb; out.n_clusters = NC;
+    out.cq = cq; out.cb = cb; out.n_clusters = NC; out.xcd_share = xcd_share;
     std::vector<std::vector<hb_seg>> per_wg(G);   // logical workgroup = cluster * CS + member
     std::map<std::pair<int, int>, int> slot_of;   // (logical wg, q_tile) -> slot
     std::vector<std::vector<int>> slots_of_qt(nqt);
     std::vector<int> clock(NC, 0);                // cluster clock: tiles each member has been dealt (idle ones included)
+    // units [qg][j0, j0 + cnt) of the panel at bank tile b0 (pp tiles) -> the members of cluster c
+    auto deal = [&](int c, int b0, int pp, int qg, int j0, int cnt) {
+        for (int m = 0; m < CS; ++m) {
+            const int ia = m / cb, ib = m % cb, q = qg * cq + ia, w = c * CS + m;
+            int n = cnt;
+            if ((j0 + cnt - 1) * cb + ib >= pp) --n;      // the partial last group has no tile for this member
+            if (q >= nqt || n <= 0) continue;             // idle for these units (its clock still advances)
+            hb_seg sg;
+            sg.q_tile = q; sg.b_tile0 = b0 + j0 * cb + ib; sg.n_tiles = n; sg.stride = cb; sg.tile0 = clock[c]; sg.next_tile0 = 0;
+            auto key = std::make_pair(w, q);
+            auto it = slot_of.find(key);
+            if (it == slot_of.end()) {
+                sg.slot = out.n_slots++; sg.first = 1;
+                slot_of[key] = sg.slot;
+                slots_of_qt[q].push_back(sg.slot);
+            } else { sg.slot = it->second; sg.first = 0; }
+            per_wg[w].push_back(sg);
+        }
+        clock[c] += cnt;
+    };
+    const int per_xcd_c = NC / 8;
+    int rot = 0;
     for (int b0 = 0; b0 < nbt; b0 += panel) {
         const int pp = std::min(panel, nbt - b0);
         const int UB = (pp + cb - 1) / cb;        // bank groups of the panel (the last one may be partial)
         const long long U = (long long)NQG * UB;
+        if (xcd_share) {
+            // XCD-level sharing of the QUERY tiles: the q-major unit list is cut into eight ranges, one per XCD, and every run of
+            // one query group inside a range is split over ALL clusters of that XCD (contiguous bank sub-ranges), so that at any
+            // time the XCD's workgroups re-read the same cq query tiles -- which then stay in its L2 (cq x 384 KiB of fp16 at
+            // D = 768 beside the bank streams) instead of being re-streamed through the fabric for every pair; the clusters among
+            // themselves need no sync for that.  The remainders of a run rotate over the clusters (balance within a tile or two).
+            for (int x = 0; x < 8; ++x) {
+                long long e = (U * x) / 8;
+                const long long e1 = (U * (x + 1)) / 8;
+                while (e < e1) {
+                    const int qg = (int)(e / UB), j0 = (int)(e % UB);
+                    const int L = (int)std::min<long long>(UB - j0, e1 - e);
+                    for (int i = 0; i < per_xcd_c; ++i) {
+                        const int a0 = (int)((long long)L * i / per_xcd_c), a1 = (int)((long long)L * (i + 1) / per_xcd_c);
+                        if (a1 > a0) deal(x * per_xcd_c + (i + rot) % per_xcd_c, b0, pp, qg, j0 + a0, a1 - a0);
+                    }
+                    ++rot;
+                    e += L;
+                }
+            }
+            continue;
+        }
         for (int c = 0; c < NC; ++c) {
             long long e0 = (U * c) / NC, e1 = (U * (c + 1)) / NC;
             while (e0 < e1) {
                 const int qg = (int)(e0 / UB), j0 = (int)(e0 % UB);
                 const int cnt = (int)std::min<long long>(UB - j0, e1 - e0);
-                for (int m = 0; m < CS; ++m) {
-                    const int ia = m / cb, ib = m % cb, q = qg * cq + ia, w = c * CS + m;
-                    int n = cnt;
-                    if ((j0 + cnt - 1) * cb + ib >= pp) --n;      // the partial last group has no tile for this member
-                    if (q >= nqt || n <= 0) continue;             // idle for these units (its clock still advances)
-                    hb_seg sg;
-                    sg.q_tile = q; sg.b_tile0 = b0 + j0 * cb + ib; sg.n_tiles = n; sg.stride = cb; sg.tile0 = clock[c]; sg.next_tile0 = 0;
-                    auto key = std::make_pair(w, q);
-                    auto it = slot_of.find(key);
-                    if (it == slot_of.end()) {
-                        sg.slot = out.n_slots++; sg.first = 1;
-                        slot_of[key] = sg.slot;
-                        slots_of_qt[q].push_back(sg.slot);
-                    } else { sg.slot = it->second; sg.first = 0; }
-                    per_wg[w].push_back(sg);
-                }
-                clock[c] += cnt;
+                deal(c, b0, pp, qg, j0, cnt);
                 e0 += cnt;
             }
         }
@@ -628,7 +656,7 @@ static void hb_build_clustered(int nqt, int nbt, int G, int panel, int cq, int c
     hb_finish_schedule(out, per_wg, logical_of_block, slots_of_qt);
 }
 
-void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out, int cq, int cb, bool phased) {
+void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out, int cq, int cb, bool phased, bool xcd_share) {
     out = hb_schedule();
     out.nqt = nqt; out.nbt = nbt; out.panel = panel; out.phased = phased;
     const long long total_pairs = (long long)nqt * nbt;
@@ -651,7 +679,7 @@ void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out, int
         }
     }
     if (cq < 1 || cb < 1 || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
-    if (cq * cb > 1) { hb_build_clustered(nqt, nbt, G, panel, cq, cb, out); return; }
+    if (cq * cb > 1) { hb_build_clustered(nqt, nbt, G, panel, cq, cb, out, xcd_share); return; }
     std::vector<std::vector<hb_seg>> per_wg(G);
     std::map<std::pair<int, int>, int> slot_of;   // (wg, q_tile) -> slot
     std::vector<std::vector<int>> slots_of_qt(nqt);
@@ -883,9 +911,10 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // phased searches (pools only: "Phased searches" above hb_launch_knn); HBIRD_PHASES=0 turns them off (A/B)
     static const bool phases_on = !(getenv("HBIRD_PHASES") && atoi(getenv("HBIRD_PHASES")) == 0);
     const bool phased = wide && phases_on && ix->variant != 1;
+    const bool xs = cq * cb > 1 && ix->xcd_share == 2;
     const bool rebuilt = !(sc.nqt == nqt && sc.nbt == nbt && sc.panel == panel && sc.cq == cq && sc.cb == cb && sc.phased == phased &&
-                           (sc.G == G || (long long)nqt * nbt < G));
-    if (rebuilt) hb_build_schedule(nqt, nbt, G, panel, sc, cq, cb, phased);
+                           sc.xcd_share == xs && (sc.G == G || (long long)nqt * nbt < G));
+    if (rebuilt) hb_build_schedule(nqt, nbt, G, panel, sc, cq, cb, phased, xs);
     // device copy of the work list: [segs][wg_off][qt_off][qt_slots][wg_member]
     const size_t b_segs = sc.segs.size() * sizeof(hb_seg), b_wg = sc.wg_off.size() * 4, b_qo = sc.qt_off.size() * 4,
                  b_qs = sc.qt_slots.size() * 4, b_wm = sc.wg_member.size() * 4;

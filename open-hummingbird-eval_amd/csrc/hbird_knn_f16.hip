@@ -233,47 +233,30 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
 // the ring then holds bank fragments only (8 slots x 16 KiB) and the bank fragments need ONE register set: fragment t is
 // re-loaded right after MFMA t has issued, 8 MFMAs before its next use.  Per group: 64 KiB of reads + 8 KiB of copies.
 // Stages are unrolled by four so that the register buffers of the query fragments have static indices.
+//
+// Round 4: the stage loop's SCALAR side.  A model of this loop with the same traffic on random operands
+// (tools/ubench/f16_stage_model.hip: 16 MFMAs + 16 fragment reads + 2 query-fragment loads + 2 copies per wave and k32 stage, one
+// barrier) runs at 0.55 of the nominal fp16 peak where this kernel's loop, without its epilogue, ran at 0.46: the difference was
+// not memory but instructions -- per copy a 64-bit multiply chain for the source address, a per-lane 64-bit VALU add (the
+// builtin's flat-address form), v_readlane reloads of 78 spilled SGPRs, compare + branch pairs for the two wave classes and the
+// cluster tick's tests in every stage.  Now: the fetch position is three running 64-bit scalars (query fragments, bank row
+// tile, row-init values) that advance by constants, the copies use the saddr form (wave-uniform base + 32-bit lane offset, M0
+// = wave-uniform LDS address) from inline asm, every wave issues at the same MFMA gaps, the cluster tick sits in the one
+// stage of four that can act, and arguments used only at segment boundaries are re-read from the kernarg segment (HB_KARG).
 #define F2_RING 8
-#if defined(F16_ABL) && (F16_ABL & 2)
-#define F2_ABL_BT(x) ((x) & 3)        // timing only: 4 bank tiles, L2-resident
-#else
-#define F2_ABL_BT(x) (x)
-#endif
-#if defined(F16_ABL) && (F16_ABL & 16)
-#define F2_RD(dst, src) asm volatile("" : "+v"(dst));     // timing only: no fragment reads
-#else
-#define F2_RD(dst, src) dst = src;
-#endif
-#if defined(F16_ABL) && (F16_ABL & 32)
-#define F2_DMA(src, dst)                                   // timing only: no bank copies
-#else
-#ifndef F2_CPOL
-#define F2_CPOL 0    /* cache policy of the bank copies (experiments: 2 = nt) */
-#endif
-#define F2_DMA(src, dst) __builtin_amdgcn_global_load_lds((gbl_cvoid*)(src), (lds_void*)(dst), 16, 0, F2_CPOL);
-#endif
-#if defined(F16_ABL) && (F16_ABL & 128)
-#define F2_BARRIER()                                       // timing only: no barrier
-#else
-#define F2_BARRIER() __builtin_amdgcn_s_barrier();
-#endif
-#if defined(F16_ABL) && (F16_ABL & 8)
-#define F2_ABL_Q(x) (reinterpret_cast<const char*>(a.q16) + (size_t)w * g16 * 1024)   // timing only: one query tile for all
-#else
-#define F2_ABL_Q(x) (x)
-#endif
 #define F2_SLOT 16384                                  // bank fragments of one k32 stage: [row tile 0..7][group 0..1][1 KiB]
 #define F2_BINIT (F2_RING * F2_SLOT)
 #define F2_SCRATCH (F2_BINIT + 2048)
 #define F2_PCNT (F2_SCRATCH + 8192)
 #define F2_CLWORDS (F2_PCNT + 1024)                    // landing zone of the cluster progress poll
-#define F2_TO4()
-#define F2_FROM4()
-#if defined(F2_MFMA16) && !(defined(F16_ABL) && (F16_ABL & 1))
-#error "F2_MFMA16 is a timing-only build of the stage loop: combine it with F16_ABL=1 (no epilogue)"
-#endif
 #define F2_LDS_TOTAL (F2_CLWORDS + 64)
 static_assert(F2_LDS_TOTAL <= 160 * 1024, "LDS budget");
+
+// one 1 KiB LDS-DMA piece: global (wave-uniform 64-bit base + 32-bit lane offset) -> LDS (wave-uniform address in M0 + 16 * lane)
+#define F2_DMA(SRC, LDS_ADDR, VOFF)                                                                                          \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(VOFF), "s"(SRC), "s"(LDS_ADDR) : "memory", "m0");
+// a query-fragment load into registers (untracked by the compiler: the hand-counted vmcnt below names the registers it releases)
+#define F2_BL(REG, SRC, OFF) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "+v"(REG) : "v"(lane_off), "s"(SRC) : "memory");
 
 template <int EMAX>   // pool capacity / 64 that the instantiation can compact (registers of the rare compaction path)
 __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) {
@@ -284,37 +267,29 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
     const int h = lane >> 5;
     float* sc = reinterpret_cast<float*>(smem + F2_SCRATCH) + w * 256;
     int* pcnt = reinterpret_cast<int*>(smem + F2_PCNT);
-    const int g16 = a.g16, k = a.k, klw = a.klw;
+    const int g16 = a.g16;
     const int NS = g16 / 2;   // k32 stages per bank tile, a multiple of 4 (dp16 is a multiple of 128)
     const int myq = w * 32 + (lane & 31);
     const unsigned lane_off = (unsigned)lane * 16u;
+    const unsigned lds_w = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)w * 2048u;   // this wave's two pieces of a ring slot
     cl_sync cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + F2_CLWORDS);
 
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_end[blockIdx.x];   // this launch's share of the block's segments (phases: hb_launch_knn)
-#ifdef F2_TL   // diagnostic build (make var NAME=tl EXTRA=-DF2_TL): time line of a launch's first segment (s_memtime: 100 MHz), one wave
-#define F2_TLS(I) { if (si == seg_begin && tl_n < 16) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl[tl_n]) :: "memory"); tl_id[tl_n++] = (I); __builtin_amdgcn_sched_barrier(0); } }
-    unsigned long long tl[16]; int tl_id[16], tl_n = 0;
-    { const int si = seg_begin; F2_TLS(0) }
-#else
-#define F2_TLS(I)
-#endif
     // "everything before my first segment is done" (a member without any work: everything)
     if (w == 0) cl_publish(cs, seg_begin < seg_end ? a.segs[seg_begin].tile0 * NS : 0x7FFFFFFF, lane);
     for (int si = seg_begin; si < seg_end; ++si) {
-        const hb_seg seg = a.segs[si];
-        const int bstride = seg.stride;
-        float* wl_s = a.state_s + (size_t)seg.slot * HB_QT * klw;
-        unsigned* wl_i = a.state_i + (size_t)seg.slot * HB_QT * klw;
-        const knn_args_pool_view pv{a.state_cnt, a.state_thr};
-        float thr = pool_begin(pv, seg.slot, seg.first, pcnt, myq, lane);
-        thr = fmaxf(thr, floor_load(a.gthr, seg.q_tile * HB_QT + myq));
-        F2_TLS(1)
+        const hb_seg seg = HB_KARG(knn16_args, segs)[si];
+        const int k = HB_KARG(knn16_args, k), klw = HB_KARG(knn16_args, klw);
+        float* wl_s = HB_KARG(knn16_args, state_s) + (size_t)seg.slot * HB_QT * klw;
+        unsigned* wl_i = HB_KARG(knn16_args, state_i) + (size_t)seg.slot * HB_QT * klw;
+        float thr;
+        {
+            const knn_args_pool_view pv{HB_KARG(knn16_args, state_cnt), HB_KARG(knn16_args, state_thr)};
+            thr = pool_begin(pv, seg.slot, seg.first, pcnt, myq, lane);
+            thr = fmaxf(thr, floor_load(HB_KARG(knn16_args, gthr), seg.q_tile * HB_QT + myq));
+        }
         const int total = seg.n_tiles * NS, clock0 = seg.tile0 * NS;
-#ifdef F2_MFMA16
-        f32x4 acc4[32];
-#else
         f32x16 acc[8];
-#endif
         f16x8 fa[8];        // bank fragments of the current group (one set)
         f16x8 bq[4][2];     // query fragments of four stages, two k16 groups each
 
@@ -322,134 +297,91 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
         // bank pieces C0, C1 (row tile w, both groups; LDS-DMA) -- all three during group 1 of the stage four earlier -- and
         // query fragment B1 (group 1) during group 0 of the stage three earlier (its register is free only then).  Wave 0
         // adds the row-init values behind the first stage of a tile.
-        // A wave stalls on the ISSUE of every such request behind the CU's other requests (measured on this kernel at
-        // 10 M x 768: the copies cost 46 ms and the query-fragment loads 48 ms of 349), and two SIMD partners stalled at the
-        // same point idle the matrix pipe.  So the requests are spread over the stage (one or two per group) and the two
-        // wave classes issue at different MFMA gaps: waves 0-3 behind MFMA 0 / 2 / 4 of a group, their partners 4-7 behind
-        // MFMA 1 / 3 / 5 (B1: 0 / 4) -- same order within a wave, so one hand-counted vmcnt serves both.
-        const char* bank_w = reinterpret_cast<const char*>(a.bank16) + (size_t)w * g16 * 1024;
-        const char* query_w = reinterpret_cast<const char*>(a.q16) + (size_t)(seg.q_tile * 8 + w) * g16 * 1024;
-        int fbt = seg.b_tile0, fks = 0, slot_f = 0, left = total, fpar = 0;
-        const char* qsrc_b1 = query_w;   // query fragments of the stage whose B1 is still to be requested
-#define F2_QSRC() (F2_ABL_Q(query_w) + (size_t)fks * 2048)
-        // a query-fragment load for ONE wave class (CLS 0: waves 0-3, 1: waves 4-7); the branch sits inside the statement, so
-        // the "+v" register is the same on both paths (an if / else around two statements made hipcc copy it early)
-#if defined(F16_ABL) && (F16_ABL & 64)
-#define F2_BL(REG, SRC, OFF, CLS) asm volatile("" : "+v"(REG) : "s"(SRC));   // timing only: no query fragment loads
-#define F2_BL_ALL(REG, SRC, OFF) asm volatile("" : "+v"(REG) : "s"(SRC));
-#else
-#ifndef F2_BPOL
-#define F2_BPOL ""   /* cache policy of the query-fragment loads (experiments: " nt", " sc1") */
-#endif
-#define F2_BL(REG, SRC, OFF, CLS)                                                                                            \
-        asm volatile("s_cmp_lt_u32 %3, 4\n\ts_cbranch_scc" #CLS " .Lf2s_%=\n\tglobal_load_dwordx4 %0, %1, %2 offset:" #OFF F2_BPOL "\n.Lf2s_%=:" \
-                     : "+v"(REG) : "v"(lane_off), "s"(SRC), "s"(w) : "memory", "scc");
-#define F2_BL_ALL(REG, SRC, OFF) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF F2_BPOL : "=v"(REG) : "v"(lane_off), "s"(SRC) : "memory");
-#endif
-#define F2_COPY(I)   /* bank piece I of this wave: row tile w, group I */                                                    \
-        {                                                                                                                    \
-            const char* bsrc = bank_w + ((size_t)F2_ABL_BT(fbt) * 8 * g16 + (size_t)fks * 2 + (I)) * 1024 + lane_off;       \
-            F2_DMA(bsrc, smem + slot_f * F2_SLOT + (w * 2 + (I)) * 1024)                                                     \
-        }
+        // The fetch position, all wave-uniform: qf / bf / bi point at the NEXT stage to request (this wave's query fragments
+        // [g16][1 KiB]; row tile w of the bank tile: [g16][1 KiB], the next row tile behind it; the tile's row-init values),
+        // qf1 at the stage whose B1 is still to be requested.  A stage advances qf and bf by 2 KiB; at a tile's end qf returns
+        // to the wave's first fragment and bf jumps from the end of row tile w to row tile w of the next tile of the segment.
+        const char* const qbase = reinterpret_cast<const char*>(a.q16) + (size_t)(seg.q_tile * 8 + w) * g16 * 1024;
+        const char* qf = qbase;
+        const char* qf1 = qbase;
+        const char* bf = reinterpret_cast<const char*>(a.bank16) + ((size_t)seg.b_tile0 * 8 + w) * g16 * 1024;
+        const float* bi = a.binit + (size_t)seg.b_tile0 * HB_BT;
+        const long long b_wrap = ((long long)seg.stride * 8 - 1) * g16 * 1024;
+        const int bi_step = seg.stride * HB_BT;
+        int fks = 0, left = total;
+        unsigned slot_f = 0, fpar = 0;        // ring slot being filled (byte offset), parity of the row-init buffer being filled
+#define F2_REQ_B0(U) F2_BL(bq[U][0], qf, 0)
+#define F2_REQ_B1(U) F2_BL(bq[U][1], qf1, 1024)
+#define F2_REQ_C(I) F2_DMA(bf, lds_w + slot_f + (I) * 1024u, lane_off + (I) * 1024u)
 #define F2_ADVANCE()                                                                                                         \
         {                                                                                                                    \
-            if (fks == 0 && w == 0) glds16(a.binit + (size_t)fbt * HB_BT + lane * 4, smem + F2_BINIT + fpar * 1024);        \
-            qsrc_b1 = F2_QSRC();                                                                                             \
-            if (--left > 0) { if (++fks == NS) { fks = 0; fbt += bstride; fpar ^= 1; } }                                     \
-            slot_f = (slot_f + 1) & (F2_RING - 1);                                                                           \
+            if (fks == 0 && w == 0) glds16(bi + lane * 4, smem + F2_BINIT + fpar);                                           \
+            qf1 = qf;                                                                                                        \
+            if (--left > 0) {                                                                                                \
+                qf += 2048; bf += 2048;                                                                                      \
+                if (++fks == NS) { fks = 0; qf = qbase; bf += b_wrap; bi += bi_step; fpar ^= 1024u; }                        \
+            }                                                                                                                \
+            slot_f = (slot_f + F2_SLOT) & (F2_RING * F2_SLOT - 1);                                                           \
         }
         // vmcnt by hand.  Order of a wave's requests: ... B1(s+3) | B0(s+4) C0 C1 | B1(s+4) | B0(s+5) ... (wave 0: now and
         // then one more, which only makes a wait stricter).  At the barrier in the middle of stage s everything of stage
         // s + 1 must have landed; its youngest request is B1(s+1), behind it come B0 C0 C1 (s+2), B1(s+2), B0 C0 C1 (s+3) and
         // B1(s+3) -> "all but the newest 8".  Past the last stage the fetch position stays put (same requests again, results
         // unused), so the count never changes.
-        F2_BL_ALL(bq[0][0], F2_QSRC(), 0) F2_COPY(0) F2_COPY(1) F2_ADVANCE() F2_BL_ALL(bq[0][1], qsrc_b1, 1024)
-        F2_BL_ALL(bq[1][0], F2_QSRC(), 0) F2_COPY(0) F2_COPY(1) F2_ADVANCE() F2_BL_ALL(bq[1][1], qsrc_b1, 1024)
-        F2_BL_ALL(bq[2][0], F2_QSRC(), 0) F2_COPY(0) F2_COPY(1) F2_ADVANCE() F2_BL_ALL(bq[2][1], qsrc_b1, 1024)
-        F2_BL_ALL(bq[3][0], F2_QSRC(), 0) F2_COPY(0) F2_COPY(1) F2_ADVANCE()
+        F2_REQ_B0(0) F2_REQ_C(0) F2_REQ_C(1) F2_ADVANCE() F2_REQ_B1(0)
+        F2_REQ_B0(1) F2_REQ_C(0) F2_REQ_C(1) F2_ADVANCE() F2_REQ_B1(1)
+        F2_REQ_B0(2) F2_REQ_C(0) F2_REQ_C(1) F2_ADVANCE() F2_REQ_B1(2)
+        F2_REQ_B0(3) F2_REQ_C(0) F2_REQ_C(1) F2_ADVANCE()
         // stage 0 (and B1 of it) has landed: eleven younger requests
         asm volatile("s_waitcnt vmcnt(11)" : "+v"(bq[0][0]), "+v"(bq[0][1]) :: "memory");
         __syncthreads();
-        F2_TLS(2)
-        int slot_c = 0, ks = 0, bt = seg.b_tile0, cpar = 0;
+        unsigned slot_c = 0;                  // ring slot being computed (byte offset)
+        int ks = 0, bt = seg.b_tile0, cpar = 0;
         bool bulk = seg.tile0 < 16;   // loose floors at the start of a search: the epilogue's quarter loop right away (pool_epilogue_scan)
-#if defined(F16_ABL) && (F16_ABL & 256)
-#define F2_INIT_TILE() { _Pragma("unroll") for (int t = 0; t < 8; ++t) asm volatile("" : "+v"(acc[t])); }   // timing only: no init
-#else
-#ifdef F2_MFMA16
 #define F2_INIT_TILE()                                                                                                       \
         {                                                                                                                    \
-            const f32x4* bi = reinterpret_cast<const f32x4*>(smem + F2_BINIT + cpar * 1024);                                 \
-            _Pragma("unroll") for (int t = 0; t < 16; ++t) { acc4[2 * t] = bi[4 * t + (lane >> 4)]; acc4[2 * t + 1] = acc4[2 * t]; } \
-        }
-#else
-#define F2_INIT_TILE()                                                                                                       \
-        {                                                                                                                    \
-            const f32x4* bi = reinterpret_cast<const f32x4*>(smem + F2_BINIT + cpar * 1024);                                 \
+            const f32x4* bi_ = reinterpret_cast<const f32x4*>(smem + F2_BINIT + cpar * 1024);                                \
             _Pragma("unroll") for (int t = 0; t < 8; ++t)                                                                    \
                 _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                              \
-                    const f32x4 v = bi[8 * t + 2 * g + h];                                                                   \
+                    const f32x4 v = bi_[8 * t + 2 * g + h];                                                                  \
                     acc[t][4 * g + 0] = v[0]; acc[t][4 * g + 1] = v[1]; acc[t][4 * g + 2] = v[2]; acc[t][4 * g + 3] = v[3]; \
                 }                                                                                                            \
         }
-#endif
-#endif
         {
             const f16x8* A = reinterpret_cast<const f16x8*>(smem) + lane;
 #pragma unroll
             for (int t = 0; t < 8; ++t) fa[t] = A[(t * 2) * 64];
         }
         F2_INIT_TILE()
-        F2_TO4()
-#ifdef F2_STAMPS   // diagnostic build (make var NAME=stamps EXTRA=-DF2_STAMPS): where a tile boundary spends its cycles; never timed
-#define F2_STAMP(T) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
-        unsigned long long ts_a = 0, ts_m = 0, ts_b = 0, ts_c = 0, ts_s = 0, ts_e = 0;
-        unsigned long long sum_scan = 0, sum_drain = 0, sum_init = 0, sum_bar_first = 0, sum_bar_other = 0, sum_all = 0;
-        int n_first = 0, n_other = 0, after_epi = 0;
-        unsigned long long ts_begin; F2_STAMP(ts_begin)
-#define F2_STAMP_STAGE_BEGIN(U) if ((U) == 0) F2_STAMP(ts_s)
-#define F2_STAMP_STAGE_BARRIER(U) if ((U) == 0) { F2_STAMP(ts_e) if (after_epi) { sum_bar_first += ts_e - ts_s; ++n_first; after_epi = 0; } else { sum_bar_other += ts_e - ts_s; ++n_other; } }
-#else
-#define F2_STAMP_STAGE_BEGIN(U)
-#define F2_STAMP_STAGE_BARRIER(U)
-#endif
-#ifdef F2_MFMA16   /* timing only (results are garbage): the same FLOPs issued as two v_mfma_f32_16x16x32_f16 per 32x32x16 */
-#define F2_MM(T, B, G)                                                                                                       \
-        acc4[4 * (T) + 2 * (G)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[T], B, acc4[4 * (T) + 2 * (G)], 0, 0, 0);       \
-        acc4[4 * (T) + 2 * (G) + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[T], B, acc4[4 * (T) + 2 * (G) + 1], 0, 0, 0);
-#else
-#define F2_MM(T, B, G) acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[T], B, acc[T], 0, 0, 0);
-#endif
+#define F2_MM(T, B) acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[T], B, acc[T], 0, 0, 0);
 #define F2_STAGE(U)                                                                                                          \
         {                                                                                                                    \
-            const f16x8* Ac = reinterpret_cast<const f16x8*>(smem + slot_c * F2_SLOT) + lane;                                \
-            const int slot_n = (slot_c + 1) & (F2_RING - 1);                                                                 \
-            const f16x8* An = reinterpret_cast<const f16x8*>(smem + slot_n * F2_SLOT) + lane;                                \
-            F2_STAMP_STAGE_BEGIN(U)                                                                                          \
+            const f16x8* Ac = reinterpret_cast<const f16x8*>(smem + slot_c) + lane;                                          \
+            const unsigned slot_n = (slot_c + F2_SLOT) & (F2_RING * F2_SLOT - 1);                                            \
+            const f16x8* An = reinterpret_cast<const f16x8*>(smem + slot_n) + lane;                                          \
             /* group 0; filler after MFMA t: fragment t of group 1; B1 of the stage three ahead */                           \
-            KN_FENCE F2_MM(0, bq[U][0], 0) KN_FENCE F2_RD(fa[0], Ac[(0 * 2 + 1) * 64]) F2_BL(bq[(U + 3) & 3][1], qsrc_b1, 1024, 0)  \
-            KN_FENCE F2_MM(1, bq[U][0], 0) KN_FENCE F2_RD(fa[1], Ac[(1 * 2 + 1) * 64])                                          \
-            KN_FENCE F2_MM(2, bq[U][0], 0) KN_FENCE F2_RD(fa[2], Ac[(2 * 2 + 1) * 64])                                          \
-            KN_FENCE F2_MM(3, bq[U][0], 0) KN_FENCE F2_RD(fa[3], Ac[(3 * 2 + 1) * 64])                                          \
-            KN_FENCE F2_MM(4, bq[U][0], 0) KN_FENCE F2_RD(fa[4], Ac[(4 * 2 + 1) * 64]) F2_BL(bq[(U + 3) & 3][1], qsrc_b1, 1024, 1)  \
-            KN_FENCE F2_MM(5, bq[U][0], 0) KN_FENCE F2_RD(fa[5], Ac[(5 * 2 + 1) * 64])                                          \
-            KN_FENCE F2_MM(6, bq[U][0], 0) KN_FENCE F2_RD(fa[6], Ac[(6 * 2 + 1) * 64])                                          \
-            KN_FENCE F2_MM(7, bq[U][0], 0) KN_FENCE F2_RD(fa[7], Ac[(7 * 2 + 1) * 64])                                          \
+            KN_FENCE F2_MM(0, bq[U][0]) KN_FENCE fa[0] = Ac[(0 * 2 + 1) * 64]; F2_REQ_B1((U + 3) & 3)                           \
+            KN_FENCE F2_MM(1, bq[U][0]) KN_FENCE fa[1] = Ac[(1 * 2 + 1) * 64];                                                  \
+            KN_FENCE F2_MM(2, bq[U][0]) KN_FENCE fa[2] = Ac[(2 * 2 + 1) * 64];                                                  \
+            KN_FENCE F2_MM(3, bq[U][0]) KN_FENCE fa[3] = Ac[(3 * 2 + 1) * 64];                                                  \
+            KN_FENCE F2_MM(4, bq[U][0]) KN_FENCE fa[4] = Ac[(4 * 2 + 1) * 64];                                                  \
+            KN_FENCE F2_MM(5, bq[U][0]) KN_FENCE fa[5] = Ac[(5 * 2 + 1) * 64];                                                  \
+            KN_FENCE F2_MM(6, bq[U][0]) KN_FENCE fa[6] = Ac[(6 * 2 + 1) * 64];                                                  \
+            KN_FENCE F2_MM(7, bq[U][0]) KN_FENCE fa[7] = Ac[(7 * 2 + 1) * 64];                                                  \
             KN_FENCE                                                                                                         \
             /* the next stage has landed: my requests (and my query fragments of it), then everyone's */                    \
             asm volatile("s_waitcnt vmcnt(8)" : "+v"(bq[(U + 1) & 3][0]), "+v"(bq[(U + 1) & 3][1]), "+v"(bq[U][1]) :: "memory"); \
-            F2_BARRIER()   /* raw s_barrier: __syncthreads() would drain the LDS-DMA copies (vmcnt(0)) */                    \
-            F2_STAMP_STAGE_BARRIER(U)                                                                                        \
+            __builtin_amdgcn_s_barrier();   /* raw s_barrier: __syncthreads() would drain the LDS-DMA copies (vmcnt(0)) */   \
             /* group 1; filler after MFMA t: fragment t of the next stage's group 0; B0 C0 C1 of the stage four ahead */     \
-            if (w == 0) cl_tick(cs, clock0 + st + (U), lane);   /* cluster soft sync, ahead of the stage's requests */       \
-            KN_FENCE F2_MM(0, bq[U][1], 1) KN_FENCE F2_RD(fa[0], An[(0 * 2) * 64]) F2_BL(bq[U][0], F2_QSRC(), 0, 0)             \
-            KN_FENCE F2_MM(1, bq[U][1], 1) KN_FENCE F2_RD(fa[1], An[(1 * 2) * 64]) F2_BL(bq[U][0], F2_QSRC(), 0, 1)             \
-            KN_FENCE F2_MM(2, bq[U][1], 1) KN_FENCE F2_RD(fa[2], An[(2 * 2) * 64]) if (w < 4) F2_COPY(0)                        \
-            KN_FENCE F2_MM(3, bq[U][1], 1) KN_FENCE F2_RD(fa[3], An[(3 * 2) * 64]) if (w >= 4) F2_COPY(0)                       \
-            KN_FENCE F2_MM(4, bq[U][1], 1) KN_FENCE F2_RD(fa[4], An[(4 * 2) * 64]) if (w < 4) F2_COPY(1)                        \
-            KN_FENCE F2_MM(5, bq[U][1], 1) KN_FENCE F2_RD(fa[5], An[(5 * 2) * 64]) if (w >= 4) F2_COPY(1)                       \
-            KN_FENCE F2_MM(6, bq[U][1], 1) KN_FENCE F2_RD(fa[6], An[(6 * 2) * 64])                                              \
-            KN_FENCE F2_MM(7, bq[U][1], 1) KN_FENCE F2_RD(fa[7], An[(7 * 2) * 64])                                              \
+            if ((U) == 0 && w == 0) cl_tick(cs, clock0 + st, lane);   /* cluster soft sync, ahead of the stage's requests; acts when the clock is a multiple of 4: st is, clock0 is (NS is) */ \
+            KN_FENCE F2_MM(0, bq[U][1]) KN_FENCE fa[0] = An[(0 * 2) * 64]; F2_REQ_B0(U)                                         \
+            KN_FENCE F2_MM(1, bq[U][1]) KN_FENCE fa[1] = An[(1 * 2) * 64];                                                      \
+            KN_FENCE F2_MM(2, bq[U][1]) KN_FENCE fa[2] = An[(2 * 2) * 64]; F2_REQ_C(0)                                          \
+            KN_FENCE F2_MM(3, bq[U][1]) KN_FENCE fa[3] = An[(3 * 2) * 64];                                                      \
+            KN_FENCE F2_MM(4, bq[U][1]) KN_FENCE fa[4] = An[(4 * 2) * 64]; F2_REQ_C(1)                                          \
+            KN_FENCE F2_MM(5, bq[U][1]) KN_FENCE fa[5] = An[(5 * 2) * 64];                                                      \
+            KN_FENCE F2_MM(6, bq[U][1]) KN_FENCE fa[6] = An[(6 * 2) * 64];                                                      \
+            KN_FENCE F2_MM(7, bq[U][1]) KN_FENCE fa[7] = An[(7 * 2) * 64];                                                      \
             KN_FENCE                                                                                                         \
             F2_ADVANCE()                                                                                                     \
             KN_FENCE                                                                                                         \
@@ -459,82 +391,40 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
             F2_STAGE(0) F2_STAGE(1) F2_STAGE(2) F2_STAGE(3)
             ks += 4;
             if (ks == NS) {
-                F2_FROM4()
-#if defined(F2_MFMA16)
-#pragma unroll
-                for (int t = 0; t < 32; ++t) asm volatile("" :: "v"(acc4[t]));   // timing only: no epilogue
-#elif defined(F16_ABL) && (F16_ABL & 1)
-#pragma unroll
-                for (int t = 0; t < 8; ++t) asm volatile("" :: "v"(acc[t]));   // timing only: no epilogue
-#elif defined(F2_STAMPS)
-                if (seg.first && bt == seg.b_tile0) thr = fmaxf(thr, cold_start_threshold(acc, k));
-                F2_STAMP(ts_a)
-                pool_epilogue_scan<EMAX>(acc, thr, wl_s, wl_i, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt, bulk, &ts_m);
-                F2_STAMP(ts_b)
-                sum_scan += ts_m - ts_a; sum_drain += ts_b - ts_m; after_epi = 1;
-#else
-                // a slot's first tile: filter below the k'-th largest of its 256 scores (radix select over the accumulators)
+                // a slot's first tile: filter below the k'-th largest of its 256 scores (bisection over the accumulators)
                 // instead of appending all 256 rows of every query through the overflow path
-                F2_TLS(3)
                 if (seg.first && bt == seg.b_tile0) thr = fmaxf(thr, cold_start_threshold(acc, k));
-                F2_TLS(4)
                 pool_epilogue_scan<EMAX>(acc, thr, wl_s, wl_i, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt, bulk);
-                F2_TLS(5)
-#endif
-                ks = 0; bt += bstride; cpar ^= 1;
+                ks = 0; bt += seg.stride; cpar ^= 1;
                 F2_INIT_TILE()
                 {   // the next tile's first fragments again (rather than kept live across the epilogue: fewer registers)
-                    const f16x8* A = reinterpret_cast<const f16x8*>(smem + slot_c * F2_SLOT) + lane;
+                    const f16x8* A = reinterpret_cast<const f16x8*>(smem + slot_c) + lane;
 #pragma unroll
                     for (int t = 0; t < 8; ++t) fa[t] = A[(t * 2) * 64];
                 }
-                F2_TO4()
-#ifdef F2_STAMPS
-                F2_STAMP(ts_c)
-                sum_init += ts_c - ts_b;
-#endif
             }
         }
         // the run-ahead requests still target the query-fragment registers: drain them while those registers are live
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]), "+v"(bq[2][0]), "+v"(bq[2][1]),
                      "+v"(bq[3][0]), "+v"(bq[3][1]) :: "memory");
-#ifdef F2_STAMPS
-        { unsigned long long ts_end; F2_STAMP(ts_end) sum_all = ts_end - ts_begin; }
-        if ((blockIdx.x == 0 || blockIdx.x == 101) && lane == 0 && (w == 0 || w == 5) && (si - seg_begin) % 64 == 17)
-            printf("STAMPS wg %d wave %d tiles %d: segment %llu cycles; per tile: scan %llu drain %llu init+refetch %llu; stage begin -> barrier passed: "
-                   "after an epilogue %llu (n %d), otherwise %llu (n %d)\n", (int)blockIdx.x, w, seg.n_tiles, sum_all, sum_scan / seg.n_tiles,
-                   sum_drain / seg.n_tiles, sum_init / seg.n_tiles, n_first ? sum_bar_first / n_first : 0ull, n_first,
-                   n_other ? sum_bar_other / n_other : 0ull, n_other);
-#undef F2_STAMP
-#endif
-#undef F2_STAMP_STAGE_BEGIN
-#undef F2_STAMP_STAGE_BARRIER
 #undef F2_STAGE
 #undef F2_MM
 #undef F2_INIT_TILE
 #undef F2_ADVANCE
-#undef F2_COPY
-#undef F2_BL
-#undef F2_BL_ALL
-#undef F2_QSRC
+#undef F2_REQ_B0
+#undef F2_REQ_B1
+#undef F2_REQ_C
         if (w == 0) cl_publish(cs, seg.next_tile0 == 0x7FFFFFFF ? 0x7FFFFFFF : seg.next_tile0 * NS, lane);   // covers idle units
-        F2_TLS(6)
-        pool_end(pv, seg.slot, pcnt, thr, myq, lane);
-        if (lane < 32) floor_publish(a.gthr, seg.q_tile * HB_QT + myq, thr);
+        {
+            const knn_args_pool_view pv{HB_KARG(knn16_args, state_cnt), HB_KARG(knn16_args, state_thr)};
+            pool_end(pv, seg.slot, pcnt, thr, myq, lane);
+        }
+        if (lane < 32) floor_publish(HB_KARG(knn16_args, gthr), seg.q_tile * HB_QT + myq, thr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        F2_TLS(7)
-#ifdef F2_TL
-        if (si == seg_begin && blockIdx.x == 7 && (tid == 0 || tid == 320)) {
-            printf("TL wave %d seg tiles %d first %d clock %d:", w, seg.n_tiles, seg.first, seg.tile0);
-            for (int i = 1; i < tl_n; ++i) printf(" [%d] +%llu", tl_id[i], (tl[i] - tl[i - 1]) / 100);
-            printf(" us\n");
-        }
-#endif
     }
     cl_finish(cs, a.cl_stats, w == 0, lane);
 }
-#undef F2_TLS
 
 // Exact re-rank: one wave per query; lane j scores candidates j, j+64, ... with the fp32 chain arithmetic of the fp32
 // kernel (acc = row init; acc = fmaf(q_k, b_k, acc) for k ascending over the fp32 fragment tiles), then the wave

@@ -71,7 +71,9 @@ SIGNATURES = {
     "hb_schedule_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, POINTER(c_int64)]),
     "hb_schedule_plan_phased": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, POINTER(c_int64),
                                         c_void_p, c_int, POINTER(c_int), c_void_p]),
+    "hb_schedule_plan_shared": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, POINTER(c_int64)]),
     "hb_index_set_cluster": (c_int, [c_void_p, c_int, c_int, c_int]),
+    "hb_index_set_cluster_sharing": (c_int, [c_void_p, c_int]),
     "hb_index_cluster_stats": (c_int, [c_void_p, POINTER(c_int64)]),
     "hb_index_set_variant": (c_int, [c_void_p, c_int]),
     "hb_index_schedule_info": (c_int, [c_void_p, POINTER(c_int64)]),

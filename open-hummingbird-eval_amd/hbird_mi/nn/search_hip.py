@@ -250,6 +250,10 @@ class HipFlatIndex:
         """L2-sharing clusters of the work list (speed only, opt-in): 0 x 0 / 1 x 1 off, e.g. 2 x 2; sync_lag in stages."""
         _lib.check(_lib.lib().hb_index_set_cluster(self._h, int(cluster_q), int(cluster_b), int(sync_lag)))
 
+    def set_cluster_sharing(self, mode: int = 0):
+        """How a clustered work list is dealt (speed only): 0 automatic, 1 per-cluster ranges, 2 XCD-level query-tile sharing."""
+        _lib.check(_lib.lib().hb_index_set_cluster_sharing(self._h, int(mode)))
+
     def cluster_stats(self) -> dict:
         out = (ctypes.c_int64 * 4)()
         _lib.check(_lib.lib().hb_index_cluster_stats(self._h, out))

@@ -139,6 +139,90 @@ def test_clustered_work_list_invariants(nqt, nbt, G, panel, cq, cb):
             assert busy.max() - busy.min() <= 2 * npanels + 1
 
 
+def plan_shared(nqt, nbt, G, panel, cluster, d=768, phased=False):
+    """plan() for the work list of hb_index_set_cluster_sharing(ix, 2): every run of a query group split over all clusters of an XCD."""
+    stats = (ctypes.c_int64 * 8)()
+    L = _lib.lib()
+    _lib.check(L.hb_schedule_plan_shared(nqt, nbt, G, panel, d, cluster[0], cluster[1], int(phased), None, 0, stats))
+    buf = np.zeros((stats[1], 10), dtype=np.int32)
+    _lib.check(L.hb_schedule_plan_shared(nqt, nbt, G, panel, d, cluster[0], cluster[1], int(phased), buf.ctypes.data_as(ctypes.c_void_p), stats[1], stats))
+    return buf, dict(workgroups=stats[0], slots=stats[2], panel_tiles=stats[3], max_slots_per_qtile=stats[4],
+                     cluster=(int(stats[7]) // 16, int(stats[7]) % 16))
+
+
+@pytest.mark.parametrize("nqt,nbt,G,panel,cq,cb,phased", [
+    (86, 39063, 256, 0, 4, 1, True), (86, 4883, 256, 256, 4, 2, True), (86, 4883, 256, 0, 8, 1, False),
+    (86, 4883, 256, 0, 2, 1, False), (49, 8102, 256, 0, 4, 1, True), (7, 1001, 64, 0, 2, 2, False), (5, 333, 32, 7, 2, 2, True),
+    (86, 300, 256, 33, 2, 2, False), (3, 4, 256, 0, 2, 2, False),
+])
+def test_xcd_shared_work_list_invariants(nqt, nbt, G, panel, cq, cb, phased):
+    """XCD-level sharing of the query tiles: the correctness invariants of any work list (every pair once; a slot = one block, one
+    query tile, ascending bank tiles; clocks never run backwards; members of a cluster on one XCD and on one unit per tick), plus
+    what the dealing is for: inside a panel every cluster of an XCD works on the SAME query groups, in the same order."""
+    segs, st = plan_shared(nqt, nbt, G, panel, (cq, cb), phased=phased)
+    a, b = st["cluster"]
+    if G % (8 * cq * cb) != 0 or nqt * nbt < G:
+        assert (a, b) == (1, 1)
+        return
+    assert (a, b) == (cq, cb)
+    g = st["workgroups"]
+    cover = np.zeros((nqt, nbt), dtype=np.int32)
+    slot_q, slot_blk, slot_last, started = {}, {}, {}, set()
+    per_block = np.zeros(g, dtype=np.int64)
+    blk_clock = {}
+    at = {}
+    qg_seq = {}                   # (cluster, panel) -> query groups in the order the cluster meets them
+    P = st["panel_tiles"]
+    for blk, q, b0, n, slot, first, stride, tile0, next_tile0, member in segs.tolist():
+        assert stride == b and n > 0
+        tiles = b0 + stride * np.arange(n)
+        assert 0 <= q < nqt and tiles[0] >= 0 and tiles[-1] < nbt
+        cover[q, tiles] += 1
+        per_block[blk] += n
+        if first:
+            assert slot not in started
+            started.add(slot); slot_q[slot] = q; slot_blk[slot] = blk
+        assert slot in started and slot_q[slot] == q and slot_blk[slot] == blk
+        assert b0 > slot_last.get(slot, -1), "bank tiles of a slot must ascend"
+        slot_last[slot] = int(tiles[-1])
+        assert tile0 >= blk_clock.get(blk, 0)
+        blk_clock[blk] = tile0 + n
+        assert next_tile0 >= tile0 + n
+        cl, m = member // 32, member % 32
+        per_xcd = g // (a * b) // 8
+        assert 0 <= m < a * b and blk % 8 == cl // per_xcd
+        if m == 0:
+            seq = qg_seq.setdefault((cl, b0 // P), [])
+            if not seq or seq[-1] != q // a:
+                seq.append(q // a)
+        if nqt * nbt <= 600_000 or cl % 16 == 3:
+            for j in range(n):
+                at.setdefault((cl, tile0 + j), []).append((m, q, int(tiles[j])))
+    assert (cover == 1).all(), "every (query tile, bank tile) pair exactly once"
+    assert len(started) == st["slots"]
+    for (cl, t), mem in at.items():
+        assert len({m for m, _, _ in mem}) == len(mem) <= a * b
+        assert len({(bt // P, (bt % P) // b) for _, _, bt in mem}) == 1
+        for m, q, bt in mem:
+            for m2, q2, bt2 in mem:
+                if m % b == m2 % b:
+                    assert bt == bt2
+                if m // b == m2 // b:
+                    assert q == q2
+    # the point of the dealing: the clusters of an XCD meet the same query groups of a panel in the same order (a cluster may miss
+    # a group whose run is shorter than the number of clusters)
+    per_xcd = g // (a * b) // 8
+    for (cl, pn), seq in qg_seq.items():
+        assert seq == sorted(set(seq))
+        union = sorted({qq for (c2, p2), s2 in qg_seq.items() if p2 == pn and c2 // per_xcd == cl // per_xcd for qq in s2})
+        assert len(union) <= -(-((nqt + a - 1) // a) // 8) + 1, "an XCD's share of a panel spans few query groups"
+        assert set(seq) <= set(union)
+    busy = per_block[per_block > 0]
+    npanels = -(-nbt // P)
+    assert busy.max() - np.median(busy) <= max(3 * npanels, 0.02 * np.median(busy)) + 2, (busy.max(), np.median(busy))
+    assert st["max_slots_per_qtile"] <= 24 * 24
+
+
 def plan_phased(nqt, nbt, G, panel, d=384, cluster=(1, 1)):
     """-> (rows as plan(), stats, cut clocks, bounds [cut][block] relative to the block's first segment)."""
     L = _lib.lib()

@@ -24,6 +24,9 @@ for r in range(rounds + 1):
         ix.set_fp16(mode == "f16")
         for c in cfgs:
             ix.set_cluster(c[0], c[1], c[2])
+            ix.set_cluster_sharing(c[3] if len(c) > 3 else 0)       # optional fields: sharing mode, panel tiles, kernel variant
+            ix.set_tuning(0, c[4] if len(c) > 4 else 0)
+            ix.set_variant(c[5] if len(c) > 5 else 0)
             ix.set_timing(True)
             idx, dist = ix.search(q, k)
             ms = ix.last_knn_ms()
@@ -37,5 +40,5 @@ for r in range(rounds + 1):
             else:
                 res[key]["ms"].append(round(ms, 2)); res[key]["sync"] = st
 for key, v in res.items():
-    print(key, "same_bits", v["same_bits"], "ms", v["ms"], "slots", v["schedule"]["slots"], "cluster", v["schedule"]["cluster"], v.get("sync"), flush=True)
+    print(key, "same_bits", v["same_bits"], "ms", v["ms"], "slots", v["schedule"]["slots"], "panel", v["schedule"].get("panel_tiles"), "cluster", v["schedule"]["cluster"], v.get("sync"), flush=True)
 json.dump({str(k_): v for k_, v in res.items()}, open(os.path.join(ROOT, "gpurun_out", os.environ.get("EXP_OUT", "exp_cluster.json")), "w"), indent=1)

@@ -13,5 +13,8 @@ g = torch.Generator(device=dev); g.manual_seed(7)
 q = 3.0 * torch.randn((21904, 768), generator=g, device=dev)
 ix.set_fp16(bool(fp16))
 for c in cfgs:
-    ix.set_cluster(*c)
+    ix.set_cluster(*c[:3])
+    ix.set_cluster_sharing(c[3] if len(c) > 3 else 0)
+    ix.set_tuning(0, c[4] if len(c) > 4 else 0)
+    ix.set_variant(c[5] if len(c) > 5 else 0)
     ix.search(q, 30); torch.cuda.synchronize()
