@@ -911,7 +911,11 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // phased searches (pools only: "Phased searches" above hb_launch_knn); HBIRD_PHASES=0 turns them off (A/B)
     static const bool phases_on = !(getenv("HBIRD_PHASES") && atoi(getenv("HBIRD_PHASES")) == 0);
     const bool phased = wide && phases_on && ix->variant != 1;
-    const bool xs = cq * cb > 1 && ix->xcd_share == 2;
+    // XCD-level sharing of the query tiles (hb_build_clustered): automatic for the fp16 candidate kernel -- same box, 10 M x 768, 8 x 1
+    // clusters: 302.7 -> 291.5 ms and 0.97 -> 0.52 TB of L2-miss traffic per search (L2 hit rate 0.60 -> 0.78); the fp32 kernel's 2 x 4
+    // clusters lose 1.6 % with it (2298 -> 2334 ms: 1600 slots instead of 592, and its 768 KiB query tiles do not stay in L2 beside
+    // sixteen bank streams anyway: 1.95 -> 1.62 TB) -> off there (profiles/r04/xs_*.txt)
+    const bool xs = cq * cb > 1 && (ix->xcd_share == 2 || (ix->xcd_share == 0 && f16));
     const bool rebuilt = !(sc.nqt == nqt && sc.nbt == nbt && sc.panel == panel && sc.cq == cq && sc.cb == cb && sc.phased == phased &&
                            sc.xcd_share == xs && (sc.G == G || (long long)nqt * nbt < G));
     if (rebuilt) hb_build_schedule(nqt, nbt, G, panel, sc, cq, cb, phased, xs);

@@ -416,14 +416,24 @@ __device__ __forceinline__ int tile_epilogue(f32x16 (&acc)[8], float& thr, float
             HB_SCAN_REG(T, 4 * (Q)) HB_SCAN_REG(T, 4 * (Q) + 1) HB_SCAN_REG(T, 4 * (Q) + 2) HB_SCAN_REG(T, 4 * (Q) + 3) \
         }                                                                                                    \
     }
-#ifndef HB_SCAN_FLAT
-#define HB_SCAN_TILE(T) HB_SCAN_QUAD(T, 0) HB_SCAN_QUAD(T, 1) HB_SCAN_QUAD(T, 2) HB_SCAN_QUAD(T, 3)
-#else   /* experiments: every register tested on its own */
+// ... and the 16 registers of a row tile (32 bank rows x 32 queries) share one test in front of that: with phased floors a wave's
+// 256 x 32 tile has well under one survivor on average (k' ln(N / n0) candidates per query over the whole search), so nearly every
+// row tile is dismissed by 8 max instructions + 1 compare instead of its four quads' 4 x (4 + 1 + 1).  v_max3_f32 from inline asm:
+// fmaxf() makes hipcc quiet a possible signalling NaN first (a v_max_f32 x, x per operand); MFMA results are never signalling,
+// a quiet NaN loses every maximum (IEEE maxNum) and the final `>` is false for it either way.
+__device__ __forceinline__ float hb_max3(float a, float b, float c) {
+    float m;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+    return m;
+}
 #define HB_SCAN_TILE(T)                                                                                      \
-    HB_SCAN_REG(T, 0) HB_SCAN_REG(T, 1) HB_SCAN_REG(T, 2) HB_SCAN_REG(T, 3) HB_SCAN_REG(T, 4) HB_SCAN_REG(T, 5) \
-    HB_SCAN_REG(T, 6) HB_SCAN_REG(T, 7) HB_SCAN_REG(T, 8) HB_SCAN_REG(T, 9) HB_SCAN_REG(T, 10) HB_SCAN_REG(T, 11) \
-    HB_SCAN_REG(T, 12) HB_SCAN_REG(T, 13) HB_SCAN_REG(T, 14) HB_SCAN_REG(T, 15)
-#endif
+    {                                                                                                        \
+        const float a_ = hb_max3(acc[T][0], acc[T][1], acc[T][2]), b_ = hb_max3(acc[T][3], acc[T][4], acc[T][5]);      \
+        const float c_ = hb_max3(acc[T][6], acc[T][7], acc[T][8]), d_ = hb_max3(acc[T][9], acc[T][10], acc[T][11]);    \
+        const float e_ = hb_max3(acc[T][12], acc[T][13], acc[T][14]);                                          \
+        const float t_ = hb_max3(hb_max3(a_, b_, c_), hb_max3(d_, e_, acc[T][15]), -INFINITY);                  \
+        if (__builtin_expect(__ballot(t_ > thr) != 0ull, 0)) { HB_SCAN_QUAD(T, 0) HB_SCAN_QUAD(T, 1) HB_SCAN_QUAD(T, 2) HB_SCAN_QUAD(T, 3) } \
+    }
 
 // `bulk` (wave-uniform, kept by the caller across the tiles of a segment): the tile goes straight to tile_epilogue's quarter loop.
 // A slot's first tiles -- and the first tiles of every phase while the floors are loose -- have survivors in every quarter: the
