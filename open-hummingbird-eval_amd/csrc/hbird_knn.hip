@@ -506,7 +506,8 @@ int hb_default_panel(int nqt, int G, size_t tile_bytes, int cq, int cb) {
 // members hold each other within a few stages through the progress words (soft sync in the kernels); placement and
 // lockstep are speed only, any schedule gives the same result.
 void hb_default_cluster(int nqt, int nbt, int G, bool fp32_kernel, int* cq, int* cb) {
-    // The first shape whose ragged last group idles at most 2.5 % of the pairs.  fp16 candidate kernel: 8 x 1 (eight
+    // The first shape whose ragged last group idles at most 2.5 % of the pairs (fp16 kernel: 1 / 16 -- 49 query tiles run 6 % faster as
+    // 4 x 2 with three idle members than as 2 x 2).  fp16 candidate kernel: 8 x 1 (eight
     // workgroups stream the same bank tiles: measured best at 10 M x 768), else 4 x 2, else 2 x 2, else none.  fp32 kernel
     // (bound by the matrix pipe, so only the cheapest sharing pays): 2 x 4, else 2 x 2 -- at 10 M x 768 fabric reads
     // 4.79 -> 1.93 TB for +0.5 % time; 4 x 2 and 8 x 1 cost 3 %.
@@ -518,7 +519,7 @@ void hb_default_cluster(int nqt, int nbt, int G, bool fp32_kernel, int* cq, int*
         const int q = sh[0], b = sh[1];
         if (G % (8 * q * b) != 0 || nqt < q) continue;
         const int padded = (nqt + q - 1) / q * q;
-        if ((padded - nqt) * 40 > padded) continue;
+        if ((padded - nqt) * (fp32_kernel ? 40 : 16) > padded) continue;
         *cq = q; *cb = b;
         return;
     }
@@ -888,12 +889,13 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // does not know strided segments.
     int cq = 1, cb = 1;
     if (ix->force_cq > 0 && ix->force_cb > 0) { cq = ix->force_cq; cb = ix->force_cb; }
-    // fp16 candidate kernel: from 400 k stages per workgroup up.  Same box, kernel ms (phased), none vs automatic: 20 M x 384 323.7 /
-    // 314.5, 10 M x 768 324.3 / 307 (21,904 queries, 630 k stages; 359 k with 12,544 queries: 183.7 / 184.7), 7 M x 768 (441 k) 227 / 221.5, 5 M x 1024
-    // 213.7 / 208.9 -- but 5 M x 768 x 12,544 queries (179 k stages) 92.8 / 94.6 and 2,074,072 x 384 (37 k) 22.7 / 24.8: more
-    // slots, shorter segments
+    // fp16 candidate kernel: from 70 k stages per workgroup up (round 4: with the lean stage loop and the XCD-level query sharing the
+    // clusters pay much earlier than the 400 k of round 3).  Same box, kernel ms (phased), none vs automatic: 10 M x 768 321 / 284,
+    // 2.5 M x 768 (157 k stages) 83.0 / 77.5, 5 M x 384 (157 k) 85.3 / 80.3, 1.25 M x 768 (79 k) 43.7 / 41.8, 5 M x 768 x 12,544 queries
+    // (179 k; 49 query tiles: 4 x 2) 94.0 / 88.2 -- but 2,074,072 x 384 (37 k) 21.3 / 22.8: more slots, shorter segments
+    // (profiles/r04/f16_cluster_threshold.txt)
     else if (f16 && (ix->variant == 0 || ix->variant == 5) && ix->force_cq == 0) {
-        if ((long long)nqt * nbt / std::max(1, G) * (ix->dp16 / 16) >= 400000) hb_default_cluster(nqt, nbt, G, false, &cq, &cb);
+        if ((long long)nqt * nbt / std::max(1, G) * (ix->dp16 / 16) >= 70000) hb_default_cluster(nqt, nbt, G, false, &cq, &cb);
     }
     // fp32: only beside the kernel with register-resident query fragments (its sync is free of spills), and only for the
     // biggest searches: 2 x 4 clusters cut the fabric reads by 60 % (10 M x 768: 4.79 -> 1.93 TB per search, L2 hit rate

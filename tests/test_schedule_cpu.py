@@ -299,9 +299,10 @@ def test_phased_work_list_invariants(nqt, nbt, G, panel, cq, cb):
 
 
 def test_automatic_cluster_shape():
-    """The widest query way that idles at most 2.5 % of the pairs; none for small searches or unsuitable grids."""
-    for nqt, nbt, G, want in ((86, 39063, 256, (8, 1)), (49, 8102, 256, (2, 2)), (48, 8102, 256, (8, 1)), (52, 8102, 256, (4, 2)),
-                              (51, 8102, 256, (4, 2)), (1, 100000, 256, (1, 1)), (86, 100, 256, (1, 1)), (86, 39063, 104, (1, 1)), (86, 39063, 32, (2, 2))):
+    """The widest query way that idles at most 1 / 16 of the pairs (fp16 candidate kernel; the fp32 kernel: 2.5 %); none for small
+    searches or unsuitable grids."""
+    for nqt, nbt, G, want in ((86, 39063, 256, (8, 1)), (49, 8102, 256, (4, 2)), (48, 8102, 256, (8, 1)), (52, 8102, 256, (4, 2)),
+                              (51, 8102, 256, (4, 2)), (50, 8102, 256, (4, 2)), (65, 8102, 256, (4, 2)), (45, 8102, 256, (8, 1)), (1, 100000, 256, (1, 1)), (86, 100, 256, (1, 1)), (86, 39063, 104, (1, 1)), (86, 39063, 32, (2, 2))):
         assert plan(nqt, nbt, G, 0, cluster=(-1, -1))[1]["cluster"] == want, (nqt, nbt, G)
     # the fp32 kernel's automatic shape (cluster_q = -2): 2 x 4, else 2 x 2
     for nqt, nbt, G, want in ((86, 39063, 256, (2, 4)), (49, 8102, 256, (2, 4)), (86, 4883, 256, (2, 4)), (1, 100000, 256, (1, 1)),
