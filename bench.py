@@ -127,37 +127,89 @@ def build_bank(index, rows_lo, rows_hi, D, C, device):
     torch.cuda.synchronize(device)
 
 
+def host_cpu_budget():
+    """Cores this process may actually use: min(affinity mask, cgroup CPU quota).  The GPU boxes of this pool show 256 hardware
+    threads but grant a container 16 CPUs of quota (cpu.max "1600000 100000"): 128 OpenMP threads on that are 8-fold oversubscribed
+    -- round 3's "0.50 TFLOP/s on 128 cores"."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota, src = None, "none"
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                      # cgroup v2
+        if q != "max":
+            quota, src = float(q) / float(per), f"cgroup v2 cpu.max {q} {per}"
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota, src = q / per, f"cgroup v1 cfs_quota_us {q} / {per}"
+        except Exception:
+            pass
+    cores = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return {"cores": cores, "hardware_threads": os.cpu_count(), "affinity": aff, "cgroup_quota_cpus": quota, "quota_source": src}
+
+
+def scann_cpu_leg(bank, q, k, exact_idx, threads):
+    """The reference's default CPU backend, restated call by call (hbird/nn/search_scann.py:18-33 builder chain with its default
+    parameters, :40 search_batched), timed on the same sample -- when `scann` can be imported at all."""
+    try:
+        import scann
+    except Exception as e:                                    # absent from this image (no network to install it)
+        return f"unavailable ({type(e).__name__}: {e})"
+    t0 = time.time()
+    b = scann.scann_ops_pybind.builder(bank, k, "dot_product")
+    b = b.tree(num_leaves=512, num_leaves_to_search=32, training_sample_size=bank.shape[0])
+    b = b.score_ah(2, anisotropic_quantization_threshold=0.2, dimensions_per_block=4)
+    index = b.reorder(120).build()
+    t_build = time.time() - t0
+    t0 = time.time()
+    nb, _ = index.search_batched(q)
+    dt = time.time() - t0
+    recall = float(np.mean([len(set(a.tolist()) & set(b_.tolist())) / float(k) for a, b_ in zip(np.asarray(nb), exact_idx)]))
+    return {"build_seconds": round(t_build, 2), "value_on_sample": q.shape[0] / dt, "unit": "query-patches/s", "recall_at_k": recall,
+            "bank_rows": int(bank.shape[0]), "queries": int(q.shape[0]), "threads": threads,
+            "parameters": "num_leaves 512, num_leaves_to_search 32, AH(2, 0.2, dimensions_per_block 4), reorder 120 (search_scann.py defaults)"}
+
+
 def cpu_baseline(D, k, M_total):
-    """The oracle's exact fp32 brute force (oracle/hbird_oracle.c, OpenMP + AVX2) on a bounded sample,
-    scaled linearly in the bank size (brute force is linear in M).  Reported baseline only."""
+    """The oracle's exact fp32 brute force (oracle/hbird_oracle.c, OpenMP + AVX2) on a bounded sample, on the cores the host grants
+    (host_cpu_budget), scaled linearly in the bank size -- with a second, half-size sample that shows the scaling instead of
+    asserting it; the host BLAS on the same product; ScaNN when it is installed.  Reported baseline only."""
     import oracle
+    import torch as _t
+    budget = host_cpu_budget()
+    threads = budget["cores"]
+    oracle.set_num_threads(threads)
+    _t.set_num_threads(threads)
     rng = np.random.default_rng(0)
-    ms, nqs = 400_000, 8192           # about 10 s of CPU work on the 128 host threads of the GPU box
+    ms, nqs = 400_000, 2048            # ~10-25 s of CPU work on 16 granted cores
     bank = rng.standard_normal((ms, D), dtype=np.float32)
     bank /= np.linalg.norm(bank, axis=1, keepdims=True)
     q = 3.0 * rng.standard_normal((nqs, D), dtype=np.float32)
     oracle.knn_chain_f32(q[:64], bank[:10000], k)            # warm up threads
     t0 = time.time()
-    oracle.knn_chain_f32(q, bank, k)
+    ex_idx, _ = oracle.knn_chain_f32(q, bank, k)
     dt = time.time() - t0
     qps_sample = nqs / dt
-    # second CPU reference point (BASELINE.md 3.2): torch mm + topk on all host threads, same sample
-    import torch as _t
+    t0 = time.time()
+    oracle.knn_chain_f32(q, bank[:ms // 2], k)               # linearity: half the rows
+    dt_half = time.time() - t0
+    # second CPU reference point (BASELINE.md 3.2): torch mm + topk, same sample
     qb, bb = _t.from_numpy(q), _t.from_numpy(bank)
+    (qb[:256] @ bb.T).topk(k, dim=1)
     t1 = time.time()
-    nqt = 2048
+    nqt = 1024
     for i in range(0, nqt, 256):
         (qb[i:i + 256] @ bb.T).topk(k, dim=1)
     dt_t = time.time() - t1
-    # the contraction alone (no k-select): what the host's BLAS sustains on this shape -- the CPU's own ceiling for the
-    # dominant term, so that the un-tuned port above can be read against it
-    qm = qb[:4096].contiguous()
-    (qm[:256] @ bb.T)
+    # the contraction alone (no k-select): what the host's BLAS sustains on this shape with the granted cores -- the CPU's own
+    # ceiling for the dominant term, so that the un-tuned port above can be read against it
+    (qb[:256] @ bb.T)
     t3 = time.time()
-    for i in range(0, 4096, 1024):
-        (qm[i:i + 1024] @ bb.T)
+    for i in range(0, nqs, 1024):
+        (qb[i:i + 1024] @ bb.T)
     dt_m = time.time() - t3
-    mm_tflops = 2.0 * 4096 * ms * D / dt_m / 1e12
+    mm_tflops = 2.0 * nqs * ms * D / dt_m / 1e12
+    blas = [ln.strip() for ln in _t.__config__.parallel_info().splitlines() if "Math Kernel" in ln or "get_num_threads" in ln or "OpenBLAS" in ln]
     # the reference-equivalent CPU stage after the search (hbird_eval.py:631-637, 575-609, 235-243), one 37 x 37 image
     S, C = 37, 151
     idx1 = rng.integers(0, ms, size=(S * S, k))
@@ -167,22 +219,28 @@ def cpu_baseline(D, k, M_total):
     lh = oracle.cross_attention(q[:1].repeat(S * S, 0)[None], kf, kl)
     oracle.upsample_argmax(lh, S, 14 * S, 14 * S)
     dt_p = time.time() - t2
+    scann_leg = scann_cpu_leg(bank, q, k, ex_idx, threads)
     return {
         "value": qps_sample * ms / M_total,
         "unit": "query-patches/s",
-        "cores": oracle.num_threads(),
+        "cores": threads,
+        "host": budget,
         "kind": "port",
         "tuned": False,                             # the chain oracle is a parity tool (one fmaf chain per score), not a tuned SGEMM
         "extrapolated": True,                       # value = measured sample rate x (sample rows / bank rows)
         "measured_on_sample": {"value": qps_sample, "unit": "query-patches/s", "bank_rows": ms, "queries": nqs, "seconds": round(dt, 2)},
-        "sample": f"oracle exact fp32 brute force on {nqs} queries x {ms} rows x {D} dims took {dt:.2f}s "
-                  f"({qps_sample:.1f} q/s), scaled x{ms}/{M_total} to the full bank; ScaNN (the reference's default CPU "
-                  f"backend) is not installed on this image",
+        "linearity_check": {"rows": [ms // 2, ms], "seconds": [round(dt_half, 2), round(dt, 2)],
+                            "seconds_ratio": dt / dt_half, "expected": 2.0,
+                            "what": "same queries against half the sample and the whole sample: brute force is linear in the bank rows, which is what the extrapolation uses"},
+        "sample": f"oracle exact fp32 brute force on {nqs} queries x {ms} rows x {D} dims took {dt:.2f}s on {threads} threads "
+                  f"({qps_sample:.1f} q/s), scaled x{ms}/{M_total} to the full bank",
+        "scann": scann_leg,
         "torch_mm_topk": {"value": nqt / dt_t * ms / M_total, "unit": "query-patches/s", "threads": _t.get_num_threads(),
                           "sample_seconds": round(dt_t, 2)},
-        "torch_mm_only": {"tflops": mm_tflops, "value": 4096 / dt_m * ms / M_total, "unit": "query-patches/s (no k-select)",
-                          "threads": _t.get_num_threads(), "sample_seconds": round(dt_m, 2),
-                          "what": f"fp32 [4096,{D}] x [{D},{ms}] products only: the host BLAS ceiling for the contraction"},
+        "torch_mm_only": {"tflops": mm_tflops, "gflops_per_core": mm_tflops * 1e3 / threads, "value": nqs / dt_m * ms / M_total,
+                          "unit": "query-patches/s (no k-select)", "threads": _t.get_num_threads(), "sample_seconds": round(dt_m, 2),
+                          "blas": blas,
+                          "what": f"fp32 [{nqs},{D}] x [{D},{ms}] products only: the host BLAS ceiling for the contraction on the granted cores"},
         "post_knn_stage": {"value": S * S / dt_p, "unit": "query-patches/s",
                            "what": "gather + cross-attention + bilinear upsample + argmax of one 37x37-token image, C=151"},
     }
@@ -253,6 +311,29 @@ def measure_traffic(a, kernel):
         f"live: rocprofv3 --pmc on {vals['kernel']} ({vals['launches']} launch(es) of one search): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE = {vals['FETCH_SIZE']:.0f} KiB x2 + {vals['WRITE_SIZE']:.0f} KiB"
 
 
+def first_collective_or_die(td, device, backend, world, rank, seconds=None):
+    """RCCL builds its communicator on the first collective.  If that does not complete (a peer that never arrives, IPC handles the
+    driver refuses, a wedged link) the run would hang until the driver's clock kills it without a word: a watchdog thread prints
+    ONE line to stderr and ends the process with status 3.  Nothing is re-executed."""
+    import threading
+    seconds = float(os.environ.get("HBIRD_BENCH_COMM_TIMEOUT", "180")) if seconds is None else seconds
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(seconds):
+            sys.stderr.write(f"bench.py: rank {rank}/{world}: the {backend} communicator did not come up within {seconds:.0f} s "
+                             f"(first all-reduce on {device}); check HSA_ENABLE_IPC_MODE_LEGACY=0, NCCL_DEBUG=INFO, visible GPUs\n")
+            sys.stderr.flush()
+            os._exit(3)
+    threading.Thread(target=watchdog, daemon=True).start()
+    t = torch.ones(1, device=device)
+    td.all_reduce(t)
+    torch.cuda.synchronize(device)
+    done.set()
+    if int(t.item()) != world:
+        raise SystemExit(f"bench.py: first all-reduce returned {t.item()} on rank {rank}, expected {world}")
+
+
 _JSON_FD = None
 
 
@@ -308,6 +389,7 @@ def main():
         else:
             td.init_process_group(backend, **kw)
         assert td.get_world_size() == world and td.get_rank() == rank
+        first_collective_or_die(td, device, backend, world, rank)
     from hbird_mi import dist as hdist
     from hbird_mi.nn.search_hip import HipFlatIndex, merge_topk_packed
 
@@ -354,7 +436,10 @@ def main():
     side = torch.cuda.Stream(device) if overlap else main_s
     ex = [hdist.PackedTopK(nq, k, device, world) for _ in range(2)] if dist_on else None
     ev_knn = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev_ag = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev_mg = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ev_done = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    split_ms = []                       # per timed step: (all-gather, merge, aggregation) ms of the exposed exchange
     used = [False, False]
     pending = []
 
@@ -372,7 +457,9 @@ def main():
         with torch.cuda.stream(side):
             side.wait_event(ev_knn[b])
             ex[b].gather()
+            ev_ag[b].record(side)
             mi, md = merge_topk_packed(ex[b].recv, ex[b].part_bytes, world, nq, k, 0)
+            ev_mg[b].record(side)
             agg.use_current_stream()
             out = agg.aggregate(q[qs_lo:qs_hi], mi[qs_lo:qs_hi].contiguous(), md[qs_lo:qs_hi].contiguous(), beta=0.02)
             ev_done[b].record(side)
@@ -396,8 +483,10 @@ def main():
         last_out = step(i)
         knn_ms.append(index.last_knn_ms())        # waits for this step's kNN kernel (HIP events on its stream)
         if dist_on and not overlap:
-            ev_done[i & 1].synchronize()
-            xchg_ms.append(ev_knn[i & 1].elapsed_time(ev_done[i & 1]))
+            b = i & 1
+            ev_done[b].synchronize()
+            xchg_ms.append(ev_knn[b].elapsed_time(ev_done[b]))
+            split_ms.append((ev_knn[b].elapsed_time(ev_ag[b]), ev_ag[b].elapsed_time(ev_mg[b]), ev_mg[b].elapsed_time(ev_done[b])))
     sync()
     dt = time.time() - t0
     index.set_timing(False)
@@ -416,15 +505,52 @@ def main():
                         "rows_per_rank": [(nq * (r + 1)) // world - (nq * r) // world for r in range(world)]}
         else:
             checksum = {"bits": int(cs[0].item()), "sum": float(cs[1:].view(torch.float64).item()), "rows_per_rank": [nq]}
+    extra_legs = {}
     if dist_on:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = float(t.item())
-        mine = torch.tensor([float(np.mean(knn_ms)), float(np.mean(xchg_ms)) if xchg_ms else -1.0, float(hi - lo), float(dev_index)],
+
+        def timed_leg(n_steps=3):
+            """n_steps whole N-rank steps (search + exchange) of the current index settings: (max-over-ranks ms per step, this rank's kNN ms)."""
+            step(0); sync()
+            index.set_timing(True)
+            t1 = time.time(); km = []
+            for i in range(n_steps):
+                step(i); km.append(index.last_knn_ms())
+            sync()
+            d = torch.tensor([(time.time() - t1) / n_steps * 1e3], device=device, dtype=torch.float64)
+            index.set_timing(False)
+            td.all_reduce(d, op=td.ReduceOp.MAX)
+            return float(d.item()), float(np.mean(km))
+        legs = []                       # every rank runs the same legs (they contain collectives); the numbers travel in `mine`
+        cl_auto = tuple(index.schedule_info().get("cluster", (1, 1)))
+        if not a.fp16 and cl_auto != (1, 1):
+            index.set_cluster(1, 1, 0)
+            legs.append(("without_clusters",) + timed_leg())
+            index.set_cluster(0, 0, -1)
+        if not a.fp16:
+            index.set_fp16(True)
+            ms16, k16 = timed_leg()
+            legs.append(("use_fp16_mode", ms16, k16))
+            fb16 = index.last_fp16_fallbacks()
+            index.set_fp16(False)
+        sp = np.mean(np.array(split_ms), axis=0) if split_ms else np.array([-1.0, -1.0, -1.0])
+        mine = torch.tensor([float(np.mean(knn_ms)), float(np.mean(xchg_ms)) if xchg_ms else -1.0, float(hi - lo), float(dev_index),
+                             float(sp[0]), float(sp[1]), float(sp[2])] + [x for lg in legs for x in lg[1:]],
                             device=device, dtype=torch.float64)
-        allr = torch.empty(world * 4, device=device, dtype=torch.float64)
+        ncol = mine.numel()
+        allr = torch.empty(world * ncol, device=device, dtype=torch.float64)
         td.all_gather_into_tensor(allr, mine)
-        per_rank = allr.view(world, 4).cpu().tolist()
+        per_rank = allr.view(world, ncol).cpu().tolist()
+        for j, lg in enumerate(legs):
+            extra_legs[lg[0]] = {"ms_per_step": lg[1], "value": nq / (lg[1] * 1e-3), "unit": "query-patches/s",
+                                 "knn_ms_per_rank": [round(r[8 + 2 * j], 3) for r in per_rank]}
+        if "use_fp16_mode" in extra_legs:
+            extra_legs["use_fp16_mode"]["fallback_queries_rank0"] = fb16
+            extra_legs["use_fp16_mode"]["note"] = "certified-exact fast mode, same outputs as the fp32 search; whole N-rank steps incl. the exchange"
+        if "without_clusters" in extra_legs:
+            extra_legs["without_clusters"]["cluster_in_timed_steps"] = list(cl_auto)
 
     if rank == 0:
         kms = float(np.mean(knn_ms))
@@ -465,7 +591,16 @@ def main():
                             "label aggregation of this rank's query slice" + (", on a side stream under the next step's kNN kernel" if overlap else
                             ", exposed after the kNN kernel (it owns every CU's registers, nothing can run beside it)"),
                 "packed_list_bytes_per_rank": ex[0].part_bytes,
+                "exchange_split_ms_per_rank": None if overlap else {
+                    "all_gather": [round(r[4], 3) for r in per_rank], "merge": [round(r[5], 3) for r in per_rank],
+                    "aggregate": [round(r[6], 3) for r in per_rank]},
+                # what ONE GPU would need for the same step = the shards' kernels one after the other (the kNN kernel is linear in
+                # the rows: 10 M / 5 M / 2.5 M / 1.25 M rows measured 2297.9 / 1146.5 / 577.5 / 289.5 ms)
+                "n1_equivalent_ms": round(sum(r[0] for r in per_rank), 3),
+                "efficiency": sum(r[0] for r in per_rank) / world / (dt / a.steps * 1e3),
+                "efficiency_definition": "(sum of the ranks' kNN kernel ms = the N=1-equivalent step) / N / measured ms_per_step",
             }
+            res.update(extra_legs)
         if world == 1 and not dist_on and not a.fp16 and tuple(index.schedule_info().get("cluster", (1, 1))) != (1, 1):
             # extra, not the headline: the timed steps ran with the automatic L2-sharing clusters (the biggest searches:
             # -60 % fabric reads for under 1 % of kernel time); the same step without them, so that the price is on the line

@@ -6,11 +6,14 @@ needs `forward_features(imgs) -> (tokens [B,N,D], attn|None)`, `eval_spatial_res
 """
 from __future__ import annotations
 
-import math
-from typing import Callable
+import logging
+import re
+from typing import Callable, Iterable, Optional
 
 import torch
 import torch.nn as nn
+
+logger = logging.getLogger(__name__)
 
 
 class FeatureExtractorSimple(nn.Module):
@@ -49,7 +52,15 @@ class FeatureExtractor(nn.Module):
       timm    forward_features + blocks[0].attn -> forward_features(imgs)[:, 1:], i.e. tokens AFTER the final norm
               (208-216) -- NOT get_intermediate_layers, which timm >= 0.9 also has and which skips that norm by default
       hf      config.model_type in {vit, deit} -> last_hidden_state[:, 1:] (218-231)
-      generic anything else: the module's output (token sequence, CLS dropped when present, or a [B,D,h,w] map)
+      generic anything else: the Q / K / V projection of the last block, caught by a forward hook on `blocks[-1].attn.qkv`
+              (233-235 -> get_intermediate_layer_feats, 257-321; `feat` selects which, "k" by default), CLS dropped.
+
+    Two deliberate supersets of the reference's generic path, both where the reference can only raise: it looks the block up by the
+    dotted name "blocks.-1.attn.qkv", which an nn.ModuleList never resolves, so its forward_features() fails with RuntimeError for
+    EVERY generic model (recorded in tests/golden/g9_feature_extractor.npz); here a negative layer counts from the end, as its
+    docstring says.  And it unpacks a 5-D qkv output only ([B, N, 3, heads, Dh], models.py:305); the [B, N, 3 * D] of a plain
+    nn.Linear is reshaped with `attn.num_heads` here.  With an explicit non-negative layer and a 5-D qkv the reference's hook path
+    runs: the fixture pins this class against it bit for bit.  A model without `blocks[i].attn.qkv` raises RuntimeError, as there.
     """
 
     def __init__(self, vit_model: nn.Module, eval_spatial_resolution: int = 14, d_model: int = 768,
@@ -61,6 +72,8 @@ class FeatureExtractor(nn.Module):
         self.use_autocast = use_autocast
         self.autocast_dtype = autocast_dtype
         self.backend = self._select_backend()
+        if self.backend == "generic":
+            logger.warning("[FeatureExtractor] Falling back to generic QKV hook backend.")      # models.py:353
 
     def _select_backend(self) -> str:
         m = self.model
@@ -84,7 +97,7 @@ class FeatureExtractor(nn.Module):
         lo, hi = a.min(dim=-1, keepdim=True).values, a.max(dim=-1, keepdim=True).values
         return (a - lo) / (hi - lo).clamp_min(1e-12)
 
-    def _tokens(self, imgs):
+    def _tokens(self, imgs, feat="k"):
         m = self.model
         if self.backend == "dino":
             return m.get_intermediate_layers(imgs)[0][:, 1:], self._cls_attention(m.get_last_selfattention(imgs))
@@ -101,34 +114,70 @@ class FeatureExtractor(nn.Module):
             out = m(imgs, output_attentions=True, return_dict=True)
             att = self._cls_attention(out.attentions[-1]) if getattr(out, "attentions", None) else None
             return out.last_hidden_state[:, 1:], att
-        # generic: whatever token stream the module offers
-        if hasattr(m, "forward_features"):
-            out = m.forward_features(imgs)
-            if isinstance(out, dict):
-                for key in ("x_norm_patchtokens", "patch_tokens", "last_hidden_state"):
-                    if key in out:
-                        out = out[key]
-                        break
-                else:
-                    raise RuntimeError("FeatureExtractor: forward_features dict has no patch-token entry")
-        elif hasattr(m, "get_intermediate_layers"):
-            out = m.get_intermediate_layers(imgs)[0]
-        else:
-            out = m(imgs)
-        if hasattr(out, "last_hidden_state"):
-            out = out.last_hidden_state
-        if out.dim() == 4:                                      # [B,D,h,w] feature map
-            out = out.flatten(2).transpose(1, 2)
-        n = out.shape[1]
-        if int(math.isqrt(n)) ** 2 != n and int(math.isqrt(n - 1)) ** 2 == n - 1:
-            out = out[:, 1:]                                    # drop CLS
-        return out, None
+        # generic ViT with blocks[*].attn.qkv: hook-based QKV (models.py:233-235)
+        return self.get_intermediate_layer_feats(imgs, feat=feat, layer_num=-1)
+
+    def _cls_attention_from_api(self, imgs):
+        """models.py:356-361: only a model with get_last_selfattention has a CLS attention map."""
+        if hasattr(self.model, "get_last_selfattention"):
+            return self._cls_attention(self.model.get_last_selfattention(imgs))
+        return None
+
+    def get_intermediate_layer_feats(self, imgs: torch.Tensor, feat: str = "k", layer_num: int = -1):
+        """Q / K / V features of one transformer block through a forward hook on `blocks[layer_num].attn.qkv`
+        (models.py:257-321): -> (features [B, N, heads * Dh] without the CLS token, CLS attention | None)."""
+        assert feat in {"q", "k", "v"}
+        imgs = imgs.to(self.device, non_blocking=True)
+        blocks = getattr(self.model, "blocks", None)
+        try:
+            qkv_module = blocks[layer_num].attn.qkv
+        except Exception:
+            raise RuntimeError(f"qkv module not found at model.blocks[{layer_num}].attn.qkv; cannot hook QKV. "
+                               "Use forward_features() instead or ensure a DINO-style backbone.") from None
+        bucket = {}
+        handle = qkv_module.register_forward_hook(lambda _m, _i, output: bucket.__setitem__("qkv", output))
+        try:
+            with torch.inference_mode():
+                if self._cls_attention_from_api(imgs) is None:      # that call is a forward already when the model has it
+                    self.model(imgs)
+        finally:
+            handle.remove()
+        if "qkv" not in bucket:
+            raise RuntimeError("QKV hook did not fire; model forward did not traverse qkv module.")
+        qkv = bucket["qkv"]
+        if qkv.dim() == 3:                      # nn.Linear output [B, N, 3 * D] (the reference cannot unpack this)
+            heads = int(getattr(blocks[layer_num].attn, "num_heads", 1))
+            qkv = qkv.reshape(qkv.shape[0], qkv.shape[1], 3, heads, -1)
+        B, N, _three, heads, Dh = qkv.shape
+        qkv = qkv.reshape(B, N, 3, heads, Dh).permute(2, 0, 3, 1, 4)
+        pick = {"q": 0, "k": 1, "v": 2}[feat]
+        feats = qkv[pick].transpose(1, 2).reshape(B, N, -1)[:, 1:, :]          # drop CLS
+        return feats, self._cls_attention_from_api(imgs)
+
+    def freeze_feature_extractor(self, unfreeze_layers: Optional[Iterable[str]] = None, regex: bool = False) -> None:
+        """Freeze every parameter of the backbone except those whose name contains (or, with regex=True, matches) one of
+        `unfreeze_layers` (models.py:237-255)."""
+        patterns = list(unfreeze_layers or [])
+        for name, p in self.model.named_parameters():
+            p.requires_grad = any((re.search(pat, name) is not None) if regex else (pat in name) for pat in patterns)
+        logger.info("[FeatureExtractor] Frozen backbone. Unfrozen patterns: %s", patterns)
+
+    @property
+    def device(self) -> torch.device:
+        """Where the backbone lives (models.py:366-369; a parameter-less module counts as CPU, 32-37)."""
+        try:
+            return next(self.model.parameters()).device
+        except StopIteration:
+            return torch.device("cpu")
 
     @torch.inference_mode()
-    def forward_features(self, imgs: torch.Tensor):
+    def forward_features(self, imgs: torch.Tensor, feat: str = "k"):
+        """`feat` in {"k", "q", "v"}: which projection the generic QKV-hook backend returns; ignored by the families that expose
+        their patch tokens (models.py:164-235)."""
+        imgs = imgs.to(self.device, non_blocking=True)          # models.py:186-187
         dev_type = imgs.device.type
         with torch.autocast(device_type=dev_type, dtype=self.autocast_dtype, enabled=(self.use_autocast and dev_type == "cuda")):
-            tok, attn = self._tokens(imgs)
+            tok, attn = self._tokens(imgs, feat)
         return tok.float(), attn
 
     def forward(self, imgs: torch.Tensor):

@@ -24,7 +24,7 @@ _lib = None
 __all__ = [
     "build", "lib", "knn_chain_f32", "knn_f64", "chain_sqnorm", "normalize_rows",
     "patchify_gt", "patch_label_hist", "cross_attention", "sample_patches", "sample_num_nonempty",
-    "upsample_bilinear", "upsample_argmax", "confusion_matrix", "PredsMIoUOracle", "num_threads",
+    "upsample_bilinear", "upsample_argmax", "confusion_matrix", "PredsMIoUOracle", "num_threads", "set_num_threads",
     "gather_neighbours", "near_tie_report", "window_origins", "sliding_window_argmax",
 ]
 
@@ -67,6 +67,14 @@ def lib() -> ctypes.CDLL:
 
 def num_threads() -> int:
     return int(lib().orc_num_threads())
+
+
+def set_num_threads(n: int) -> None:
+    """OpenMP threads of the C restatement (bench.py's cpu_baseline: the cores the host grants, not the machine's count)."""
+    L = lib()
+    L.orc_set_num_threads.argtypes = [ctypes.c_int]
+    L.orc_set_num_threads.restype = None
+    L.orc_set_num_threads(int(n))
 
 
 def _f32(a) -> np.ndarray:

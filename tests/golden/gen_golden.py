@@ -256,6 +256,34 @@ def main():
                   f"conf_{name}": m._conf_mat.numpy()})
     np.savez_compressed(os.path.join(out, "g8_predsmiou.npz"), **g)
 
+    # ---- G9 the reference FeatureExtractor's generic QKV-hook path on a tiny random ViT (models.py:257-321) ------------
+    # forward_features() of the generic backend asks for layer -1 through a dotted-name lookup ("blocks.-1.attn.qkv") that an
+    # nn.ModuleList never resolves: it raises RuntimeError for every model (recorded below).  With an explicit non-negative layer
+    # the hook path itself works, for a qkv module with 5-D output: that pins the unpacking (reshape / permute / CLS drop).
+    from hbird.models import FeatureExtractor as RefFE
+    from tiny_vit import TinyQKVViT
+    g = {}
+    vit = TinyQKVViT(seed=5).eval()
+    imgs = torch.from_numpy(np.random.default_rng(77).standard_normal((2, 3, 32, 32)).astype(np.float32))
+    fe = RefFE(vit, eval_spatial_resolution=4, d_model=16)
+    g["backend"] = np.array(fe._backend.name)
+    g["imgs"] = imgs.numpy()
+    try:
+        fe.forward_features(imgs)
+        g["default_layer_raises"] = np.array("")
+    except RuntimeError as e:
+        g["default_layer_raises"] = np.array(type(e).__name__)
+    for feat in ("q", "k", "v"):
+        for layer in (0, 1):
+            f, att = fe.get_intermediate_layer_feats(imgs, feat=feat, layer_num=layer)
+            assert att is None
+            g[f"feats_{feat}_{layer}"] = f.numpy()
+    fe.freeze_feature_extractor(["blocks.1.attn"])
+    g["trainable_after_freeze"] = np.array(sorted(n for n, p_ in vit.named_parameters() if p_.requires_grad))
+    fe.freeze_feature_extractor([r"blocks\.0\..*bias$"], regex=True)
+    g["trainable_after_regex_freeze"] = np.array(sorted(n for n, p_ in vit.named_parameters() if p_.requires_grad))
+    np.savez_compressed(os.path.join(out, "g9_feature_extractor.npz"), **g)
+
     # (y/255)*255 round trip that hbird_eval.py:219,309 rely on
     c = np.arange(256, dtype=np.float32)
     rt = (torch.from_numpy(c / np.float32(255.0)) * 255).long().numpy()

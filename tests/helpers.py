@@ -52,3 +52,27 @@ def golden_case_indexed(g, name):
         x[0, 0, 0, 0] = float(1000 + i); tok[1000 + i] = c["va_tok"][i]
     c["tokens_by_key"] = tok
     return c
+
+
+def chain_oracle_topk_chunked(ix, q_sel, M, k, metric="dot_product", chunk=1_000_000):
+    """The fp32 chain oracle (oracle.knn_chain_f32: the bit-exact target of the kernels) over a device-resident bank of ANY size:
+    the bank is reconstructed chunk by chunk (no 30-80 GB host copy), each chunk is searched by the oracle with its id base, and the
+    per-chunk lists are merged on the host by the kernels' ordering key (score descending / distance ascending, then id ascending).
+    A row's chain score does not depend on which chunk it sits in, so the merged list is the oracle's answer for the whole bank.
+    -> (idx int64 [n, k], dist float32 [n, k]) as numpy."""
+    import oracle
+    qn = q_sel.detach().cpu().numpy().astype(np.float32)
+    n = qn.shape[0]
+    best_i = np.full((n, 0), -1, dtype=np.int64)
+    best_d = np.zeros((n, 0), dtype=np.float32)
+    sign = 1.0 if metric.lower() in ("l2", "euclidean") else -1.0          # sort key: ascending
+    for r in range(0, M, chunk):
+        ids = torch.arange(r, min(M, r + chunk), device=q_sel.device)
+        rows = ix.reconstruct(ids)
+        rows = rows.cpu().numpy() if isinstance(rows, torch.Tensor) else np.asarray(rows)
+        ci, cd = oracle.knn_chain_f32(qn, rows, min(k, rows.shape[0]), metric, id_base=r)
+        del rows
+        ai = np.concatenate([best_i, ci], axis=1); ad = np.concatenate([best_d, cd], axis=1)
+        order = np.lexsort((ai, sign * ad.astype(np.float64)), axis=1)[:, :k]      # primary: the distance, ties: the lower id
+        best_i = np.take_along_axis(ai, order, axis=1); best_d = np.take_along_axis(ad, order, axis=1)
+    return best_i, best_d

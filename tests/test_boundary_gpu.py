@@ -120,6 +120,13 @@ def test_bench_gpus_2_runs_two_ranks(cuda_device):
     assert mg["packed_list_bytes_per_rank"] == (3000 * 30 * 12 + 15) // 16 * 16
     assert all(x > 0 for x in mg["knn_ms_per_rank"]) and all(x > 0 for x in mg["exchange_ms_per_rank"])
     assert two["value"] > 0 and two["roofline"]["algorithmic_flops_per_launch"] == 2.0 * 3000 * 300000 * 64
+    # what the first real N-GPU run needs on its line: the exposed exchange split three ways, the N=1-equivalent efficiency, and the
+    # use_fp16 leg as whole N-rank steps
+    sp = mg["exchange_split_ms_per_rank"]
+    assert set(sp) == {"all_gather", "merge", "aggregate"} and all(len(v) == 2 and min(v) >= 0 for v in sp.values())
+    assert 0 < mg["efficiency"] <= 1.05 and mg["n1_equivalent_ms"] == pytest.approx(sum(mg["knn_ms_per_rank"]), rel=1e-3)
+    f16 = two["use_fp16_mode"]
+    assert f16["value"] > 0 and len(f16["knn_ms_per_rank"]) == 2 and f16["fallback_queries_rank0"] == 0
 
 
 def test_bench_rccl_path_with_one_rank(cuda_device):
@@ -188,3 +195,37 @@ def test_c_abi_multi_gpu_handle(cuda_device, metric, shard, fp16):
                                  dist.ctypes.data_as(ctypes.c_void_p)) != 0
     finally:
         L.hb_multi_free(h)
+
+
+@pytest.mark.parametrize("metric,shard", [("dot_product", 1), ("l2", 1), ("dot_product", 0)])
+def test_c_abi_multi_gpu_handle_on_distinct_devices(cuda_device, metric, shard):
+    """The same through TWO DISTINCT GPUs (peer copies and per-device streams that `gpu_ids=[0, 0, 0]` never exercises), and the Python
+    composition (HipMultiIndex) beside it: skipped where only one GPU is visible (the build pool), live on a multi-GPU node."""
+    import ctypes
+    from hbird_mi.nn.search_hip import NearestNeighborSearchHIP
+    L = _lib.lib()
+    if _lib.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    M, D, nq, k = 40_003, 96, 513, 30
+    bank = gi.unit_bank(M, D, seed=17)
+    bank[30_000:30_004] = bank[5]
+    q = gi.vit_like_queries(nq, D, seed=18); q[:4] = 2.0 * bank[5]
+    ridx, rdist = oracle.knn_chain_f32(q, bank, k, metric)
+    h = ctypes.c_void_p()
+    ids = (ctypes.c_int * 2)(0, 1)
+    _lib.check(L.hb_multi_create(D, 0 if metric == "dot_product" else 1, ids, 2, shard, ctypes.byref(h)))
+    try:
+        _lib.check(L.hb_multi_reserve(h, M))
+        for a, b in ((0, 15_000), (15_000, 25_001), (25_001, M)):
+            piece = np.ascontiguousarray(bank[a:b])
+            _lib.check(L.hb_multi_add(h, piece.ctypes.data_as(ctypes.c_void_p), b - a, 0))
+        idx = np.empty((nq, k), np.int64); dist = np.empty((nq, k), np.float32)
+        _lib.check(L.hb_multi_search(h, q.ctypes.data_as(ctypes.c_void_p), nq, k, idx.ctypes.data_as(ctypes.c_void_p),
+                                     dist.ctypes.data_as(ctypes.c_void_p)))
+        assert np.array_equal(idx, ridx) and np.array_equal(dist.view(np.uint32), rdist.view(np.uint32))
+    finally:
+        L.hb_multi_free(h)
+    nn = NearestNeighborSearchHIP(torch.from_numpy(bank), n_neighbors=k, distance_measure=metric, idx_shard=bool(shard), gpu_ids=[0, 1])
+    pi, pd = nn.find_nearest_neighbors(torch.from_numpy(q).cuda())
+    pi = pi.cpu().numpy() if isinstance(pi, torch.Tensor) else pi; pd = pd.cpu().numpy() if isinstance(pd, torch.Tensor) else pd
+    assert np.array_equal(pi, ridx) and np.array_equal(np.asarray(pd).view(np.uint32), rdist.view(np.uint32))

@@ -14,6 +14,7 @@ import torch
 
 import golden_inputs as gi
 import oracle
+from helpers import chain_oracle_topk_chunked
 from hbird_mi.nn.search_hip import HipFlatIndex, NearestNeighborSearchHIP, merge_topk
 
 pytestmark = pytest.mark.gpu
@@ -108,8 +109,9 @@ def _float64_topk(ix, q_sel, M, k, dev, chunk=1_000_000):
 
 
 def _full_size_properties(M, D, nq, ks, dev, seed, n_plant=128):
-    """Planted neighbours, sortedness, distinct ids, determinism, 2-shard merge == single index, use_fp16 == fp32 bits,
-    and a float64 check of 16 queries against ALL rows -- for every k in `ks` on one bank."""
+    """Planted neighbours, sortedness, distinct ids, determinism, 2-shard merge == single index, use_fp16 == fp32 bits, the fp32
+    chain oracle bit for bit on 32 queries against ALL rows (chunked; whatever kernel the size selects automatically -- clusters,
+    pools -- and the use_fp16 path) and a float64 check of 16 queries -- for every k in `ks` on one bank."""
     ix = HipFlatIndex(D, 0, 0); ix.reserve(M)
     half = M // 2
     a, b = HipFlatIndex(D, 0, 0), HipFlatIndex(D, 0, 0)
@@ -143,6 +145,11 @@ def _full_size_properties(M, D, nq, ks, dev, seed, n_plant=128):
         assert ix.last_fp16_fallbacks() < max(1, nq // 100)
     ix.set_fp16(False)
     kmax = max(ks)
+    sel32 = torch.linspace(0, nq - 1, 32, device=dev).long()
+    ci, cd = chain_oracle_topk_chunked(ix, q[sel32], M, kmax)
+    for k in ks:      # idx16 == idx was asserted above: the same bits hold for the use_fp16 path
+        assert np.array_equal(out[k][0][sel32].cpu().numpy(), ci[:, :k]), f"k={k}: indices differ from the chain oracle at full size"
+        assert np.array_equal(out[k][1][sel32].cpu().numpy().view(np.uint32), cd[:, :k].view(np.uint32)), f"k={k}: distance bits differ"
     best_i, best_s = _float64_topk(ix, q[sel], M, kmax, dev)
     for k in ks:
         got = out[k][0][sel].cpu().numpy(); ref = best_i[:, :k].cpu().numpy()

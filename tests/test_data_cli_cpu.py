@@ -150,7 +150,13 @@ def test_feature_extractor_backends_cpu():
 
     x = torch.zeros(B, 3, 8, 8)
     Dino.get_last_selfattention = lambda self, x: torch.rand(B, 2, S * S + 1, S * S + 1)
-    for m, backend, want in ((Dino(), "dino", tok[:, 1:]), (DinoV2(), "dinov2", tok[:, 1:]), (Plain(), "generic", tok[:, 1:]),
+    # a module with none of the family APIs and no blocks[i].attn.qkv: the reference's generic QKV-hook fallback raises RuntimeError
+    # (hbird/models.py:280-285) -- so does this one, instead of guessing a token stream from the module's output
+    fe = FeatureExtractor(Plain(), eval_spatial_resolution=S, d_model=D)
+    assert fe.backend == "generic"
+    with pytest.raises(RuntimeError, match="qkv module not found"):
+        fe.forward_features(x)
+    for m, backend, want in ((Dino(), "dino", tok[:, 1:]), (DinoV2(), "dinov2", tok[:, 1:]),
                              (TimmLike(), "timm", 2.0 * tok[:, 1:] + 1.0), (HfLike(), "hf", tok[:, 1:])):
         fe = FeatureExtractor(m, eval_spatial_resolution=S, d_model=D)
         assert fe.backend == backend
@@ -166,6 +172,38 @@ def test_feature_extractor_backends_cpu():
     assert attn is None and torch.equal(out, tok[:, 1:])
     fs2 = FeatureExtractorSimple(Plain(), lambda model, imgs: (model(imgs)[:, 1:], "a"), S, D)
     assert fs2(x)[1] == "a"
+
+
+def test_feature_extractor_generic_qkv_hook_golden_g9(golden_dir):
+    """The generic fallback (hook on blocks[i].attn.qkv, hbird/models.py:257-321) against the REFERENCE's FeatureExtractor on a tiny
+    random ViT (tests/golden/g9_feature_extractor.npz, written by gen_golden.py): Q / K / V of both blocks bit for bit; the default
+    layer (-1: the reference's dotted lookup never resolves it and raises, recorded in the fixture) = the last block here; a plain
+    nn.Linear qkv ([B, N, 3 D]) gives the same features; freeze_feature_extractor (237-255) with substrings and regexes."""
+    from tiny_vit import TinyQKVViT
+    from hbird_mi.models import FeatureExtractor
+    g = np.load(os.path.join(golden_dir, "g9_feature_extractor.npz"))
+    assert str(g["backend"]) == "generic" and str(g["default_layer_raises"]) == "RuntimeError"
+    imgs = torch.from_numpy(g["imgs"])
+    vit = TinyQKVViT(seed=5).eval()
+    fe = FeatureExtractor(vit, eval_spatial_resolution=4, d_model=16)
+    assert fe.backend == "generic" and fe.device == torch.device("cpu")
+    for feat in "qkv":
+        for layer in (0, 1):
+            f, att = fe.get_intermediate_layer_feats(imgs, feat=feat, layer_num=layer)
+            assert att is None and np.array_equal(f.numpy(), g[f"feats_{feat}_{layer}"]), (feat, layer)
+        f, att = fe.forward_features(imgs, feat=feat)                     # layer -1 = the last block
+        assert att is None and f.dtype == torch.float32 and np.array_equal(f.numpy(), g[f"feats_{feat}_1"])
+        f2, _ = FeatureExtractor(TinyQKVViT(seed=5, flat=True).eval(), 4, 16).forward_features(imgs, feat=feat)
+        assert np.array_equal(f2.numpy(), g[f"feats_{feat}_1"])
+    assert np.array_equal(fe(imgs)[0].numpy(), g["feats_k_1"])          # "k" is the default (models.py:164)
+    with pytest.raises(RuntimeError, match="qkv module not found"):
+        fe.get_intermediate_layer_feats(imgs, layer_num=7)
+    fe.freeze_feature_extractor(["blocks.1.attn"])
+    assert sorted(n for n, p in vit.named_parameters() if p.requires_grad) == list(g["trainable_after_freeze"])
+    fe.freeze_feature_extractor([r"blocks\.0\..*bias$"], regex=True)
+    assert sorted(n for n, p in vit.named_parameters() if p.requires_grad) == list(g["trainable_after_regex_freeze"])
+    fe.freeze_feature_extractor()
+    assert not any(p.requires_grad for p in vit.parameters())
 
 
 def test_coco_stuff_and_cityscapes_folder(tmp_path):
@@ -257,7 +295,7 @@ def test_c_abi_rejects_a_null_handle_without_a_gpu():
         "hb_index_set_score_output": (None, 1), "hb_index_distances_from_scores": (None, None, 1, 1, None),
         "hb_index_set_timing": (None, 1), "hb_index_last_knn_ms": (None, ctypes.byref(ms)),
         "hb_index_set_tuning": (None, 0, 0), "hb_index_last_fp16_fallbacks": (None, ctypes.byref(n64)),
-        "hb_index_set_variant": (None, 0), "hb_index_schedule_info": (None, info), "hb_index_set_cluster": (None, 2, 2, 16),
+        "hb_index_set_variant": (None, 0), "hb_index_schedule_info": (None, info), "hb_index_set_cluster": (None, 2, 2, 16), "hb_index_set_cluster_sharing": (None, 2),
         "hb_index_cluster_stats": (None, info),
     }
     for name, args in calls.items():

@@ -405,8 +405,9 @@ def test_reference_named_backends(cuda_device):
 
 
 def test_headline_size_10m_x_768(cuda_device):
-    """BASELINE.json's headline shape (10 M x 768 bank, 21,904-query batch, k = 30): planted neighbours,
-    sortedness, determinism, sharding invariance and an independent float64 check of 16 queries against ALL rows."""
+    """BASELINE.json's headline shape (10 M x 768 bank, 21,904-query batch, k = 30): planted neighbours, sortedness, determinism,
+    sharding invariance, the fp32 chain oracle BIT FOR BIT on 32 queries against all rows (the automatic clustered kernel that the
+    bench times, and the use_fp16 path) and an independent float64 check of 16 queries."""
     M, D, nq, k = 10_000_000, 768, 21_904, 30
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(3)
@@ -442,6 +443,14 @@ def test_headline_size_10m_x_768(cuda_device):
     assert torch.equal(idx16, idx) and torch.equal(dist16, dist)
     assert ix.last_fp16_fallbacks() < nq // 100
     ix.set_fp16(False)
+    # the chain oracle at full size: the bank comes back in 1 M-row chunks, each searched by the oracle with its id base, merged on the host
+    from helpers import chain_oracle_topk_chunked
+    assert tuple(ix.schedule_info()["cluster"]) != (1, 1), "the headline search is expected to run on the clustered instantiation"
+    sel32 = torch.linspace(0, nq - 1, 32, device=dev).long()
+    ci, cd = chain_oracle_topk_chunked(ix, q[sel32], M, k)
+    for name, (gi_, gd_) in (("fp32 clustered", (idx, dist)), ("use_fp16", (idx16, dist16))):
+        assert np.array_equal(gi_[sel32].cpu().numpy(), ci), f"{name}: indices differ from the chain oracle at 10 M x 768"
+        assert np.array_equal(gd_[sel32].cpu().numpy().view(np.uint32), cd.view(np.uint32)), f"{name}: distance bits differ"
     # float64 scores of 16 queries against every bank row (chunked reconstruct), exact top-k by (score, id)
     sel = torch.tensor([0, 5, 127, 128, 1000, 5000, 9999, 12345, 15000, 17000, 19000, 20000, 21000, 21500, 21900, 21903],
                        device=dev)
