@@ -47,6 +47,13 @@ int hb_index_reserve(hb_index_t* ix, int64_t n_rows);
 int hb_index_add(hb_index_t* ix, const float* x, int64_t n, int x_on_device, int normalize);
 /* label_memory rows (hbird_eval.py:329, 354), co-indexed with the bank rows. */
 int hb_index_add_labels(hb_index_t* ix, const float* labels, int64_t n, int c, int on_device);
+/* Every label value of the reference is j / P, P = patch_size^2: one_hot(...).float().mean(dim=3) over the P pixels of a patch
+ * (hbird_eval.py:319-320, computed as (float)j / (float)P).  With a denominator set BEFORE the first label row, the index stores the
+ * uint16 count j instead of the fp32 value -- half the table (6.2 -> 3.1 GB at cfg-3) and half the aggregation's gather traffic --
+ * and hands back exactly the same fp32 values.  A value that is not such a multiple fails the next call that reads the labels.
+ * 0 (default) = fp32 storage. */
+int hb_index_set_label_denominator(hb_index_t* ix, int P);
+int hb_index_label_denominator(const hb_index_t* ix, int* P);
 int64_t hb_index_ntotal(const hb_index_t* ix);
 int64_t hb_index_nlabels(const hb_index_t* ix);
 /* Drop all rows and labels (keeps allocations). */
@@ -85,6 +92,11 @@ int hb_index_gather_labels(hb_index_t* ix, const int64_t* ids, int64_t n, int64_
 int hb_index_set_label_table(hb_index_t* ix, const float* labels, const float* norms, int64_t n, int c,
                              int64_t id_base);
 int hb_index_copy_norms(hb_index_t* ix, float* out, int on_device);
+/* The same for a table held as counts (hb_index_set_label_denominator): hb_index_copy_label_counts exports this shard's nlabels x c
+ * uint16 counts for the all-gather, hb_index_set_label_count_table borrows the gathered counts[n, c] / norms[n] of denominator P. */
+int hb_index_copy_label_counts(hb_index_t* ix, uint16_t* out, int on_device);
+int hb_index_set_label_count_table(hb_index_t* ix, const uint16_t* counts, const float* norms, int64_t n, int c, int P,
+                                   int64_t id_base);
 
 /* Sharded searches (faiss.IndexShards, search_faiss.py:53-63): with score output enabled a search returns the
  * ORDERING score in out_dist (inner product: q.b; L2: q.b - |b|^2/2; larger is better; missing neighbours -inf)

@@ -16,7 +16,12 @@
 // ordinary index.  Label-sharded aggregation (hb_index_aggregate_partial): the norms of ALL rows are replicated (4 B per row), the
 // label rows stay with their owners; every rank computes the same weights and the partial sum over the neighbours it owns, the
 // all-reduce of the partial sums is label_hat ("distributed softmax + all-reduce").
-__global__ __launch_bounds__(256) void aggregate_kernel(const float* __restrict__ labels, int64_t nlabels, int C,
+// Label rows come as fp32 values or (U16) as uint16 counts j of values j / P -- what K2 produces: (float)j / (float)P, so a table
+// of the P + 1 quotients in LDS gives the very same fp32 values at half the gather traffic and half the table in HBM (6.2 -> 3.1 GB
+// at cfg-3, per rank when the table is replicated); denominators beyond AGG_LUT entries divide in place (same rounding).
+#define AGG_LUT 2048
+template <bool U16>
+__global__ __launch_bounds__(256) void aggregate_kernel(const void* __restrict__ labels_v, int P, int64_t nlabels, int C,
                                                         const float* __restrict__ bnorm, int64_t norm_base, int64_t nnorm,
                                                         const float* __restrict__ qnorm,
                                                         const int64_t* __restrict__ idx,
@@ -25,8 +30,16 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const float* __restrict_
                                                         float beta, float* __restrict__ out) {
     __shared__ float s_w[4][AGG_MAX_K];
     __shared__ int64_t s_row[4][AGG_MAX_K];
+    __shared__ float s_lut[U16 ? AGG_LUT + 1 : 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t q = (int64_t)blockIdx.x * 4 + wv;
+    const float* labels = reinterpret_cast<const float*>(labels_v);
+    const unsigned short* counts = reinterpret_cast<const unsigned short*>(labels_v);
+    const float Pf = (float)P;
+    if (U16 && P <= AGG_LUT) {
+        for (int j = threadIdx.x; j <= P; j += 256) s_lut[j] = (float)j / Pf;
+        __syncthreads();
+    }
     if (q >= nq) return;   // whole wave exits together (no block-level barrier below)
     float* wgt = s_w[wv];
     int64_t* rows = s_row[wv];
@@ -65,7 +78,12 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const float* __restrict_
         if (c < C)
             for (int j = 0; j < k; ++j) {
                 const int64_t rj = rows[j];
-                if (rj >= 0) accv = fmaf(wgt[j] * inv, labels[rj * (int64_t)C + c], accv);
+                if (rj >= 0) {
+                    float lv;
+                    if (U16) { const int cnt = counts[rj * (int64_t)C + c]; lv = P <= AGG_LUT ? s_lut[cnt] : (float)cnt / Pf; }
+                    else lv = labels[rj * (int64_t)C + c];
+                    accv = fmaf(wgt[j] * inv, lv, accv);
+                }
             }
         if (c < C) out[q * (int64_t)C + c] = accv;
     }
@@ -75,19 +93,62 @@ int hb_launch_aggregate(const hb_index* ix, const float* qnorm, const int64_t* i
                         int k, int64_t id_base, float beta, float* out, hipStream_t s, const float* norms_all, int64_t n_all) {
     if (nq == 0) return 0;
     if (k > AGG_MAX_K) return hb_fail("hb_index_search_aggregate: k must be <= 256");
-    const float* labels = ix->labels; const float* bnorm = ix->bnorm; int64_t nlab = ix->nlabels;
+    const bool own16 = ix->label_P > 0;
+    const void* labels = own16 ? (const void*)ix->labels16 : (const void*)ix->labels;
+    const float* bnorm = ix->bnorm; int64_t nlab = ix->nlabels;
+    int P = ix->label_P;
+    const dim3 grid((unsigned)((nq + 3) / 4)), block(256);
     if (norms_all) {   // label-sharded: this index's own label rows, everybody's norms
-        if (!ix->labels || ix->nlabels < ix->ntotal) return hb_fail("hb_index_aggregate_partial: label rows missing (hb_index_add_labels)");
-        aggregate_kernel<<<dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s>>>(labels, ix->ntotal, ix->c, norms_all, 0, n_all, qnorm, idx, dist, nq, k,
-                                                                             id_base, ix->metric, ix->q_aux, beta, out);
+        if (!labels || ix->nlabels < ix->ntotal) return hb_fail("hb_index_aggregate_partial: label rows missing (hb_index_add_labels)");
+        if (own16) aggregate_kernel<true><<<grid, block, 0, s>>>(labels, P, ix->ntotal, ix->c, norms_all, 0, n_all, qnorm, idx, dist, nq, k, id_base, ix->metric, ix->q_aux, beta, out);
+        else aggregate_kernel<false><<<grid, block, 0, s>>>(labels, 0, ix->ntotal, ix->c, norms_all, 0, n_all, qnorm, idx, dist, nq, k, id_base, ix->metric, ix->q_aux, beta, out);
         HB_HIP(hipGetLastError());
         return 0;
     }
-    if (ix->ext_labels) { labels = ix->ext_labels; bnorm = ix->ext_bnorm; nlab = ix->ext_n; id_base = ix->ext_base; }
-    else if (!ix->labels || ix->nlabels < ix->ntotal) return hb_fail("hb_index_search_aggregate: label rows missing (hb_index_add_labels)");
-    aggregate_kernel<<<dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s>>>(labels, nlab, ix->c, bnorm, id_base, nlab, qnorm,
-                                                                         idx, dist, nq, k, id_base, ix->metric,
-                                                                         ix->q_aux, beta, out);
+    bool u16 = own16;
+    if (ix->ext_labels || ix->ext_labels16) {
+        u16 = ix->ext_labels16 != nullptr;
+        labels = u16 ? (const void*)ix->ext_labels16 : (const void*)ix->ext_labels; P = ix->ext_P;
+        bnorm = ix->ext_bnorm; nlab = ix->ext_n; id_base = ix->ext_base;
+    } else if (!labels || ix->nlabels < ix->ntotal) return hb_fail("hb_index_search_aggregate: label rows missing (hb_index_add_labels)");
+    if (u16) aggregate_kernel<true><<<grid, block, 0, s>>>(labels, P, nlab, ix->c, bnorm, id_base, nlab, qnorm, idx, dist, nq, k, id_base, ix->metric, ix->q_aux, beta, out);
+    else aggregate_kernel<false><<<grid, block, 0, s>>>(labels, 0, nlab, ix->c, bnorm, id_base, nlab, qnorm, idx, dist, nq, k, id_base, ix->metric, ix->q_aux, beta, out);
+    HB_HIP(hipGetLastError());
+    return 0;
+}
+
+// fp32 label values -> uint16 counts: j = round(v P); the stored j is exact iff (float)j / (float)P == v (every value K2 produces);
+// anything else raises the sticky flag (read once after the table grew: hb_labels_checked)
+__global__ __launch_bounds__(256) void labels_to_counts_kernel(const float* __restrict__ src, int64_t n, int P, unsigned short* __restrict__ dst,
+                                                               int* __restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = src[i], Pf = (float)P;
+    const float r = rintf(v * Pf);
+    const bool ok = r >= 0.0f && r <= Pf && r / Pf == v;
+    dst[i] = ok ? (unsigned short)r : 0;
+    if (!ok) *flag = 1;
+}
+
+int hb_launch_labels_to_counts(const float* src, int64_t n, int P, uint16_t* dst, int* flag, hipStream_t s) {
+    if (n == 0) return 0;
+    labels_to_counts_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(src, n, P, dst, flag);
+    HB_HIP(hipGetLastError());
+    return 0;
+}
+
+// out[i, :] = counts[ids[i], :] / P as fp32 (label_memory.index_select on a table stored as counts); ids outside the table give zeros
+__global__ __launch_bounds__(256) void gather_label_counts_kernel(const unsigned short* __restrict__ src, int64_t src_rows, int c, int P,
+                                                                  const int64_t* __restrict__ ids, int64_t n, float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * c) return;
+    const int64_t i = t / c, r = ids[i];
+    out[t] = (r >= 0 && r < src_rows) ? (float)src[r * c + (t % c)] / (float)P : 0.0f;
+}
+
+int hb_launch_gather_label_counts(const uint16_t* src, int64_t src_rows, int c, int P, const int64_t* ids, int64_t n, float* out, hipStream_t s) {
+    if (n == 0) return 0;
+    gather_label_counts_kernel<<<dim3((unsigned)((n * c + 255) / 256)), dim3(256), 0, s>>>(src, src_rows, c, P, ids, n, out);
     HB_HIP(hipGetLastError());
     return 0;
 }

@@ -85,7 +85,7 @@ extern "C" int hb_index_free(hb_index_t* ix) {
     (void)hipSetDevice(ix->device);
     (void)hipStreamSynchronize(ix->stream);
     void* ptrs[] = {ix->tiles, ix->binit, ix->bnorm, ix->labels, ix->q_tiles, ix->q_aux, ix->state, ix->sched_dev, ix->tmp,
-                    ix->tiles16, ix->q16, ix->cand, ix->bmax, ix->fb, ix->mtmp, ix->f16_flag};
+                    ix->tiles16, ix->q16, ix->cand, ix->bmax, ix->fb, ix->mtmp, ix->f16_flag, ix->labels16, ix->lab_flag};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ix->ev0) (void)hipEventDestroy(ix->ev0);
     if (ix->ev1) (void)hipEventDestroy(ix->ev1);
@@ -281,7 +281,8 @@ extern "C" int hb_index_reset(hb_index_t* ix) {
         HB_HIP(hipStreamSynchronize(s));
     }
     HB_HIP(hipMemsetAsync(ix->bmax, 0, 4, s));
-    ix->ntotal = 0; ix->nlabels = 0; ix->f16_rows = 0; ix->f16_overflow = 0;
+    ix->ntotal = 0; ix->nlabels = 0; ix->lab_checked = 0; ix->f16_rows = 0; ix->f16_overflow = 0;
+    if (ix->lab_flag) HB_HIP(hipMemsetAsync(ix->lab_flag, 0, 4, s));
     if (ix->f16_flag) HB_HIP(hipMemsetAsync(ix->f16_flag, 0, 4, s));
     return 0;
 }
@@ -324,6 +325,31 @@ extern "C" int hb_index_add(hb_index_t* ix, const float* x, int64_t n, int x_on_
     return 0;
 }
 
+extern "C" int hb_index_set_label_denominator(hb_index_t* ix, int P) {
+    if (!ix) return hb_fail("hb_index_set_label_denominator: NULL index handle");
+    if (P < 0 || P > 65535) return hb_fail("hb_index_set_label_denominator: the denominator must be in [0, 65535]");
+    if (ix->nlabels > 0 && P != ix->label_P) return hb_fail("hb_index_set_label_denominator: the index already holds label rows");
+    ix->label_P = P;
+    return 0;
+}
+extern "C" int hb_index_label_denominator(const hb_index_t* ix, int* P) {
+    if (!ix || !P) return hb_fail("hb_index_label_denominator: NULL pointer");
+    *P = ix->label_P;
+    return 0;
+}
+
+// one read-back (a stream synchronisation) after the label table grew: was every stored value a multiple of 1 / P?
+int hb_labels_checked(hb_index* ix) {
+    if (ix->label_P == 0 || ix->lab_checked >= ix->nlabels || !ix->lab_flag) return 0;
+    int bad = 0;
+    HB_HIP(hipMemcpyAsync(&bad, ix->lab_flag, 4, hipMemcpyDeviceToHost, ix->stream));
+    HB_HIP(hipStreamSynchronize(ix->stream));
+    if (bad) return hb_fail("label rows are not multiples of 1 / " + std::to_string(ix->label_P) +
+                            " (hb_index_set_label_denominator): store them as fp32 (denominator 0) instead");
+    ix->lab_checked = ix->nlabels;
+    return 0;
+}
+
 extern "C" int hb_index_add_labels(hb_index_t* ix, const float* labels, int64_t n, int c, int on_device) {
     if (!ix) return hb_fail("hb_index_add_labels: NULL index handle");
     if (n < 0 || c <= 0) return hb_fail("hb_index_add_labels: bad shape");
@@ -331,14 +357,31 @@ extern "C" int hb_index_add_labels(hb_index_t* ix, const float* labels, int64_t 
     HB_HIP(hipSetDevice(ix->device));
     if (ix->c != 0 && ix->c != c && ix->nlabels > 0) return hb_fail("hb_index_add_labels: class count changed");
     ix->c = c;
+    const size_t esz = ix->label_P ? 2 : 4;      // uint16 counts or fp32 values
     if (ix->nlabels + n > ix->lab_cap) {
         int64_t cap = std::max<int64_t>(ix->nlabels + n, std::max<int64_t>(ix->cap_rows, ix->lab_cap + ix->lab_cap / 2));
-        float* nl = nullptr;
-        HB_HIP(hipMalloc((void**)&nl, (size_t)cap * c * 4));
-        if (ix->nlabels > 0) HB_HIP(hipMemcpyAsync(nl, ix->labels, (size_t)ix->nlabels * c * 4, hipMemcpyDeviceToDevice, ix->stream));
+        char* nl = nullptr;
+        char* old = ix->label_P ? (char*)ix->labels16 : (char*)ix->labels;
+        HB_HIP(hipMalloc((void**)&nl, (size_t)cap * c * esz));
+        if (ix->nlabels > 0) HB_HIP(hipMemcpyAsync(nl, old, (size_t)ix->nlabels * c * esz, hipMemcpyDeviceToDevice, ix->stream));
         HB_HIP(hipStreamSynchronize(ix->stream));
-        if (ix->labels) HB_HIP(hipFree(ix->labels));
-        ix->labels = nl; ix->lab_cap = cap;
+        if (old) HB_HIP(hipFree(old));
+        if (ix->label_P) ix->labels16 = (uint16_t*)nl; else ix->labels = (float*)nl;
+        ix->lab_cap = cap;
+    }
+    if (ix->label_P) {
+        // values j / P (what K2 produces, hbird_eval.py:319-320) stored as the uint16 count j: half the table, the same fp32 value back
+        if (!ix->lab_flag) { HB_HIP(hipMalloc((void**)&ix->lab_flag, 4)); HB_HIP(hipMemsetAsync(ix->lab_flag, 0, 4, ix->stream)); }
+        const float* src = labels;
+        if (!on_device) {
+            if (grow((void**)&ix->tmp, &ix->tmp_bytes, (size_t)n * c * 4)) return -1;
+            if (stage_in(ix, labels, (size_t)n * c * 4, 0)) return -1;
+            src = (const float*)ix->tmp;
+        }
+        if (hb_launch_labels_to_counts(src, n * (int64_t)c, ix->label_P, ix->labels16 + ix->nlabels * (int64_t)c, ix->lab_flag, ix->stream)) return -1;
+        if (!on_device) HB_HIP(hipStreamSynchronize(ix->stream));
+        ix->nlabels += n;
+        return 0;
     }
     HB_HIP(hipMemcpyAsync(ix->labels + ix->nlabels * (int64_t)c, labels, (size_t)n * c * 4,
                           on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ix->stream));
@@ -415,7 +458,8 @@ extern "C" int hb_index_search_aggregate(hb_index_t* ix, const float* q, int64_t
     if (!ix) return hb_fail("hb_index_search_aggregate: NULL index handle");
     if (nq > 0 && !out_label_hat) return hb_fail("hb_index_search_aggregate: out_label_hat is NULL");
     if (!(beta > 0.f)) return hb_fail("hb_index_search_aggregate: beta must be positive");
-    if (!ix->ext_labels && (!ix->labels || ix->nlabels < ix->ntotal)) return hb_fail("hb_index_search_aggregate: label rows missing (hb_index_add_labels)");
+    if (!ix->ext_labels && !ix->ext_labels16 && ((!ix->labels && !ix->labels16) || ix->nlabels < ix->ntotal)) return hb_fail("hb_index_search_aggregate: label rows missing (hb_index_add_labels)");
+    if (hb_labels_checked(ix)) return -1;
     return search_impl(ix, q, nq, k, id_base, beta, out_label_hat, out_idx_opt, out_dist_opt, io_on_device, true);
 }
 
@@ -427,6 +471,7 @@ extern "C" int hb_index_aggregate(hb_index_t* ix, const float* q, int64_t nq, co
     if (!(beta > 0.f)) return hb_fail("hb_index_aggregate: beta must be positive");
     hb_range range("hbird:aggregate");
     HB_HIP(hipSetDevice(ix->device));
+    if (hb_labels_checked(ix)) return -1;
     if (grow((void**)&ix->q_aux, &ix->q_aux_bytes, (size_t)nq * 2 * 4)) return -1;
     if (hb_launch_query_aux(q, nq, ix->d, ix->q_aux, ix->q_aux + nq, ix->stream)) return -1;
     return hb_launch_aggregate(ix, ix->q_aux + nq, idx, dist, nq, k, id_base, beta, out_label_hat, ix->stream);
@@ -440,6 +485,7 @@ extern "C" int hb_index_aggregate_partial(hb_index_t* ix, const float* q, int64_
     if (!(beta > 0.f)) return hb_fail("hb_index_aggregate_partial: beta must be positive");
     hb_range range("hbird:aggregate_partial");
     HB_HIP(hipSetDevice(ix->device));
+    if (hb_labels_checked(ix)) return -1;
     if (ix->ntotal == 0) {   // an empty shard owns no neighbour: its partial sums are zero
         HB_HIP(hipMemsetAsync(out_partial, 0, (size_t)nq * ix->c * 4, ix->stream));
         return 0;
@@ -454,7 +500,8 @@ static int gather_impl(hb_index* ix, const int64_t* ids, int64_t n, int64_t id_b
     if (n == 0) return 0;
     HB_HIP(hipSetDevice(ix->device));
     const int width = labels ? ix->c : ix->d;
-    if (labels && !ix->labels) return hb_fail("hb_index_gather_labels: no labels stored");
+    if (labels && !ix->labels && !ix->labels16) return hb_fail("hb_index_gather_labels: no labels stored");
+    if (labels && hb_labels_checked(ix)) return -1;
     const int64_t* d_ids = ids;
     float* d_out = out;
     if (!io_on_device) {
@@ -467,7 +514,8 @@ static int gather_impl(hb_index* ix, const int64_t* ids, int64_t n, int64_t id_b
     if (labels) {
         // shift global ids to local rows inside the kernel via src offset: ids are global, rows local
         if (id_base != 0) return hb_fail("hb_index_gather_labels: id_base != 0 is not supported yet");
-        if (hb_launch_gather_rows(ix->labels, ix->nlabels, width, d_ids, n, d_out, ix->stream)) return -1;
+        if (ix->label_P ? hb_launch_gather_label_counts(ix->labels16, ix->nlabels, width, ix->label_P, d_ids, n, d_out, ix->stream)
+                        : hb_launch_gather_rows(ix->labels, ix->nlabels, width, d_ids, n, d_out, ix->stream)) return -1;
     } else {
         if (hb_launch_tiles_to_rows(ix->tiles, ix->g8, ix->d, d_ids, n, id_base, d_out, ix->stream)) return -1;
     }
@@ -493,8 +541,30 @@ extern "C" int hb_index_set_label_table(hb_index_t* ix, const float* labels, con
                                         int64_t id_base) {
     if (!ix) return hb_fail("hb_index_set_label_table: NULL index handle");
     if (labels && (!bnorm || n <= 0 || c <= 0)) return hb_fail("hb_index_set_label_table: bad arguments");
-    ix->ext_labels = labels; ix->ext_bnorm = bnorm; ix->ext_n = labels ? n : 0; ix->ext_base = labels ? id_base : 0;
+    ix->ext_labels = labels; ix->ext_labels16 = nullptr; ix->ext_P = 0;
+    ix->ext_bnorm = bnorm; ix->ext_n = labels ? n : 0; ix->ext_base = labels ? id_base : 0;
     if (labels) ix->c = c;
+    return 0;
+}
+
+extern "C" int hb_index_set_label_count_table(hb_index_t* ix, const uint16_t* counts, const float* bnorm, int64_t n, int c, int P,
+                                              int64_t id_base) {
+    if (!ix) return hb_fail("hb_index_set_label_count_table: NULL index handle");
+    if (counts && (!bnorm || n <= 0 || c <= 0 || P <= 0 || P > 65535)) return hb_fail("hb_index_set_label_count_table: bad arguments");
+    ix->ext_labels = nullptr; ix->ext_labels16 = counts; ix->ext_P = counts ? P : 0;
+    ix->ext_bnorm = bnorm; ix->ext_n = counts ? n : 0; ix->ext_base = counts ? id_base : 0;
+    if (counts) ix->c = c;
+    return 0;
+}
+
+extern "C" int hb_index_copy_label_counts(hb_index_t* ix, uint16_t* out, int on_device) {
+    if (!ix) return hb_fail("hb_index_copy_label_counts: NULL index handle");
+    if (ix->label_P == 0) return hb_fail("hb_index_copy_label_counts: the labels are stored as fp32 (hb_index_set_label_denominator)");
+    if (ix->nlabels == 0) return 0;
+    HB_HIP(hipSetDevice(ix->device));
+    if (hb_labels_checked(ix)) return -1;
+    HB_HIP(hipMemcpyAsync(out, ix->labels16, (size_t)ix->nlabels * ix->c * 2, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ix->stream));
+    if (!on_device) HB_HIP(hipStreamSynchronize(ix->stream));
     return 0;
 }
 

@@ -79,12 +79,17 @@ struct hb_index {
     float* tiles = nullptr;                // fragment-tiled bank  [cap_rows/32][g8][256]
     float* binit = nullptr;                // per-row accumulator init [cap_rows]
     float* bnorm = nullptr;                // per-row L2 norm (fp32)  [cap_rows]
-    float* labels = nullptr;               // [lab_cap][c]
+    float* labels = nullptr;               // [lab_cap][c] fp32 (label_P == 0) ...
+    uint16_t* labels16 = nullptr;          // ... or [lab_cap][c] uint16 counts j of values j / label_P (hb_index_set_label_denominator)
+    int label_P = 0;
+    int* lab_flag = nullptr;               // sticky device flag: a label value was not a multiple of 1 / label_P
+    int64_t lab_checked = 0;               // label rows whose conversion has been checked (one read-back after the table grew)
     int c = 0;
     int64_t nlabels = 0, lab_cap = 0;
     int num_cu = 256;
     // optional borrowed tables covering a GLOBAL id range (multi-GPU: all-gathered labels / norms)
     const float* ext_labels = nullptr; const float* ext_bnorm = nullptr; int64_t ext_n = 0, ext_base = 0;
+    const uint16_t* ext_labels16 = nullptr; int ext_P = 0;   // the borrowed label table as counts (hb_index_set_label_count_table)
     // search workspace (grown on demand, reused)
     float* q_tiles = nullptr; size_t q_tiles_bytes = 0;
     float* q_aux = nullptr; size_t q_aux_bytes = 0;      // qn2 (chain) and qnorm (fp32), 2*nq floats
@@ -152,6 +157,10 @@ int hb_knn_f16_launch(const knn16_args& args, int grid, int design, hipStream_t 
 int hb_knn_f16s_launch(const knn16_args& args, int grid, hipStream_t s);
 int hb_launch_tiles_to_f16s(const float* t32, int g8, _Float16* t16, int g32, int64_t n_row_tiles, int64_t rt0, int* overflow,
                             hipStream_t s);
+// label storage: fp32 values, or uint16 counts of values j / P (exactly the fp32 value: K2 computes (float)j / (float)P)
+int hb_launch_labels_to_counts(const float* src, int64_t n, int P, uint16_t* dst, int* flag, hipStream_t s);
+int hb_launch_gather_label_counts(const uint16_t* src, int64_t src_rows, int c, int P, const int64_t* ids, int64_t n, float* out, hipStream_t s);
+int hb_labels_checked(hb_index* ix);   // 0, or fails when a stored label was not a multiple of 1 / label_P
 int hb_launch_aggregate(const hb_index* ix, const float* qnorm, const int64_t* idx, const float* dist, int64_t nq,
                         int k, int64_t id_base, float beta, float* out, hipStream_t s, const float* norms_all = nullptr, int64_t n_all = 0);
 int hb_launch_merge_parts(const float* dist_parts, const int64_t* idx_parts, int parts, int64_t nq, int k, int metric,

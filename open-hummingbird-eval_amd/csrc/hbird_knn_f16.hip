@@ -252,7 +252,9 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
 #define F2_LDS_TOTAL (F2_CLWORDS + 64)
 static_assert(F2_LDS_TOTAL <= 160 * 1024, "LDS budget");
 
-// one 1 KiB LDS-DMA piece: global (wave-uniform 64-bit base + 32-bit lane offset) -> LDS (wave-uniform address in M0 + 16 * lane)
+// one 1 KiB LDS-DMA piece: global (wave-uniform 64-bit base + 32-bit lane offset) -> LDS (wave-uniform address in M0 + 16 * lane).
+// M0 is on the clobber list so that the compiler never assumes a value of its own survives the statement (hipcc notes that it will
+// not SAVE a reserved register around it -- nothing to save: -Wno-inline-asm in the Makefile).
 #define F2_DMA(SRC, LDS_ADDR, VOFF)                                                                                          \
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(VOFF), "s"(SRC), "s"(LDS_ADDR) : "memory", "m0");
 // a query-fragment load into registers (untracked by the compiler: the hand-counted vmcnt below names the registers it releases)
@@ -271,7 +273,8 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
     const int NS = g16 / 2;   // k32 stages per bank tile, a multiple of 4 (dp16 is a multiple of 128)
     const int myq = w * 32 + (lane & 31);
     const unsigned lane_off = (unsigned)lane * 16u;
-    const unsigned lds_w = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)w * 2048u;   // this wave's two pieces of a ring slot
+    const unsigned lds_0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned lds_w = lds_0 + (unsigned)w * 2048u;   // this wave's two pieces of a ring slot
     cl_sync cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + F2_CLWORDS);
 
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_end[blockIdx.x];   // this launch's share of the block's segments (phases: hb_launch_knn)
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
 #define F2_REQ_C(I) F2_DMA(bf, lds_w + slot_f + (I) * 1024u, lane_off + (I) * 1024u)
 #define F2_ADVANCE()                                                                                                         \
         {                                                                                                                    \
-            if (fks == 0 && w == 0) glds16(bi + lane * 4, smem + F2_BINIT + fpar);                                           \
+            if (fks == 0 && w == 0) F2_DMA(bi, lds_0 + F2_BINIT + fpar, lane_off)                                            \
             qf1 = qf;                                                                                                        \
             if (--left > 0) {                                                                                                \
                 qf += 2048; bf += 2048;                                                                                      \

@@ -120,6 +120,7 @@ class HbirdEvaluation:
         # being replicated on every rank (6.2 GB at BASELINE cfg-3, 16.7 GB for the full ADE20K bank); only the bank-row norms are
         # replicated (4 B per row) and every search ends in one more all-reduce of [queries, classes] partial sums
         self.label_shard = self.sharded and bool(nn_params.get("label_shard", False))
+        self.compress_labels = bool(nn_params.get("compress_labels", True))
         if self.world > 1:
             logger.warning("torch.distributed world of %d ranks: bank %s (nn_params['idx_shard']=%s)", self.world,
                            "row-sharded over the ranks" if self.sharded else "replicated on every rank", self.sharded)
@@ -202,6 +203,8 @@ class HbirdEvaluation:
                         if flat - 1 < own_lo:
                             rows_before_me += bs * S * S
                         continue
+                    if self.index.ntotal == 0:
+                        self._set_label_denominator(patch_size * patch_size)
                     # K2: `y[y == 255] = 0` (310) + patchify (317) + one-hot mean (319-320)
                     label = ops.patch_label_hist(y, patch_size, num_classes, map255=True)   # [bs,S,S,C]
                     if self.memory_size is None:
@@ -240,6 +243,34 @@ class HbirdEvaluation:
         self.id_base = rows_before_me if self.sharded else 0
         return self.index.ntotal
 
+    def _set_label_denominator(self, P: int) -> None:
+        """Every soft label is j / P, P = patch_size ** 2 (the mean of a one-hot over a patch's P pixels, hbird_eval.py:319-320): the
+        index keeps the uint16 count j instead of the fp32 value -- half the label table (6.2 -> 3.1 GB at cfg-3, per rank when it is
+        replicated) and half K5's gather traffic, the same fp32 values back.  nn_params["compress_labels"] = False keeps fp32."""
+        if self.compress_labels and 0 < int(P) <= 32767 and self.index.ntotal == 0 and self.index.label_denominator != int(P):
+            self.index.set_label_denominator(int(P))
+
+    @staticmethod
+    def _infer_label_denominator(lm: torch.Tensor) -> int:
+        """P of a stored label_memory (rows of j / P summing to 1), or 0: the smallest positive value of a sample suggests 1 / P, the whole
+        tensor is then checked exactly (chunked) -- a table that is not of that form stays fp32."""
+        if lm.numel() == 0:
+            return 0
+        head = lm[:4096].float()
+        pos = head[head > 0]
+        if pos.numel() == 0:
+            return 0
+        P = int(round(1.0 / float(pos.min())))
+        if not 0 < P <= 32767:
+            return 0
+        for lo in range(0, lm.shape[0], 1 << 18):
+            v = lm[lo:lo + (1 << 18)].float()
+            Pt = torch.tensor(float(P))
+            c = torch.round(v * Pt)
+            if not bool(((c / Pt) == v).all()) or bool((c < 0).any()) or bool((c > P).any()):
+                return 0
+        return P
+
     def _tokens(self, x: torch.Tensor) -> torch.Tensor:
         feats, _ = self.feature_extractor.forward_features(x.to(self.device))    # (BS, N, D)
         return feats.to(self.gpu_device, dtype=torch.float32).contiguous()
@@ -262,11 +293,27 @@ class HbirdEvaluation:
         if self.label_shard:
             self._label_table = (None, norms)          # label rows stay with their owners
             return
+        # every rank agrees on the storage form (an empty shard never saw a batch: it takes the others' denominator)
+        pden = torch.tensor([self.index.label_denominator], dtype=torch.int64, device=self.gpu_device)
+        torch.distributed.all_reduce(pden, op=torch.distributed.ReduceOp.MAX)
+        P = int(pden.item())
+        if P > 0:      # the replicated table travels and stays as uint16 counts: half the bytes on the wire and per rank
+            if n_local == 0 and self.index.label_denominator != P:
+                self.index.set_label_denominator(P)
+            cnt_local = (self.index.copy_label_counts() if n_local
+                         else torch.zeros((0, self.num_classes), dtype=torch.int16, device=self.gpu_device))
+            cnt_all, _ = hdist.allgather_rows(cnt_local.contiguous().view(torch.uint8))      # bytes: gloo has no int16 collectives
+            counts_tab = torch.cat([cnt_all[r, :counts[r]] for r in range(self.world)]).contiguous().view(torch.int16)
+            self._label_table = (counts_tab, norms)
+            self._label_table_P = P
+            self.index.set_label_count_table(counts_tab, norms, P, 0)
+            return
         lab_local = (self.index.gather_labels(torch.arange(n_local, device=self.gpu_device)) if n_local
                      else torch.zeros((0, self.num_classes), device=self.gpu_device))
         lab_all, _ = hdist.allgather_rows(lab_local)
         labels = torch.cat([lab_all[r, :counts[r]] for r in range(self.world)]).contiguous()
         self._label_table = (labels, norms)
+        self._label_table_P = 0
         self.index.set_label_table(labels, norms, 0)
 
     # ------------------------------------------------------------------------------------------------
@@ -340,6 +387,9 @@ class HbirdEvaluation:
             lo, hi = hdist.shard_range(fm.shape[0], self.rank, self.world) if self.sharded else (0, fm.shape[0])
             with torch.cuda.device(self.gpu_device):
                 self.index.reset()
+                P = self._infer_label_denominator(lm) if self.compress_labels else 0
+                if P != self.index.label_denominator:
+                    self.index.set_label_denominator(P)
                 self.index.reserve(max(1, hi - lo))
                 self.index.add(fm[lo:hi].to(self.gpu_device), normalize=False)
                 self.index.add_labels(lm[lo:hi].to(self.gpu_device))
@@ -378,6 +428,17 @@ class HbirdEvaluation:
         lh = self.index.aggregate(q, idx, dist, beta=0.02, id_base=self.id_base)
         return lh.view(B, N, -1), idx, dist
 
+    def _replicated_label_rows(self, ids: torch.Tensor) -> torch.Tensor:
+        """label_memory.index_select(0, ids) (hbird_eval.py:633) on the table replicated over the ranks; ids outside it give zeros."""
+        tab = self._label_table[0]
+        if getattr(self, "_label_table_P", 0):      # uint16 counts -> the fp32 values (a float32 division: K2's own quotient)
+            ok = (ids >= 0) & (ids < tab.shape[0])
+            # (tensor divisor: a Python-scalar divisor becomes a multiplication by the reciprocal on the GPU -- another rounding)
+            out = tab[ids.clamp(0, max(0, tab.shape[0] - 1))].to(torch.float32) / torch.tensor(float(self._label_table_P), device=tab.device)
+            out[~ok] = 0.0
+            return out
+        return ops.gather_rows(tab, ids)
+
     def _gather_details(self, idx: torch.Tensor, B: int, N: int):
         k = idx.shape[1]
         flat = idx.reshape(-1)
@@ -386,7 +447,7 @@ class HbirdEvaluation:
             own = (flat >= self.id_base) & (flat < self.id_base + self.index.ntotal)
             kf = self.index.reconstruct(torch.where(own, flat, torch.full_like(flat, -1)), id_base=self.id_base)
             torch.distributed.all_reduce(kf)
-            kl = ops.gather_rows(self._label_table[0], flat)
+            kl = self._replicated_label_rows(flat)
         else:
             kf = self.index.reconstruct(flat)
             kl = self.index.gather_labels(flat)
@@ -517,7 +578,7 @@ class HbirdEvaluation:
                     label_hat = self.index.aggregate(q.contiguous(), my_idx, my_dist, beta=0.02).view(B, N, -1)
                 if want_details:
                     kl = (kl_all[lo:lo + q.shape[0]].reshape(B, N, k, -1) if self.label_shard
-                          else ops.gather_rows(self._label_table[0], my_idx.reshape(-1)).view(B, N, k, -1))
+                          else self._replicated_label_rows(my_idx.reshape(-1)).view(B, N, k, -1))
                     knns.append(kf_all[lo:lo + q.shape[0]].reshape(B, N, k, D).cpu())
                     knns_labels.append(kl.cpu())
                     knns_ca_labels.append(label_hat.cpu())

@@ -208,6 +208,34 @@ class HipFlatIndex:
             _lib.check(_lib.lib().hb_index_copy_norms(self._h, _ptr(out), 1))
         return out
 
+    def set_label_denominator(self, P: int):
+        """Every label value is j / P (P = patch_size ** 2: one_hot(...).mean over a patch's P pixels, hbird_eval.py:319-320): the
+        index then stores the uint16 counts j -- half the table -- and hands back the same fp32 values.  Before the first label row."""
+        _lib.check(_lib.lib().hb_index_set_label_denominator(self._h, int(P)))
+
+    @property
+    def label_denominator(self) -> int:
+        P = ctypes.c_int(0)
+        _lib.check(_lib.lib().hb_index_label_denominator(self._h, ctypes.byref(P)))
+        return int(P.value)
+
+    def copy_label_counts(self) -> torch.Tensor:
+        """This shard's label rows as counts: int16 tensor [nlabels, C] holding the uint16 bit patterns (CUDA)."""
+        n = int(_lib.lib().hb_index_nlabels(self._h))
+        out = torch.empty((n, self.num_classes), dtype=torch.int16, device=torch.device("cuda", self.device))
+        if n:
+            _lib.check(_lib.lib().hb_index_copy_label_counts(self._h, _ptr(out), 1))
+        return out
+
+    def set_label_count_table(self, counts: torch.Tensor, norms: torch.Tensor, P: int, id_base: int = 0):
+        """set_label_table for a table held as counts (int16 tensor of uint16 bit patterns, denominator P)."""
+        counts = counts.contiguous(); norms = norms.contiguous().float()
+        assert counts.is_cuda and norms.is_cuda and counts.dtype == torch.int16 and counts.shape[0] == norms.shape[0]
+        self._tables = (counts, norms)     # keep alive: the index only borrows the pointers
+        self._c = int(counts.shape[1])
+        _lib.check(_lib.lib().hb_index_set_label_count_table(self._h, _ptr(counts), _ptr(norms), counts.shape[0], counts.shape[1],
+                                                             int(P), int(id_base)))
+
     def set_label_table(self, labels: Optional[torch.Tensor], norms: Optional[torch.Tensor], id_base: int = 0):
         """Borrow all-gathered label / norm tables that cover global ids [id_base, id_base + n)."""
         if labels is None:
@@ -310,6 +338,8 @@ class HipMultiIndex:
         self.home = torch.device("cuda", self.device)
         self.indexes = [HipFlatIndex(d, metric, g) for g in self.devices]
         self.agg = HipFlatIndex(d, metric, self.device)        # row-less handle: aggregation against the home tables
+        self._warned_no_plan = False
+        self._label_P = 0               # > 0: label rows are kept as int16 counts j of values j / P (set_label_denominator)
         self._quota = None              # shard mode: planned rows per shard (reserve); None = everything into the first
         self._labels = None             # [cap, C] on the home device, co-indexed with the global row ids
         self._nlab = 0
@@ -406,6 +436,13 @@ class HipMultiIndex:
             for i in range(len(self.indexes)):
                 self._put(i, x, normalize)
             return
+        if self._quota is None and len(self.indexes) > 1 and not self._warned_no_plan:
+            import warnings
+            warnings.warn("HipMultiIndex.add in shard mode without reserve(): no row plan exists, every row goes to the first GPU "
+                          f"(cuda:{self.devices[0]}) and the other {len(self.indexes) - 1} search empty shards -- correct results, "
+                          "nothing sharded.  Call reserve(total_rows) first (HbirdEvaluation does when the loader has a length or "
+                          "memory_size is set).", RuntimeWarning, stacklevel=2)
+            self._warned_no_plan = True
         lo = 0
         while lo < n:
             i = len(self.indexes) - 1
@@ -422,6 +459,18 @@ class HipMultiIndex:
             self._put(i, x[lo:lo + room], normalize)
             lo += room
 
+    def set_label_denominator(self, P: int):
+        """As HipFlatIndex.set_label_denominator: the home device's label table holds int16 counts (P <= 32767)."""
+        if self._nlab and int(P) != self._label_P:
+            raise RuntimeError("set_label_denominator: the index already holds label rows")
+        if not 0 <= int(P) <= 32767:
+            raise ValueError("set_label_denominator: P must be in [0, 32767]")
+        self._label_P = int(P)
+
+    @property
+    def label_denominator(self) -> int:
+        return self._label_P
+
     def add_labels(self, lab):
         """label_memory rows (hbird_eval.py:329, 354) of the rows just added, in global row order, on the home device."""
         if not isinstance(lab, torch.Tensor):
@@ -430,14 +479,24 @@ class HipMultiIndex:
         n, c = lab.shape
         self._c = int(c)
         need = self._nlab + n
+        dt = torch.int16 if self._label_P else torch.float32
         if self._labels is None or self._labels.shape[0] < need or self._labels.shape[1] != c:
             planned = (self._quota * len(self.indexes)) if (self.shard and self._quota) else 0
             cap = max(need, planned, 0 if self._labels is None else self._labels.shape[0] * 3 // 2)
-            grown = torch.empty((cap, c), dtype=torch.float32, device=self.home)
+            grown = torch.empty((cap, c), dtype=dt, device=self.home)
             if self._nlab:
                 grown[:self._nlab] = self._labels[:self._nlab]
             self._labels = grown
-        self._labels[self._nlab:need] = lab.to(self.home)
+        lab = lab.to(self.home)
+        if self._label_P:
+            # (a 0-dim TENSOR divisor: torch turns a division by a Python scalar into a multiplication by its reciprocal on the GPU,
+            # which rounds differently from the (float)j / (float)P that K2 and the library compute)
+            Pt = torch.tensor(float(self._label_P), device=lab.device)
+            cnt = torch.round(lab * Pt)
+            if not bool(((cnt / Pt) == lab).all()):       # same exactness rule as the library (labels_to_counts_kernel)
+                raise RuntimeError(f"label rows are not multiples of 1 / {self._label_P} (set_label_denominator): store them as fp32 instead")
+            lab = cnt.to(torch.int16)
+        self._labels[self._nlab:need] = lab
         self._nlab = need
         self._norms = None
 
@@ -461,7 +520,10 @@ class HipMultiIndex:
                         self._norms = self.indexes[0].copy_norms()
                         torch.cuda.current_stream(self.home).synchronize()
                 if self._labels is not None and self._nlab >= n and n > 0:
-                    self.agg.set_label_table(self._labels[:n], self._norms, 0)
+                    if self._label_P:
+                        self.agg.set_label_count_table(self._labels[:n], self._norms, self._label_P, 0)
+                    else:
+                        self.agg.set_label_table(self._labels[:n], self._norms, 0)
         return (None if self._labels is None else self._labels[:self.ntotal]), self._norms
 
     def copy_norms(self) -> torch.Tensor:
@@ -485,6 +547,11 @@ class HipMultiIndex:
         bases = self.shard_bases
         # q is complete before other devices' streams (and the workers' own streams on q's device) read it
         torch.cuda.current_stream(q.device).synchronize()
+        # ... and so is every index: the workers run on THEIR threads' current streams (the default streams), while add() / peer
+        # copies were enqueued on the CALLER's current stream of each device -- not the same when the bank was built under a
+        # torch.cuda.stream(...) context
+        for d in set(self.devices):
+            torch.cuda.current_stream(torch.device("cuda", d)).synchronize()
 
         def run(i):
             index, dev = self.indexes[i], torch.device("cuda", self.devices[i])
@@ -586,7 +653,12 @@ class HipMultiIndex:
         host = not (isinstance(ids, torch.Tensor) and ids.is_cuda)
         ids_h = (torch.as_tensor(np.asarray(ids)) if host else ids).to(self.home).to(torch.int64).contiguous().view(-1)
         with torch.cuda.device(self.home):
-            out = ops.gather_rows(self._labels[:self._nlab], ids_h)
+            if self._label_P:       # counts -> the fp32 values (float32 division: the very quotient K2 computed)
+                ok = (ids_h >= 0) & (ids_h < self._nlab)
+                out = self._labels[:self._nlab][ids_h.clamp(0, max(0, self._nlab - 1))].to(torch.float32) / torch.tensor(float(self._label_P), device=self.home)
+                out[~ok] = 0.0
+            else:
+                out = ops.gather_rows(self._labels[:self._nlab], ids_h)
         return out.cpu().numpy() if host else out
 
     def set_label_table(self, labels, norms, id_base: int = 0):

@@ -103,6 +103,55 @@ def test_k5_aggregate_golden_g3(cuda_device, golden_dir):
         assert np.abs(out - oracle.cross_attention(q, k, v)).max() < 2e-5
 
 
+@pytest.mark.parametrize("P,C", [(196, 21), (256, 151), (4096, 19)])
+def test_label_table_as_counts_returns_the_fp32_bits(cuda_device, golden_dir, P, C):
+    """hb_index_set_label_denominator: label rows j / P (hbird_eval.py:319-320) stored as uint16 counts.  Everything that reads the table
+    -- the fused search + aggregation, the aggregation alone, the label-sharded partial sums, gather_labels, a borrowed count table --
+    returns the bits of the fp32 table (P = 4096 is beyond the kernel's LDS quotient table: in-place division); the G2 fixture's values
+    (the reference's own one_hot means) convert without loss; a value that is no multiple of 1 / P fails the next read."""
+    M, D, nq, k = 6000, 64, 500, 30
+    bank = gi.unit_bank(M, D, seed=3)
+    lab = gi.labels_from_masks(M, C, P, seed=4)
+    q = torch.from_numpy(gi.vit_like_queries(nq, D, seed=5)).cuda()
+    a, b = HipFlatIndex(D, 0, 0), HipFlatIndex(D, 0, 0)
+    b.set_label_denominator(P)
+    assert a.label_denominator == 0 and b.label_denominator == P
+    for ix in (a, b):
+        ix.add(torch.from_numpy(bank).cuda())
+        ix.add_labels(torch.from_numpy(lab[:2500]).cuda()); ix.add_labels(lab[2500:])      # device and host rows, a growth in between
+        ix.set_num_classes(C)
+    la, ia, da = a.search_aggregate(q, k, want_neighbours=True)
+    lb, ib, db = b.search_aggregate(q, k, want_neighbours=True)
+    assert torch.equal(ia, ib) and torch.equal(la.view(torch.int32), lb.view(torch.int32))
+    assert torch.equal(a.aggregate(q, ia, da).view(torch.int32), b.aggregate(q, ib, db).view(torch.int32))
+    ids = torch.tensor([0, 5, M - 1, 17, 17, -1, M + 3], device="cuda")
+    assert torch.equal(a.gather_labels(ids).view(torch.int32), b.gather_labels(ids).view(torch.int32))
+    assert np.array_equal(b.gather_labels(np.arange(M)).view(np.uint32), lab.view(np.uint32))
+    nrm = a.copy_norms()
+    pa = a.aggregate_partial(q, ia, da, nrm); pb = b.aggregate_partial(q, ib, db, nrm)
+    assert torch.equal(pa.view(torch.int32), pb.view(torch.int32))
+    cnt = b.copy_label_counts()
+    assert cnt.dtype == torch.int16 and tuple(cnt.shape) == (M, C)
+    assert np.array_equal(cnt.cpu().numpy().view(np.uint16).astype(np.float32) / np.float32(P), lab)
+    c = HipFlatIndex(D, 0, 0); c.set_label_count_table(cnt, nrm, P, 0)               # the replicated table of a sharded run
+    assert torch.equal(c.aggregate(q, ia, da).view(torch.int32), la.view(torch.int32))
+    with pytest.raises(RuntimeError, match="already holds label rows"):
+        b.set_label_denominator(P + 1)
+    bad = lab[:10].copy(); bad[3, 2] += 1e-4
+    d = HipFlatIndex(D, 0, 0); d.set_label_denominator(P)
+    d.add(torch.from_numpy(bank[:10]).cuda()); d.add_labels(torch.from_numpy(bad).cuda()); d.set_num_classes(C)
+    with pytest.raises(RuntimeError, match="not multiples of 1 /"):
+        d.search_aggregate(q[:4], 5)
+    g = np.load(f"{golden_dir}/g12_patchify_softlabels.npz")                         # the reference's own values
+    for name in "abc":
+        ref = g[f"label_{name}_{C if C in (21, 151) else 21}"]
+        ps = int(g[f"ps_{name}_{C if C in (21, 151) else 21}"])
+        e = HipFlatIndex(8, 0, 0); e.set_label_denominator(ps * ps)
+        rows = ref.reshape(-1, ref.shape[-1])
+        e.add(torch.zeros((rows.shape[0], 8)).cuda()); e.add_labels(rows); e.set_num_classes(rows.shape[1])
+        assert np.array_equal(e.gather_labels(np.arange(rows.shape[0])).view(np.uint32), rows.view(np.uint32))
+
+
 def test_k4_k5_fused_vs_oracle(cuda_device):
     M, D, C, nq, k = 30000, 384, 21, 500, 30
     bank = gi.unit_bank(M, D, seed=1)
