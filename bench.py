@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--workgroups", type=int, default=0)
     ap.add_argument("--panel", type=int, default=0)
     ap.add_argument("--fp16", action="store_true", help="use_fp16: fp16 candidate pass + exact fp32 re-rank")
-    ap.add_argument("--variant", type=int, default=0, help="kNN kernel variant (0: 8 waves, 1: 4 waves)")
+    ap.add_argument("--variant", type=int, default=0, help="kNN kernel variant for A/B runs (hb_index_set_variant: 0 default, 2 / 3 / 4 / 6)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: keep the exchange on the kNN stream even when "
                     "HBIRD_BENCH_OVERLAP=1 asks for the side stream (the default is the kNN stream anyway)")

@@ -178,7 +178,7 @@ int hb_confusion_update(const int64_t* gt, const int64_t* pred, int64_t n, int n
 /* When enabled, every search brackets the kNN kernel with HIP events on the handle's stream. */
 int hb_index_set_timing(hb_index_t* ix, int enable);
 int hb_index_last_knn_ms(const hb_index_t* ix, double* ms);
-/* Overrides for tests: number of workgroups (0 = one per CU) and bank tiles per panel (0 = auto). */
+/* Overrides for tests: number of workgroups (0 = one per CU) and bank tiles per panel (0 = auto); negative values are errors. */
 int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_tiles);
 /* GpuIndexFlatConfig.useFloat16 (search_faiss.py:40): 1 = searches run an fp16 candidate pass (fp16 copies of the
  * fragment tiles, fp16 MFMA, k' >= 2k candidates) followed by an exact fp32 re-rank of the candidates, so the
@@ -190,14 +190,16 @@ int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_tiles);
 int hb_index_set_fp16(hb_index_t* ix, int enable);
 /* Number of queries of the last fp16-mode search that needed the exact fp32 re-search. */
 int hb_index_last_fp16_fallbacks(const hb_index_t* ix, int64_t* n);
-/* kNN kernel variant, for A/B runs and tests (same results): 0 = default; 1 = fp32 kernel with 4 waves per workgroup (one per
- * SIMD, 256 accumulator registers per lane); 2 = the first design of the fp16 candidate kernel (query fragments staged
- * through LDS); 3 = the fp32 kernel with register-resident query fragments wherever it applies (D padded to a
- * multiple of 32: what the default does too); 4 = never that kernel (both operands staged through LDS); 5 = the third design of
- * the fp16 candidate kernel (v_mfma_f32_16x16x32_f16 on fp16 blocks of 16 rows x 32 k; as fast as the default within the box-to-box
- * spread, kept for A/B); 6 = small fp32 searches with k <= 32 on sorted LDS lists as until round 3 (the default runs them on
- * phased candidate pools).  The environment variable HBIRD_KNN_VARIANT presets it for new handles. */
+/* kNN kernel variant, for A/B runs and tests (same results): 0 = default; 2 = the first design of the fp16 candidate kernel (query
+ * fragments staged through LDS; what pools beyond 256 entries run anyway); 3 = the fp32 kernel with register-resident query fragments
+ * wherever it applies (D padded to a multiple of 32: what the default does too); 4 = never that kernel (both operands staged through
+ * LDS); 6 = small fp32 searches with k <= 32 on sorted LDS lists as until round 3 (the default runs them on phased candidate pools).
+ * 1 (4-wave fp32 kernel) and 5 (16x16x32 fp16 kernel) no longer exist: same bits, not faster. */
 int hb_index_set_variant(hb_index_t* ix, int variant);
+/* Two more A/B switches (same results): phases = 0 launches a pool search (k > 32, use_fp16, small fp32 searches) once instead of in
+ * phases; small_limit_stages > 0 moves the size (k8 stages per workgroup) below which a search takes the small-search kernels (0 =
+ * the built-in 400,000). */
+int hb_index_set_search_options(hb_index_t* ix, int phases, int64_t small_limit_stages);
 /* Work-list statistics of the last search: out[0]=workgroups, [1]=segments, [2]=slots, [3]=panel tiles,
  * [4]=max slots per query tile, [5]=query tiles, [6]=bank tiles, [7]=cluster shape (query ways * 16 + bank ways). */
 int hb_index_schedule_info(const hb_index_t* ix, int64_t out[8]);

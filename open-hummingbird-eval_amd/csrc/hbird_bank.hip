@@ -50,12 +50,11 @@ int hb_launch_patch_label_hist(const int64_t* y, int64_t B, int H, int W, int ps
     int dev = 0;
     HB_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return hb_fail("hb_patch_label_hist: device index out of range");
-    int* err = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        if (!words[dev]) HB_HIP(hipMalloc((void**)&words[dev], 4));
-        err = words[dev];
-    }
+    // the mutex covers the whole clear + kernel + read-back: two calls on one device (other streams / threads) share the word, and one
+    // must not clear or read the other's flag; the call synchronises its stream anyway, so nothing is lost by serialising it
+    std::lock_guard<std::mutex> lock(mu);
+    if (!words[dev]) HB_HIP(hipMalloc((void**)&words[dev], 4));
+    int* err = words[dev];
     HB_HIP(hipMemsetAsync(err, 0, 4, s));
     patch_label_hist_kernel<<<dim3((unsigned)((np + 3) / 4)), dim3(256), (size_t)C * 16, s>>>(y, np, H, W, ps, C, map255, out, err);
     HB_HIP(hipGetLastError());

@@ -75,7 +75,6 @@ extern "C" int hb_index_create(int d, int metric, int device, hb_index_t** out) 
     HB_HIP(hipMemset(ix->bmax, 0, 4));
     HB_HIP(hipEventCreate(&ix->ev0));
     HB_HIP(hipEventCreate(&ix->ev1));
-    if (const char* v = getenv("HBIRD_KNN_VARIANT")) ix->variant = atoi(v) >= 0 && atoi(v) <= 6 ? atoi(v) : 0;   // A/B of kernel variants
     *out = ix;
     return 0;
 }
@@ -119,8 +118,7 @@ extern "C" int hb_index_last_knn_ms(const hb_index_t* ix, double* ms) {
 }
 extern "C" int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_tiles) {
     if (!ix) return hb_fail("hb_index_set_tuning: NULL index handle");
-    // workgroups < 0 selects a timing-only ablation variant (HB_ABLATION builds): bits = -workgroups
-    if (workgroups < 0) { ix->ablate = -workgroups; workgroups = 0; } else ix->ablate = 0;
+    if (workgroups < 0 || panel_tiles < 0) return hb_fail("hb_index_set_tuning: negative value");
     ix->force_G = workgroups; ix->force_panel = panel_tiles; ix->sched = hb_schedule(); return 0;
 }
 extern "C" int hb_index_set_fp16(hb_index_t* ix, int enable) {
@@ -222,7 +220,14 @@ extern "C" int hb_index_set_cluster(hb_index_t* ix, int cluster_q, int cluster_b
 extern "C" int hb_index_set_variant(hb_index_t* ix, int variant) {
     if (!ix) return hb_fail("hb_index_set_variant: NULL index handle");
     if (variant < 0 || variant > 6) return hb_fail("hb_index_set_variant: unknown kernel variant");
+    if (variant == 1 || variant == 5) return hb_fail("hb_index_set_variant: variants 1 (4-wave fp32 kernel) and 5 (16x16x32 fp16 kernel) were removed in round 4 (same bits, not faster)");
     ix->variant = variant;
+    return 0;
+}
+extern "C" int hb_index_set_search_options(hb_index_t* ix, int phases, int64_t small_limit_stages) {
+    if (!ix) return hb_fail("hb_index_set_search_options: NULL index handle");
+    if (small_limit_stages < 0) return hb_fail("hb_index_set_search_options: negative limit");
+    ix->phases_on = phases ? 1 : 0; ix->small_limit = small_limit_stages; ix->sched = hb_schedule();
     return 0;
 }
 extern "C" int hb_index_schedule_info(const hb_index_t* ix, int64_t out[8]) {

@@ -105,7 +105,6 @@ struct hb_index {
     // fp16 candidate mode (use_fp16): fp16 copies of the bank / query fragment tiles, candidate buffers
     int fp16 = 0, dp16 = 0;
     void* tiles16 = nullptr; int64_t f16_cap_rows = 0, f16_rows = 0;
-    int f16_layout = 0;                                  // block shape of tiles16: 0 = 32 rows x 16 k (first / second design), 1 = 16 rows x 32 k (third)
     int* f16_flag = nullptr; int f16_overflow = 0;       // a finite bank value overflowed fp16: the fp32 kernel serves this bank
     void* q16 = nullptr; size_t q16_bytes = 0;
     char* cand = nullptr; size_t cand_bytes = 0;
@@ -114,8 +113,9 @@ struct hb_index {
     char* fb = nullptr; size_t fb_bytes = 0;             // fallback workspace (uncertified queries)
     int64_t last_fp16_fallbacks = 0;
     int score_output = 0;                                // 1: searches return ordering scores instead of distances
-    int variant = 0;                                     // 0: 8-wave kernel, 1: 4-wave (one wave per SIMD) kernel
-    int ablate = 0;                                      // timing-only kernel ablation (HB_ABLATION builds)
+    int variant = 0;                                     // kernel selection for A/B runs and tests (hb_index_set_variant)
+    int phases_on = 1;                                   // pool searches are launched in phases (hb_index_set_search_options)
+    long long small_limit = 0;                           // stages per workgroup below which a search counts as small (0 = default)
     double last_knn_ms = 0.0;                            // HIP-event time of the last knn kernel launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int time_kernels = 0;
@@ -153,10 +153,6 @@ int hb_launch_scatter_rows(const int64_t* rows, int64_t n, int k, const int64_t*
                            int64_t* out_idx, float* out_dist, hipStream_t s);
 struct knn16_args;
 int hb_knn_f16_launch(const knn16_args& args, int grid, int design, hipStream_t s);
-// third design (hbird_knn_f16s.hip): v_mfma_f32_16x16x32_f16 on fp16 blocks of 16 rows x 32 k (their own conversion kernel)
-int hb_knn_f16s_launch(const knn16_args& args, int grid, hipStream_t s);
-int hb_launch_tiles_to_f16s(const float* t32, int g8, _Float16* t16, int g32, int64_t n_row_tiles, int64_t rt0, int* overflow,
-                            hipStream_t s);
 // label storage: fp32 values, or uint16 counts of values j / P (exactly the fp32 value: K2 computes (float)j / (float)P)
 int hb_launch_labels_to_counts(const float* src, int64_t n, int P, uint16_t* dst, int* flag, hipStream_t s);
 int hb_launch_gather_label_counts(const uint16_t* src, int64_t src_rows, int c, int P, const int64_t* ids, int64_t n, float* out, hipStream_t s);

@@ -28,12 +28,13 @@
 // between two MFMAs so that the 64-cycle matrix op ahead of it hides its issue.
 #define KN_MFMA(T, FR, B, S) acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(FR[(T) & 3][S], B[S], acc[T], 0, 0, 0);
 
-// ABL: timing-only ablation bits (results are garbage when != 0): 1 = no LDS-DMA in the steady state,
-// 2 = no fragment reads, 4 = no barrier / vmcnt wait, 8 = no epilogue.  Bit 512 is NOT an ablation: it adds the
-// radix-select cold start of a slot's first tile (exact; used for searches with few tiles per workgroup).
+// COLD: the small-search instantiation -- cold start of a slot's first tile, scan epilogue, per-tile exchange of threshold floors
+// (used for searches with few tiles per workgroup).
 // CL: support for L2-sharing clusters (strided segments, soft sync).  A separate instantiation: its extra scalar state
 // spilled SGPRs inside the stage loop of the pool (WIDE) instantiation (k = 90: +12 % kernel time).
-template <int ABL, bool WIDE, bool CL = false>
+// (The timing-only ablation instantiations of rounds 1-3 -- no copies / no fragment reads / no barrier / no epilogue -- and the
+// in-kernel counters of the small-search work are gone from the product: their numbers are in DESIGN.md and profiles/r01 - r03.)
+template <bool COLD, bool WIDE, bool CL = false>
 __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -51,10 +52,6 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
     if constexpr (CL) cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + KN_CLWORDS);
 
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_end[blockIdx.x];   // this launch's share of the block's segments (phases: hb_launch_knn)
-#ifdef KN_STAMPS
-    int kn_dbg[2] = {0, 0}, kn_tiles = 0; unsigned long long kn_epi = 0, kn_t0;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kn_t0) :: "memory");
-#endif
     // "everything before my first segment is done" (a member without any work: everything)
     if constexpr (CL) { if (w == 0) cl_publish(cs, seg_begin < seg_end ? a.segs[seg_begin].tile0 * g8 : 0x7FFFFFFF, lane); }
     for (int si = seg_begin; si < seg_end; ++si) {
@@ -87,28 +84,17 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
         // w, w+4).  Waves w and w+4 share a SIMD: when both stalled on a copy's issue at the same point of the
         // stage the matrix pipe idled; with one issuer per SIMD the partner keeps it fed (+3.1 % measured).
         auto issue_a = [&](int bt, int ks, int slot) {
-            if constexpr (ABL & 32) bt = bt & 7;   // timing only: 8 bank tiles, L2-resident
             const float* src = a.bank_tiles + ((size_t)(bt * 8 + w) * g8 + ks) * HB_BLK + lane * 4;
             if (w < 4) {
-                if constexpr (ABL & 256) {   // timing only: same global traffic into registers, no LDS writes
-                    f32x4 d0 = *reinterpret_cast<const f32x4*>(src), d1 = *reinterpret_cast<const f32x4*>(src + (size_t)4 * g8 * HB_BLK);
-                    asm volatile("" :: "v"(d0), "v"(d1));
-                } else {
-                    glds16(src, smem + slot * KN_SLOT_BYTES + w * 1024);
-                    glds16(src + (size_t)4 * g8 * HB_BLK, smem + slot * KN_SLOT_BYTES + (w + 4) * 1024);
-                }
+                glds16(src, smem + slot * KN_SLOT_BYTES + w * 1024);
+                glds16(src + (size_t)4 * g8 * HB_BLK, smem + slot * KN_SLOT_BYTES + (w + 4) * 1024);
             }
         };
         auto issue_b = [&](int bt, int ks, int slot) {
-            const float* src = ((ABL & 64) ? a.q_tiles + (size_t)w * g8 * HB_BLK + lane * 4 : qsrc) + (size_t)ks * HB_BLK;
+            const float* src = qsrc + (size_t)ks * HB_BLK;
             if (w < 4) {
-                if constexpr (ABL & 256) {
-                    f32x4 d0 = *reinterpret_cast<const f32x4*>(src), d1 = *reinterpret_cast<const f32x4*>(src + (size_t)4 * g8 * HB_BLK);
-                    asm volatile("" :: "v"(d0), "v"(d1));
-                } else {
-                    glds16(src, smem + slot * KN_SLOT_BYTES + 8192 + w * 1024);
-                    glds16(src + (size_t)4 * g8 * HB_BLK, smem + slot * KN_SLOT_BYTES + 8192 + (w + 4) * 1024);
-                }
+                glds16(src, smem + slot * KN_SLOT_BYTES + 8192 + w * 1024);
+                glds16(src + (size_t)4 * g8 * HB_BLK, smem + slot * KN_SLOT_BYTES + 8192 + (w + 4) * 1024);
             }
             if (ks == 0 && w == 0) glds16(a.binit + (size_t)bt * HB_BT + lane * 4, smem + KN_BINIT + (CL ? fpar : (bt & 1)) * 1024);
         };
@@ -137,17 +123,15 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
             fb = reinterpret_cast<const f32x4*>(smem + 8192)[w * 64 + lane];
         }
         for (int st = 0; st < total; ++st) {
-            if constexpr (!(ABL & 4)) {
-                if constexpr (!(ABL & 128)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // my copies of stage st+1 have landed (st+2 in flight)
-                __syncthreads();   // ... everyone's have; the slot of stage st-1 is free for stage st+3
-            }
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // my copies of stage st+1 have landed (st+2 in flight)
+            __syncthreads();   // ... everyone's have; the slot of stage st-1 is free for stage st+3
             int slot_n = slot_c + 1; if (slot_n == KN_RING) slot_n = 0;
             const f32x4* Ac = reinterpret_cast<const f32x4*>(smem + slot_c * KN_SLOT_BYTES) + lane;
             const f32x4* An = reinterpret_cast<const f32x4*>(smem + slot_n * KN_SLOT_BYTES) + lane;
             // small searches: the floors of this tile come in by LDS-DMA during its last four stages (older than the stage's copies:
             // the hand-counted vmcnt still holds; four stages of counted waits cover them) and are read at its end -- requested at
             // the tile's START they were one tile staler: 50,176 x 384 4.62 -> 4.53 ms on the kernel with register-resident fragments
-            if constexpr ((ABL & 512) && !WIDE) { if (ks == (g8 > 4 ? g8 - 4 : 0)) small_floor_request(a.qfl, a.gthr, seg, w, lane, qf, sc); }
+            if constexpr (COLD && !WIDE) { if (ks == (g8 > 4 ? g8 - 4 : 0)) small_floor_request(a.qfl, a.gthr, seg, w, lane, qf, sc); }
             if (ks == 0) {
                 const f32x4* bi = reinterpret_cast<const f32x4*>(smem + KN_BINIT + (CL ? cpar : (bt & 1)) * 1024);
 #pragma unroll
@@ -160,28 +144,28 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
                     }
             }
             // ---- X half: tiles 0-3, k-steps 0-3; fillers: the four Y fragments, the two LDS-DMA copies ----
-            KN_FENCE KN_MFMA(0, fa, fb, 0) KN_FENCE if constexpr (!(ABL & 2)) fy[0] = Ac[4 * 64];
-            KN_FENCE KN_MFMA(1, fa, fb, 0) KN_FENCE if constexpr (!(ABL & 2)) fy[1] = Ac[5 * 64];
-            KN_FENCE KN_MFMA(2, fa, fb, 0) KN_FENCE if constexpr (!(ABL & 2)) fy[2] = Ac[6 * 64];
-            KN_FENCE KN_MFMA(3, fa, fb, 0) KN_FENCE if constexpr (!(ABL & 2)) fy[3] = Ac[7 * 64];
+            KN_FENCE KN_MFMA(0, fa, fb, 0) KN_FENCE fy[0] = Ac[4 * 64];
+            KN_FENCE KN_MFMA(1, fa, fb, 0) KN_FENCE fy[1] = Ac[5 * 64];
+            KN_FENCE KN_MFMA(2, fa, fb, 0) KN_FENCE fy[2] = Ac[6 * 64];
+            KN_FENCE KN_MFMA(3, fa, fb, 0) KN_FENCE fy[3] = Ac[7 * 64];
             KN_FENCE KN_MFMA(0, fa, fb, 1) KN_MFMA(1, fa, fb, 1) KN_FENCE
             // cluster soft sync: wave 0 pays the issue of one more vector-memory instruction now and then (its SIMD partner
             // covers it like it covers the copies); issued AHEAD of the stage's copies, so the hand-counted vmcnt still holds
             if constexpr (CL) { if (w == 0) cl_tick(cs, clock0 + st, lane); }
-            if constexpr (!(ABL & 1)) issue_a(fbt, fks, slot_f);
+            issue_a(fbt, fks, slot_f);
             KN_FENCE KN_MFMA(2, fa, fb, 1) KN_MFMA(3, fa, fb, 1) KN_MFMA(0, fa, fb, 2) KN_MFMA(1, fa, fb, 2) KN_FENCE
-            if constexpr (!(ABL & 1)) issue_b(fbt, fks, slot_f);
+            issue_b(fbt, fks, slot_f);
             KN_FENCE KN_MFMA(2, fa, fb, 2) KN_MFMA(3, fa, fb, 2) KN_FENCE
             advance_fetch();
             KN_FENCE KN_MFMA(0, fa, fb, 3) KN_MFMA(1, fa, fb, 3) KN_MFMA(2, fa, fb, 3) KN_MFMA(3, fa, fb, 3) KN_FENCE
             fbk = fb;   // the Y half still needs this stage's query fragment
             // ---- Y half: tiles 4-7; fillers: the X fragments and the query fragment of stage st+1 ----
-            KN_FENCE KN_MFMA(4, fy, fbk, 0) KN_FENCE if constexpr (!(ABL & 2)) fa[0] = An[0 * 64];
-            KN_FENCE KN_MFMA(5, fy, fbk, 0) KN_FENCE if constexpr (!(ABL & 2)) fa[1] = An[1 * 64];
-            KN_FENCE KN_MFMA(6, fy, fbk, 0) KN_FENCE if constexpr (!(ABL & 2)) fa[2] = An[2 * 64];
-            KN_FENCE KN_MFMA(7, fy, fbk, 0) KN_FENCE if constexpr (!(ABL & 2)) fa[3] = An[3 * 64];
+            KN_FENCE KN_MFMA(4, fy, fbk, 0) KN_FENCE fa[0] = An[0 * 64];
+            KN_FENCE KN_MFMA(5, fy, fbk, 0) KN_FENCE fa[1] = An[1 * 64];
+            KN_FENCE KN_MFMA(6, fy, fbk, 0) KN_FENCE fa[2] = An[2 * 64];
+            KN_FENCE KN_MFMA(7, fy, fbk, 0) KN_FENCE fa[3] = An[3 * 64];
             KN_FENCE KN_MFMA(4, fy, fbk, 1) KN_FENCE
-            if constexpr (!(ABL & 2)) fb = reinterpret_cast<const f32x4*>(smem + slot_n * KN_SLOT_BYTES + 8192)[w * 64 + lane];
+            fb = reinterpret_cast<const f32x4*>(smem + slot_n * KN_SLOT_BYTES + 8192)[w * 64 + lane];
             KN_FENCE
             KN_MFMA(5, fy, fbk, 1) KN_MFMA(6, fy, fbk, 1) KN_MFMA(7, fy, fbk, 1)
             KN_MFMA(4, fy, fbk, 2) KN_MFMA(5, fy, fbk, 2) KN_MFMA(6, fy, fbk, 2) KN_MFMA(7, fy, fbk, 2)
@@ -189,46 +173,28 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
             KN_FENCE
             slot_c = slot_n;
             if (++ks == g8) {
-                if constexpr (!(ABL & 8)) {
-                    if constexpr (WIDE) {
-                        // the slot's pool pointers are derived HERE (from one scalar, laundered so that the compiler cannot
-                        // hoist them): kept live through the stage loop they crowd out the copy loop's own pointers, which
-                        // then come back from spilled SGPRs in every stage (k = 90: +10 % kernel time)
-                        int slot_ = seg.slot;
-                        asm volatile("" : "+s"(slot_));
-                        float* ps = a.state_s + (size_t)slot_ * HB_QT * klw;
-                        unsigned* pi = a.state_i + (size_t)slot_ * HB_QT * klw;
-                        tile_epilogue<true, true>(acc, thr, ps, pi, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
-                    }
-                    else {
-                        if constexpr (ABL & 512) {   // small searches: radix-select cold start (separate instantiation, see launcher)
-                            if (seg.first && bt == seg.b_tile0) thr = fmaxf(thr, cold_start_threshold(acc, k));
-                            // the floors requested four stages ago (waves 4-7 have nothing else in flight; waves 0-3 have passed
-                            // counted waits that cover them -- except in a one-stage tile, D <= 8)
-                            if (g8 < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 .Lfl_%=\n\ts_waitcnt vmcnt(0)\n.Lfl_%=:" :: "s"(w) : "memory", "scc");
-                            thr = fmaxf(thr, small_floor_read(seg, qf, sc, lane));
-                        }
-                        // small searches (few rows per slot -> many insertions per tile): scan + register queue; the big
-                        // ones keep the plain epilogue (insertions are rare there, and the scan's registers would spill)
-                        if constexpr (ABL & 512) {
-#ifdef KN_STAMPS   // diagnostic build (make varu UNIT=hbird_knn NAME=stamps EXTRA=-DKN_STAMPS): the small-search epilogue in numbers
-                            unsigned long long t0_, t1_;
-                            __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory"); __builtin_amdgcn_sched_barrier(0);
-                            list_epilogue_scan(acc, thr, lst_s, lst_i, w * 32, lane, k, (unsigned)bt, kn_dbg);
-                            __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_) :: "memory"); __builtin_amdgcn_sched_barrier(0);
-                            kn_epi += t1_ - t0_; ++kn_tiles;
-#else
-                            list_epilogue_scan(acc, thr, lst_s, lst_i, w * 32, lane, k, (unsigned)bt);
-#endif
-                            small_floor_publish(a.qfl, a.gthr, seg, lst_s, myq, k, thr, lane);
-                        } else tile_epilogue<!(ABL & 16), false>(acc, thr, lst_s, lst_i, sc, w * 32, lane, k, (unsigned)bt);
-                    }
-                }
-                else {
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) asm volatile("" :: "v"(acc[t]));
-                }
+                if constexpr (WIDE) {
+                    // the slot's pool pointers are derived HERE (from one scalar, laundered so that the compiler cannot
+                    // hoist them): kept live through the stage loop they crowd out the copy loop's own pointers, which
+                    // then come back from spilled SGPRs in every stage (k = 90: +10 % kernel time)
+                    int slot_ = seg.slot;
+                    asm volatile("" : "+s"(slot_));
+                    float* ps = a.state_s + (size_t)slot_ * HB_QT * klw;
+                    unsigned* pi = a.state_i + (size_t)slot_ * HB_QT * klw;
+                    tile_epilogue<true, true>(acc, thr, ps, pi, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
+                } else if constexpr (COLD) {
+                    // small searches: cold start of a slot's first tile (separate instantiation, see launcher)
+                    if (seg.first && bt == seg.b_tile0) thr = fmaxf(thr, cold_start_threshold(acc, k));
+                    // the floors requested four stages ago (waves 4-7 have nothing else in flight; waves 0-3 have passed
+                    // counted waits that cover them -- except in a one-stage tile, D <= 8)
+                    if (g8 < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 .Lfl_%=\n\ts_waitcnt vmcnt(0)\n.Lfl_%=:" :: "s"(w) : "memory", "scc");
+                    thr = fmaxf(thr, small_floor_read(seg, qf, sc, lane));
+                    // (few rows per slot -> many insertions per tile): scan + register queue; the big searches keep the plain
+                    // epilogue (insertions are rare there, and the scan's registers would spill)
+                    list_epilogue_scan(acc, thr, lst_s, lst_i, w * 32, lane, k, (unsigned)bt);
+                    small_floor_publish(a.qfl, a.gthr, seg, lst_s, myq, k, thr, lane);
+                } else tile_epilogue<true, false>(acc, thr, lst_s, lst_i, sc, w * 32, lane, k, (unsigned)bt);
                 ks = 0;
                 bt += bstride; if constexpr (CL) cpar ^= 1;
             }
@@ -244,19 +210,6 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
         __syncthreads();   // the ring is reused by the next segment's prologue
     }
     if constexpr (CL) cl_finish(cs, a.cl_stats, w == 0, lane);
-#ifdef KN_STAMPS
-    if constexpr ((ABL & 512) != 0) {
-        unsigned long long kn_t1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kn_t1) :: "memory");
-        // max / sum over the workgroups of (cycles, epilogue cycles, candidates) / 1024 through the statistics words of the
-        // cluster sync (hb_index_cluster_stats; no printf: 256 of them distort the timing)
-        if (lane == 0 && w == 0) {
-            atomicMax(a.cl_stats, (int)((kn_t1 - kn_t0) >> 10));
-            atomicAdd(a.cl_stats + 1, (int)((kn_t1 - kn_t0) >> 10));
-            atomicAdd(a.cl_stats + 2, (int)(kn_epi >> 10));
-            atomicAdd(a.cl_stats + 3, kn_dbg[1]);
-        }
-    }
-#endif
 }
 
 // ---- merge of the partial lists of one query: rank by counting over <= slots*k candidates --------
@@ -794,8 +747,15 @@ __global__ __launch_bounds__(256) void pool_floor_kernel(const float* __restrict
     // the first 256 gathered scores in registers (usually all of them): a round is then compares and ballots only
     const float r0 = lane < n ? cs[lane] : -INFINITY, r1 = 64 + lane < n ? cs[64 + lane] : -INFINITY;
     const float r2 = 128 + lane < n ? cs[128 + lane] : -INFINITY, r3 = 192 + lane < n ? cs[192 + lane] : -INFINITY;
+    const bool stretched = !(hi - mn <= 1e30f);   // an astronomically large score: halve the interval of the monotone keys (cold_start_threshold)
     for (int it = 0; it < 14; ++it) {
-        const float mid = 0.5f * lo + 0.5f * hi;
+        float mid = 0.5f * lo + 0.5f * hi;
+        if (stretched) {
+            const unsigned klo = pool_key(lo), khi = pool_key(hi);
+            unsigned km = klo + ((khi - klo) >> 1);
+            if (km == 0x7FFFFFFFu) km = 0x7FFFFFFEu;
+            mid = __builtin_bit_cast(float, (km & 0x80000000u) ? (km ^ 0x80000000u) : ~km);
+        }
         int c = __popcll(__ballot(r0 > mid)) + __popcll(__ballot(r1 > mid)) + __popcll(__ballot(r2 > mid)) + __popcll(__ballot(r3 > mid));
         for (int base = 256; base < n; base += 64) c += __popcll(__ballot(base + lane < n && cs[base + lane] > mid));
         if (c >= kk) lo = mid; else hi = mid;
@@ -815,12 +775,11 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // Same results either way.
     bool f16 = ix->fp16 != 0 && k <= 128 && (ix->fp16 == 1 || (ix->ntotal >= 16384 && ix->ntotal * nq >= ((int64_t)1 << 27)));
     // which candidate kernel: 2 = the second design (32x32x16 MFMA, register-resident query fragments: the default wherever its pools
-    // fit, k' <= 128, i.e. k <= 64), 1 = the first design (variant 2, and pools beyond 256 entries), 3 = the third design on
-    // v_mfma_f32_16x16x32_f16 (variant 5: same bits, not faster -- hbird_knn_f16s.hip)
+    // fit, k' <= 128, i.e. k <= 64), 1 = the first design (variant 2, and pools beyond 256 entries).  (A third design on
+    // v_mfma_f32_16x16x32_f16 -- same bits, same speed, rounds 3 / 4 -- was removed: profiles/r03/f16_mfma_shape_ab.md.)
     const int kc_f16 = std::min(256, std::max(64, (2 * k + 63) / 64 * 64));
     const int klw_f16 = std::min(HB_POOL_MAX, (std::max(2 * kc_f16, kc_f16 + 128) + 63) / 64 * 64);
-    const int f16_design = (ix->variant == 2 || klw_f16 > 256) ? 1 : (ix->variant == 5 ? 3 : 2);
-    const int f16_layout = f16_design == 3 ? 1 : 0;
+    const int f16_design = (ix->variant == 2 || klw_f16 > 256) ? 1 : 2;
     if (f16 && nq > 0 && ix->ntotal > 0) {
         // bring the fp16 copy of the bank fragment tiles up to date.  A finite value beyond the fp16 range (|x| > 65504) turns
         // into inf there and the scores into inf / NaN, which the exactness certificate cannot bound: such a bank stays on the
@@ -834,11 +793,9 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
             HB_HIP(hipMemsetAsync(ix->tiles16, 0, (size_t)ix->cap_rows * ix->dp16 * 2, s0));
             ix->f16_cap_rows = ix->cap_rows;
         }
-        if (ix->f16_layout != f16_layout) { ix->f16_rows = 0; ix->f16_layout = f16_layout; }   // the other kernel's block shape: convert again
         if (ix->f16_rows < ix->ntotal) {
             const int64_t rt0 = ix->f16_rows / 32, need_rt = (ix->ntotal + 31) / 32;
-            if (f16_layout ? hb_launch_tiles_to_f16s(ix->tiles, ix->g8, (_Float16*)ix->tiles16, ix->dp16 / 32, need_rt - rt0, rt0, ix->f16_flag, s0)
-                           : hb_launch_tiles_to_f16(ix->tiles, ix->g8, (_Float16*)ix->tiles16, ix->dp16 / 16, need_rt - rt0, rt0, ix->f16_flag, s0)) return -1;
+            if (hb_launch_tiles_to_f16(ix->tiles, ix->g8, (_Float16*)ix->tiles16, ix->dp16 / 16, need_rt - rt0, rt0, ix->f16_flag, s0)) return -1;
             ix->f16_rows = ix->ntotal;
             HB_HIP(hipMemcpyAsync(&ix->f16_overflow, ix->f16_flag, 4, hipMemcpyDeviceToHost, s0));
             HB_HIP(hipStreamSynchronize(s0));
@@ -855,11 +812,11 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // 573.5 / 571.5, 20 k x 384 x 784 queries 0.59 / 0.26, 100 k x 384 x 196 queries 0.61 / 0.26; k = 5 at 50,176 x 384 3.61 / 3.68 and
     // k = 1 at 200 k x 384 13.47 / 13.54 (few insertions anyway) -> from k = 8.  (Round 2 measured pools at 8.1 vs 5.0 ms for the first
     // of these: unphased, radix cold start, LDS walk.)  Variant 6 keeps the lists (A/B, tests).
-    static const long long small_limit = getenv("HBIRD_SMALL_LIMIT") ? atoll(getenv("HBIRD_SMALL_LIMIT")) : 400000;   // stages per workgroup
+    const long long small_limit = ix->small_limit > 0 ? ix->small_limit : 400000;   // stages per workgroup (hb_index_set_search_options)
     const int G0 = ix->force_G > 0 ? ix->force_G : ix->num_cu;
     const long long pairs0 = (long long)((nq + HB_QT - 1) / HB_QT) * ((ix->ntotal + HB_BT - 1) / HB_BT);
     const bool small_shape = pairs0 / std::max<long long>(1, std::min<long long>(G0, pairs0)) * ix->g8 < std::min<long long>(small_limit, 120000);   // no gain beyond (1.25 M x 768: 157 k stages)
-    const bool bd_shape = ix->g8 % 4 == 0 && !ix->ablate && ix->variant != 4;
+    const bool bd_shape = ix->g8 % 4 == 0 && ix->variant != 4;
     const bool small_pools = !f16 && k >= 8 && k <= HB_KL && small_shape && bd_shape && (ix->variant == 0 || ix->variant == 3) && ix->force_cq <= 1;
     const bool wide = f16 || k > HB_KL || small_pools;
     // pools (k > HB_KL): capacity >= 2 kc so that a compaction is paid for by >= kc cheap appends
@@ -894,7 +851,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // 2.5 M x 768 (157 k stages) 83.0 / 77.5, 5 M x 384 (157 k) 85.3 / 80.3, 1.25 M x 768 (79 k) 43.7 / 41.8, 5 M x 768 x 12,544 queries
     // (179 k; 49 query tiles: 4 x 2) 94.0 / 88.2 -- but 2,074,072 x 384 (37 k) 21.3 / 22.8: more slots, shorter segments
     // (profiles/r04/f16_cluster_threshold.txt)
-    else if (f16 && (ix->variant == 0 || ix->variant == 5) && ix->force_cq == 0) {
+    else if (f16 && ix->variant == 0 && ix->force_cq == 0) {
         if ((long long)nqt * nbt / std::max(1, G) * (ix->dp16 / 16) >= 70000) hb_default_cluster(nqt, nbt, G, false, &cq, &cb);
     }
     // fp32: only beside the kernel with register-resident query fragments (its sync is free of spills), and only for the
@@ -903,16 +860,15 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // (same box, kernel ms, none vs 2 x 4): 10 M x 768 2280 vs 2298 (+0.8 %), 5 M x 1024 1528 vs 1531 (+0.2 %), but
     // 1.25 M x 768 289.3 vs 293.9 (+1.6 %), 2 M x 384 142.3 vs 146.4 (+2.9 %): more slots, shorter segments.  Automatic from
     // one million stages per workgroup up (8 M rows at D = 768); hb_index_set_cluster(ix, 1, 1, 0) turns them off, (ix, 2, 4, -1) forces them.
-    else if (!f16 && !wide && ix->variant == 0 && ix->force_cq == 0 && !ix->ablate && ix->g8 % 4 == 0 &&
+    else if (!f16 && !wide && ix->variant == 0 && ix->force_cq == 0 && ix->g8 % 4 == 0 &&
              (long long)nqt * nbt / std::max(1, G) * ix->g8 >= 1000000)
         hb_default_cluster(nqt, nbt, G, true, &cq, &cb);
-    if (ix->variant == 1 || (long long)nqt * nbt < G || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
+    if ((long long)nqt * nbt < G || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
     const int panel = ix->force_panel > 0 ? ix->force_panel
                                           : hb_default_panel(nqt, std::min<long long>(G, (long long)nqt * nbt), tile_bytes, cq, cb);
     hb_schedule& sc = ix->sched;
-    // phased searches (pools only: "Phased searches" above hb_launch_knn); HBIRD_PHASES=0 turns them off (A/B)
-    static const bool phases_on = !(getenv("HBIRD_PHASES") && atoi(getenv("HBIRD_PHASES")) == 0);
-    const bool phased = wide && phases_on && ix->variant != 1;
+    // phased searches (pools only: "Phased searches" above hb_launch_knn); hb_index_set_search_options(ix, 0, ...) turns them off (A/B, tests)
+    const bool phased = wide && ix->phases_on;
     // XCD-level sharing of the query tiles (hb_build_clustered): automatic for the fp16 candidate kernel -- same box, 10 M x 768, 8 x 1
     // clusters: 302.7 -> 291.5 ms and 0.97 -> 0.52 TB of L2-miss traffic per search (L2 hit rate 0.60 -> 0.78); the fp32 kernel's 2 x 4
     // clusters lose 1.6 % with it (2298 -> 2334 ms: 1600 slots instead of 592, and its 768 KiB query tiles do not stay in L2 beside
@@ -977,10 +933,6 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     a.cl_stats = a.prog + (size_t)std::max(1, sc.n_clusters) * HB_CLUSTER_MAX * HB_CLUSTER_LINE;
     ix->cl_stats_dev = a.cl > 1 ? a.cl_stats : nullptr;
     if (a.cl > 1) HB_HIP(hipMemsetAsync(a.prog, 0, prog_bytes, s));
-#ifdef KN_STAMPS
-    ix->cl_stats_dev = a.cl_stats;
-    HB_HIP(hipMemsetAsync(a.prog, 0, prog_bytes, s));
-#endif
     // between two phases of a pool search: the kk-th best of all rows seen so far becomes every slot's floor -- straight from the pools
     // where a query tile's pools fit the floor kernel's LDS, else through the merge (few queries against a big bank: many slots)
     auto seed_floors = [&](int kk, int64_t* scratch_idx, float* scratch_dist) -> int {
@@ -1003,8 +955,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         // fp16 copy of the query fragment tiles (the bank's is up to date: top of this function)
         const int64_t nqp = (int64_t)nqt * HB_QT;
         if (ensure_bytes((char**)&ix->q16, &ix->q16_bytes, (size_t)nqp * ix->dp16 * 2)) return -1;
-        if (f16_layout ? hb_launch_tiles_to_f16s(ix->q_tiles, ix->g8, (_Float16*)ix->q16, ix->dp16 / 32, nqp / 32, 0, nullptr, s)
-                       : hb_launch_tiles_to_f16(ix->q_tiles, ix->g8, (_Float16*)ix->q16, ix->dp16 / 16, nqp / 32, 0, nullptr, s)) return -1;
+        if (hb_launch_tiles_to_f16(ix->q_tiles, ix->g8, (_Float16*)ix->q16, ix->dp16 / 16, nqp / 32, 0, nullptr, s)) return -1;
         if (ensure_bytes(&ix->cand, &ix->cand_bytes, (size_t)nq * kc * 12)) return -1;
         int64_t* cand_idx = reinterpret_cast<int64_t*>(ix->cand);
         float* cand_dist = reinterpret_cast<float*>(ix->cand + (size_t)nq * kc * 8);
@@ -1020,7 +971,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         }
         for (int ph = 0; ph < n_phases; ++ph) {
             h.wg_off = phase_begin(ph); h.wg_end = phase_end(ph);
-            if (f16_design == 3 ? hb_knn_f16s_launch(h, sc.G, s) : hb_knn_f16_launch(h, sc.G, f16_design, s)) return -1;
+            if (hb_knn_f16_launch(h, sc.G, f16_design, s)) return -1;
             if (ph + 1 < n_phases) {   // the k'-th best of all rows seen so far -> every slot's floor
                 if (seed_floors(kc, cand_idx, cand_dist)) return -1;
                 if (a.cl > 1) HB_HIP(hipMemsetAsync(a.prog, 0, prog_bytes - HB_CLUSTER_LINE * 4, s));   // progress words (not the statistics)
@@ -1080,41 +1031,23 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         return 0;
     }
     typedef void (*knn_fn)(knn_args);
-    static const knn_fn variants[] = {knn_fused_kernel<0, false>, knn_fused_kernel<0, true>,
-#ifdef HB_ABLATION
-                                      knn_fused_kernel<1, false>, knn_fused_kernel<2, false>, knn_fused_kernel<4, false>,
-                                      knn_fused_kernel<8, false>, knn_fused_kernel<15, false>, knn_fused_kernel<16, false>,
-                                      knn_fused_kernel<13, false>, knn_fused_kernel<14, false>, knn_fused_kernel<11, false>,
-                                      knn_fused_kernel<7, false>, knn_fused_kernel<3, false>, knn_fused_kernel<5, false>,
-                                      knn_fused_kernel<6, false>, knn_fused_kernel<9, false>, knn_fused_kernel<10, false>,
-                                      knn_fused_kernel<12, false>, knn_fused_kernel<32, false>, knn_fused_kernel<64, false>,
-                                      knn_fused_kernel<96, false>, knn_fused_kernel<128, false>, knn_fused_kernel<256, false>, knn_fused_kernel<384, false>
-#endif
-    };
-    static const int variant_bits[] = {0, -1, 1, 2, 4, 8, 15, 16, 13, 14, 11, 7, 3, 5, 6, 9, 10, 12, 32, 64, 96, 128, 256, 384};
-    knn_fn fn = variants[wide ? 1 : 0];
-    if (a.cl > 1) fn = wide ? (knn_fn)knn_fused_kernel<0, true, true> : (knn_fn)knn_fused_kernel<0, false, true>;
+    knn_fn fn = wide ? (knn_fn)knn_fused_kernel<false, true> : (knn_fn)knn_fused_kernel<false, false>;
+    if (a.cl > 1) fn = wide ? (knn_fn)knn_fused_kernel<false, true, true> : (knn_fn)knn_fused_kernel<false, false, true>;
     // Few stages per workgroup: a slot sees few rows, so its cold start (the first tile inserts all 256 rows of every
     // query) and its insertions (k ln(rows / k) per query) are a visible share of the search -> the instantiations with the
-    // radix-select cold start, the scan epilogue (register queue + immediate inserts) and the per-tile exchange of
+    // cold start, the scan epilogue (register queue + immediate inserts) and the per-tile exchange of
     // threshold floors (hbird_knn_dev.h: small_floor_*).  Same box, kernel ms, LDS-staged small / B-direct plain / B-direct small:
     // 50,176 x 384: 4.86 / 6.76 / 4.62 (round 1: 6.3; 0.49 -> 0.665 of the fp32 MFMA peak); 200 k x 384: 15.9 / 17.7 / 15.1;
     // 300 k x 768: 74.7 / 72.8 / 70.7; 2 M x 384: 149.3 / 143.1 / 142.3; 1.25 M x 768: 305.9 / 291.2 / 289.8; 2.5 M x 768 (315 k
     // stages per workgroup): 612.7 / 579.1 / 579.6 -> small below 400 k stages.  The big searches keep the plain
     // instantiations: at 10 M x 768 the extra code costs 0.3 % (same-box A/B).
-    static const knn_fn cold_fn = knn_fused_kernel<512, false>;
+    static const knn_fn cold_fn = knn_fused_kernel<true, false>;
     // lists: cold_fn / <false, false, COLD>; pools: <WIDE, false, COLD> -- for k > 32 only below 50 k stages (k = 90: 50,176 x 384 4.78 -> 4.45 ms,
     // k = 64 at 300 k x 768 41.9 -> 40.3, but 2,074,072 x 384 (74 k stages) 142.0 -> 142.7)
     const long long stages_per_wg = (long long)nqt * nbt / std::max(1, sc.G) * ix->g8;
     const bool small = !f16 && a.cl == 1 && stages_per_wg < (k > HB_KL ? std::min<long long>(small_limit, 50000) : small_limit);
     if (small && !wide) fn = cold_fn;
-    if (!wide && ix->ablate)
-        for (size_t i = 0; i < sizeof(variants) / sizeof(variants[0]); ++i) if (variant_bits[i] == ix->ablate) fn = variants[i];
-    int threads = HB_THREADS;
-    if (ix->variant == 1 && !wide) {   // the experimental 4-wave variant only has the LDS-list path
-        fn = hb_knn_w4_kernel(false);
-        threads = 256;
-    }
+    const int threads = HB_THREADS;
     int lds_bytes = fn == cold_fn ? KN_LDS_TOTAL_COLD : KN_LDS_TOTAL;
     // The query fragments straight into registers (hbird_knn_bd.hip): -3.8 % kernel time at 10 M x 768 (0.895 -> 0.93 of the
     // fp32 MFMA peak), same bits.  Default for the big LDS-list searches whose stage count per tile is a multiple of four

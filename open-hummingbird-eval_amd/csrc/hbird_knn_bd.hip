@@ -20,9 +20,7 @@
 #define BD_CLWORDS (BD_SCRATCH + 8192)       // landing zone of the cluster progress poll
 // Stages between two looks at the other cluster members.  Measured at 10 M x 768, 2 x 4, lag 16 (kernel ms over no clusters /
 // FETCH_SIZE x 2): every 16 stages +1.3 %, 32: +0.9 % / 1.93 TB, 64: +0.8 %, 128: +0.3 % / 1.97 TB, 256: +0.4 % / 2.12 TB.
-#ifndef BD_CL_PERIOD
 #define BD_CL_PERIOD 128
-#endif
 #define BD_LDS_TOTAL (BD_CLWORDS + 64)
 #define BD_QF BD_LDS_TOTAL                    // small-search instantiation: quota floors, 2 KiB per wave
 #define BD_LDS_TOTAL_COLD (BD_QF + 8 * 2048)
@@ -30,29 +28,15 @@
 #define BD_MFMA(T, FR, B, S) acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(FR[(T) & 3][S], B[S], acc[T], 0, 0, 0);
 // the two wave classes have different numbers of requests in flight: ONE statement with the branch inside, so that the
 // "+v" register is the same on both paths (hbird_knn_f16.hip: two statements in an if / else made hipcc copy it early)
-#ifdef BD_SYM
-#define BD_WAIT(N_ISSUER, N_OTHER, B) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(B) : "i"((N_ISSUER + N_OTHER) / 2) : "memory");
-#else
 #define BD_WAIT(N_ISSUER, N_OTHER, B)                                                                                   \
     asm volatile("s_cmp_lt_u32 %1, 4\n\ts_cbranch_scc1 .Lbdw_%=\n\ts_waitcnt vmcnt(" #N_OTHER ")\n\ts_branch .Lbdd_%=\n"  \
                  ".Lbdw_%=:\n\ts_waitcnt vmcnt(" #N_ISSUER ")\n.Lbdd_%=:"                                               \
                  : "+v"(B) : "s"(w) : "memory", "scc");
-#endif
-// timing-only ablation builds (results are garbage): make varu UNIT=hbird_knn_bd NAME=<tag> EXTRA=-DBD_ABL=<bits>
-//   1 no bank copies, 2 no query-fragment loads, 4 no epilogue, 8 no bank-fragment reads
-#ifndef BD_ABL
-#define BD_ABL 0
-#endif
-#if BD_ABL & 2
-#define BD_BLOAD(B) asm volatile("" : "+v"(B));
-#else
+// (Rounds 2 / 3 carried timing-only ablation builds of this loop -- no bank copies / no query-fragment loads / no epilogue / no
+// fragment reads -- and placement experiments -- every wave copying its own row tile, static wave priorities, the requests in the Y
+// half, floors requested at a tile's start: their numbers are in DESIGN.md section 4 and profiles/r02, the switches are gone.)
 #define BD_BLOAD(B) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(B) : "v"(lane_off), "s"(qsrc + (size_t)fks * 1024) : "memory");
-#endif
-#if BD_ABL & 8
-#define BD_RD(DST, SRC) asm volatile("" : "+v"(DST));
-#else
 #define BD_RD(DST, SRC) DST = SRC;
-#endif
 
 // WIDE: k > HB_KL, candidate pools in global memory; CL: member of an L2-sharing cluster (strided segments on a common
 // clock, soft sync from wave 0); COLD: small search (radix-select cold start, scan epilogue, per-tile floors) -- all as in
@@ -75,11 +59,6 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
     cl_sync cs;
     if constexpr (CL) cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + BD_CLWORDS);
 
-#if defined(BD_PRIO) && BD_PRIO == 1
-    if (w >= 4) __builtin_amdgcn_s_setprio(1);   // experiments: static priority for the later-dispatched half
-#elif defined(BD_PRIO) && BD_PRIO == 2
-    if (w < 4) __builtin_amdgcn_s_setprio(1);    // ... or for the copy-issuing half
-#endif
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_end[blockIdx.x];   // this launch's share of the block's segments (phases: hb_launch_knn)
     // "everything before my first segment is done" (a member without any work: everything)
     if constexpr (CL) { if (w == 0) cl_publish(cs, seg_begin < seg_end ? a.segs[seg_begin].tile0 * g8 : 0x7FFFFFFF, lane); }
@@ -109,16 +88,11 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
 
         // waves 0-3 copy the bank row tiles w and w + 4 of a stage (their SIMD partners 4-7 issue no copies, hbird_knn.hip)
         auto issue_a = [&](int bt, int ks, int slot) {
-#ifdef BD_SYM   // experiments: every wave copies its own row tile
-            const float* src = a.bank_tiles + ((size_t)(bt * 8 + w) * g8 + ks) * HB_BLK + lane * 4;
-            glds16(src, smem + slot * BD_SLOT + w * 1024);
-#else
-            if (w < 4 && !(BD_ABL & 1)) {
+            if (w < 4) {
                 const float* src = a.bank_tiles + ((size_t)(bt * 8 + w) * g8 + ks) * HB_BLK + lane * 4;
                 glds16(src, smem + slot * BD_SLOT + w * 1024);
                 glds16(src + (size_t)4 * g8 * HB_BLK, smem + slot * BD_SLOT + (w + 4) * 1024);
             }
-#endif
         };
         int bt = seg.b_tile0, ks = 0;          // tile / stage being computed
         int fbt = seg.b_tile0, fks = 0;        // next stage to fetch
@@ -144,38 +118,16 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
 #pragma unroll
             for (int t = 0; t < 4; ++t) fa[t] = A[t * 64 + lane];
         }
-        // where in the stage the requests are issued (experiments: -DBD_PLACE=1 query fragment in the Y half, 2 the bank pieces
-        // and the query fragment in the Y half; 5 M x 768, same box: 1149 / 1147 / 1161 ms -- no gain, the X half it is)
-#ifndef BD_PLACE
-#define BD_PLACE 0
-#endif
-#if BD_PLACE == 0
+        // the requests are issued in the X half of the stage (in the Y half: no gain, 5 M x 768 1149 / 1147 / 1161 ms)
 #define BD_REQ_X1 issue_a(fbt, fks, slot_f);
 #define BD_REQ_X2(U) BD_BLOAD(bq[((U) + 3) & 3])
 #define BD_REQ_X3 advance_fetch();
 #define BD_REQ_Y1(U)
 #define BD_REQ_Y2
-#elif BD_PLACE == 1
-#define BD_REQ_X1 issue_a(fbt, fks, slot_f);
-#define BD_REQ_X2(U)
-#define BD_REQ_X3
-#define BD_REQ_Y1(U) BD_BLOAD(bq[((U) + 3) & 3])
-#define BD_REQ_Y2 advance_fetch();
-#else
-#define BD_REQ_X1
-#define BD_REQ_X2(U)
-#define BD_REQ_X3
-#define BD_REQ_Y1(U) issue_a(fbt, fks, slot_f); BD_BLOAD(bq[((U) + 3) & 3])
-#define BD_REQ_Y2 advance_fetch();
-#endif
 // small searches: the floors are requested in the tile's LAST four stages (at its start they were one tile staler: 50,176 x 384
-// 4.62 -> 4.53 ms, 200 k x 384 15.12 -> 14.98; -DBD_FLOOR_EARLY for the A/B).  Four stages of counted waits cover the request for
+// 4.62 -> 4.53 ms, 200 k x 384 15.12 -> 14.98).  Four stages of counted waits cover the request for
 // waves 0-3, waves 4-7 wait for it explicitly before they read.
-#ifdef BD_FLOOR_EARLY
-#define BD_FLOOR_KS 0
-#else
 #define BD_FLOOR_KS (g8 - 4)
-#endif
 #define BD_STAGE(U)                                                                                                     \
         {                                                                                                               \
             BD_WAIT(3, 1, bq[((U) + 1) & 3])   /* stage st + 1 has landed for me (st + 2 in flight) ... */              \
@@ -227,10 +179,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
             BD_STAGE(0) BD_STAGE(1) BD_STAGE(2) BD_STAGE(3)
             ks += 4;
             if (ks == g8) {
-                if constexpr (BD_ABL & 4) {
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) asm volatile("" :: "v"(acc[t]));
-                } else if constexpr (WIDE) {
+                if constexpr (WIDE) {
                     // the slot's pool pointers are derived HERE from one laundered scalar (hbird_knn.hip: kept live through
                     // the stage loop they push the loop's own pointers into spilled SGPRs, reloaded in every stage)
                     const hb_seg* sp_ = HB_KARG(knn_args, segs) + si;     // boundary-only fields: read again where they are used

@@ -1,4 +1,4 @@
-// Device-side helpers shared by the kNN kernel variants (hbird_knn.hip, hbird_knn_w4.hip).
+// Device-side helpers shared by the kNN kernels (hbird_knn.hip, hbird_knn_bd.hip, hbird_knn_f16.hip).
 #pragma once
 #include "hbird_internal.h"
 
@@ -83,13 +83,9 @@ struct knn16_args {
 //    its SIMD partner stalled together idle the matrix pipe.  Issued by wave 0, which already pays that price for its
 //    copies and whose partner covers it, AHEAD of the stage's copies (so that the hand-counted vmcnt still holds):
 //    +1.9 % without any sharing, +0.3 % net with it.
-#ifndef HB_CL_PERIOD
 #define HB_CL_PERIOD 32
-#endif
-#ifndef HB_CL_SPINS
 #define HB_CL_SPINS 8192    // re-polls before a member gives up waiting (each about 0.5-1 us); 1024 let 20 of 256 members of the
                             // fp16 kernel give up during the slots' cold starts (10 M x 768: 330.8 -> 328.2 ms with 8192)
-#endif
 struct cl_sync {
     int* line;      // progress words of the cluster, one 128-B line per member
     int* lds;       // HB_CLUSTER_MAX words of LDS: landing zone of the poll
@@ -443,22 +439,12 @@ __device__ __forceinline__ float hb_max3(float a, float b, float c) {
 #define HB_BULK_QUADS 12
 template <int EMAX>
 __device__ __forceinline__ void pool_epilogue_scan(f32x16 (&acc)[8], float& thr, float* pool_s, unsigned* pool_i, float* sc, int qb,
-                                                   int lane, int k, unsigned bt, int klw, int* cnt, bool& bulk,
-                                                   unsigned long long* stamp_after_scan = nullptr /* diagnostic builds */) {
+                                                   int lane, int k, unsigned bt, int klw, int* cnt, bool& bulk) {
     if (!bulk) {
         float q0v = 0.f, q1v = 0.f, q2v = 0.f, q3v = 0.f;
         int q0c = 0, q1c = 0, q2c = 0, q3c = 0, np = 0;
         HB_SCAN_TILE(0) HB_SCAN_TILE(1) HB_SCAN_TILE(2) HB_SCAN_TILE(3) HB_SCAN_TILE(4) HB_SCAN_TILE(5) HB_SCAN_TILE(6) HB_SCAN_TILE(7)
-        if (stamp_after_scan) {
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(*stamp_after_scan) :: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
         if (__ballot(np != 0) == 0ull) return;
-#if defined(F16_ABL) && (F16_ABL & 512)
-        asm volatile("" :: "v"(q0v), "v"(q1v), "v"(q2v), "v"(q3v), "v"(q0c), "v"(q1c), "v"(q2c), "v"(q3c));   // timing only: no drain
-        return;
-#endif
         if (__ballot(np > 4) == 0ull) {
             pool_drain<EMAX>(np, q0v, q1v, q2v, q3v, q0c, q1c, q2c, q3c, thr, pool_s, pool_i, qb, lane, k,
                              bt * HB_BT + 4u * (unsigned)(lane >> 5), klw, cnt);
@@ -481,11 +467,6 @@ __device__ __forceinline__ void pool_epilogue_scan(f32x16 (&acc)[8], float& thr,
 // passed a threshold that is strict against rows of earlier tiles (lower ids), and list_insert compares the full key.
 // Measured at 50,176 x 384 (few rows per slot: 170 insertions per query and slot): the dump-and-walk path of
 // tile_epilogue spent 45 % of the kernel there.
-#ifdef KN_STAMPS   // diagnostic build: flagged quads and queued candidates per call
-#define HB_DBG_COUNT(VAR, N) VAR += (N);
-#else
-#define HB_DBG_COUNT(VAR, N)
-#endif
 #define HB_LIST_QUAD(T, Q)                                                                                   \
     {                                                                                                        \
         const float m_ = fmaxf(fmaxf(acc[T][4 * (Q)], acc[T][4 * (Q) + 1]), fmaxf(acc[T][4 * (Q) + 2], acc[T][4 * (Q) + 3])); \
@@ -493,7 +474,6 @@ __device__ __forceinline__ void pool_epilogue_scan(f32x16 (&acc)[8], float& thr,
             float q0v = 0.f, q1v = 0.f, q2v = 0.f, q3v = 0.f;                                                \
             int q0c = 0, q1c = 0, q2c = 0, q3c = 0, np = 0;                                                  \
             HB_SCAN_REG(T, 4 * (Q)) HB_SCAN_REG(T, 4 * (Q) + 1) HB_SCAN_REG(T, 4 * (Q) + 2) HB_SCAN_REG(T, 4 * (Q) + 3) \
-            HB_DBG_COUNT(dbg_quads, 1) HB_DBG_COUNT(dbg_cands, __popcll(__ballot(np > 0)) + __popcll(__ballot(np > 1)) + __popcll(__ballot(np > 2)) + __popcll(__ballot(np > 3))) \
             list_drain(lst_s, lst_i, qb, lane, k, row0, thr, np, q0v, q1v, q2v, q3v, q0c, q1c, q2c, q3c);    \
         }                                                                                                    \
     }
@@ -519,12 +499,9 @@ __device__ __forceinline__ void list_drain(float* lst_s, unsigned* lst_i, int qb
     }
 }
 __device__ __forceinline__ void list_epilogue_scan(f32x16 (&acc)[8], float& thr, float* lst_s, unsigned* lst_i, int qb, int lane,
-                                                   int k, unsigned bt, int* dbg = nullptr /* diagnostic builds */) {
+                                                   int k, unsigned bt) {
     const unsigned row0 = bt * HB_BT;
-    int dbg_quads = 0, dbg_cands = 0;
-    (void)dbg_quads; (void)dbg_cands;
     HB_LIST_TILE(0) HB_LIST_TILE(1) HB_LIST_TILE(2) HB_LIST_TILE(3) HB_LIST_TILE(4) HB_LIST_TILE(5) HB_LIST_TILE(6) HB_LIST_TILE(7)
-    if (dbg) { dbg[0] += dbg_quads; dbg[1] += dbg_cands; }
 }
 
 // ---- shared threshold floor ----------------------------------------------------------------------------------
@@ -647,9 +624,21 @@ __device__ __forceinline__ float cold_start_threshold(f32x16 (&acc)[8], int k) {
     // how compares and adds treat denormals -- a zero query scores 0 against every row)
     float lo = mn - fmaxf(fabsf(mn) * 1e-6f, 1.2e-38f);
     if (real < k) { lo = -INFINITY; hi = -INFINITY; }   // fewer than k real rows: the answer stays -inf
+    // An astronomically large score (a +inf or 1e30-sized outlier: an inf component in the query, unnormalised rows of huge norm under
+    // IP) stretches the interval so far that twelve LINEAR halvings never reach the bulk of the scores: lo would stay just below the
+    // minimum and the whole tile would pass (correct, but the slow path this function exists to avoid).  Such a query halves the
+    // interval of the monotone integer KEYS instead (the number of representable values between the ends, whatever their
+    // distribution; coarser for ordinary data, which keeps the linear midpoint).  Same loop, another midpoint per lane.
+    const bool stretched = !(hi - mn <= 1e30f);
 #pragma unroll 1
     for (int it = 0; it < 12; ++it) {
-        const float mid = 0.5f * lo + 0.5f * hi;
+        float mid = 0.5f * lo + 0.5f * hi;
+        if (stretched) {
+            const unsigned klo = pool_key(lo), khi = pool_key(hi);
+            unsigned km = klo + ((khi - klo) >> 1);
+            if (km == 0x7FFFFFFFu) km = 0x7FFFFFFEu;      // the key of -0.0, which compares equal to the +0.0 above it
+            mid = __builtin_bit_cast(float, (km & 0x80000000u) ? (km ^ 0x80000000u) : ~km);
+        }
         int c = 0;
 #pragma unroll
         for (int t = 0; t < 8; ++t)
@@ -674,6 +663,5 @@ __device__ __forceinline__ float cold_start_threshold(f32x16 (&acc)[8], int k) {
 #define KN_FENCE __builtin_amdgcn_sched_barrier(0);
 
 typedef void (*hb_knn_fn)(knn_args);
-hb_knn_fn hb_knn_w4_kernel(bool wide);   // 4-wave (one wave per SIMD) variant, hbird_knn_w4.hip
 hb_knn_fn hb_knn_bd_kernel(bool wide, bool clustered, bool small);   // query fragments straight into registers, hbird_knn_bd.hip
 int hb_knn_bd_lds_bytes(bool small);

@@ -115,14 +115,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
                 const int r = i >> 2, g = (i >> 1) & 1;
                 char* dst = smem + slot * F16_SLOT_BYTES + ((w + 4 * r) * F16_GROUPS + g) * 1024;
                 const size_t off = ((size_t)4 * r * g16 + ks * F16_GROUPS + g) * 1024;
-#if defined(F16_ABL) && (F16_ABL & 2)
-                bt &= 3;   // timing only: 4 bank tiles, L2-resident
-#endif
-#if defined(F16_ABL) && (F16_ABL & 8)
-                const char* qw = reinterpret_cast<const char*>(a.q16) + (size_t)w * g16 * 1024;   // timing only: one query tile for all
-#else
                 const char* qw = query_w;
-#endif
                 if (i & 1) __builtin_amdgcn_global_load_lds((gbl_cvoid*)(qw + off + lane_off), (lds_void*)(dst + F16_HALF), 16, 0, 0);
                 else __builtin_amdgcn_global_load_lds((gbl_cvoid*)(bank_w + (size_t)bt * 8 * g16 * 1024 + off + lane_off), (lds_void*)dst, 16, 0, 0);
             }
@@ -204,12 +197,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
                 KN_FENCE
                 slot_c = slot_n;
             }
-#if defined(F16_ABL) && (F16_ABL & 1)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) asm volatile("" :: "v"(acc[t]));   // timing only: no epilogue
-#else
             tile_epilogue<true, true>(acc, thr, wl_s, wl_i, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
-#endif
         }
 #undef F16_MM
         if (w == 0) cl_publish(cs, seg.next_tile0 == 0x7FFFFFFF ? 0x7FFFFFFF : seg.next_tile0 * NS, lane);   // covers idle units

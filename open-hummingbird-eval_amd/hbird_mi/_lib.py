@@ -80,6 +80,7 @@ SIGNATURES = {
     "hb_index_set_label_count_table": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64]),
     "hb_index_cluster_stats": (c_int, [c_void_p, POINTER(c_int64)]),
     "hb_index_set_variant": (c_int, [c_void_p, c_int]),
+    "hb_index_set_search_options": (c_int, [c_void_p, c_int, c_int64]),
     "hb_index_schedule_info": (c_int, [c_void_p, POINTER(c_int64)]),
 }
 

@@ -274,6 +274,10 @@ class HipFlatIndex:
     def set_variant(self, variant: int):
         _lib.check(_lib.lib().hb_index_set_variant(self._h, int(variant)))
 
+    def set_search_options(self, phases: bool = True, small_limit_stages: int = 0):
+        """A/B switches (same results): pool searches in one launch instead of phases; the size below which a search is "small"."""
+        _lib.check(_lib.lib().hb_index_set_search_options(self._h, int(bool(phases)), int(small_limit_stages)))
+
     def set_cluster(self, cluster_q: int = 0, cluster_b: int = 0, sync_lag: int = -1):
         """L2-sharing clusters of the work list (speed only, opt-in): 0 x 0 / 1 x 1 off, e.g. 2 x 2; sync_lag in stages."""
         _lib.check(_lib.lib().hb_index_set_cluster(self._h, int(cluster_q), int(cluster_b), int(sync_lag)))

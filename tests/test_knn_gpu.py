@@ -108,7 +108,7 @@ def test_cluster_soft_sync_holds_the_members_together(cuda_device):
     ix = HipFlatIndex(D, 0, 0)
     ix.add(bank)
     ref = ix.search(q, k)
-    for variant, fp16 in ((0, False), (4, False), (0, True), (5, True)):
+    for variant, fp16 in ((0, False), (4, False), (0, True)):
         ix.set_variant(variant); ix.set_fp16(fp16)
         for shape in ((2, 2, 16), (4, 1, 16), (2, 4, 16), (8, 1, 16)):
             ix.set_cluster(*shape)
@@ -354,19 +354,13 @@ def test_wide_k_aggregate(cuda_device):
     assert np.abs(out - oracle.cross_attention(q[None], kf, kl)[0]).max() < 2e-5
 
 
-@pytest.mark.parametrize("M,D,nq,k", [(5000, 64, 300, 30), (20000, 384, 520, 30), (3000, 32, 100, 90)])
-def test_four_wave_kernel_variant_bit_exact(cuda_device, M, D, nq, k):
-    """hb_index_set_variant(1): one wave per SIMD with 256 accumulator registers -- same results."""
-    bank = gi.unit_bank(M, D, seed=1)
-    q = gi.vit_like_queries(nq, D, seed=2)
-    ix = HipFlatIndex(D, 0, 0)
-    ix.add(bank)
-    ix.set_variant(1)
-    idx, dist = ix.search(q, k)
-    _check_exact(idx, dist, q, bank, k, "dot_product")
-    ix.set_tuning(5, 2)
-    idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
-    _check_exact(idx, dist, q, bank, k, "dot_product")
+def test_removed_kernel_variants_are_rejected(cuda_device):
+    """Variants 1 (4-wave fp32 kernel) and 5 (16x16x32 fp16 kernel) left the library in round 4 (same bits, not faster)."""
+    ix = HipFlatIndex(32, 0, 0)
+    for v in (1, 5, 7, -1):
+        with pytest.raises(RuntimeError):
+            ix.set_variant(v)
+    ix.set_variant(2); ix.set_variant(0)
 
 
 @pytest.mark.parametrize("variant", [3, 4, 6])   # 6: small searches on sorted LDS lists (the default runs them on pools since round 3)
@@ -495,9 +489,8 @@ def test_use_fp16_candidate_pass_with_exact_rerank(cuda_device, M, D, nq, k, met
     ix.add(bank[:100] * 0.5)                    # appending after a search re-converts the touched tiles
     idx, dist = ix.search(q, k)
     _check_exact(idx, dist, q, np.concatenate([bank, bank[:100] * 0.5]), k, metric)
-    # the other candidate kernels (2: first design, 5: 16x16x32 MFMA on its own fp16 block shape -- switching re-converts the
-    # bank copy) and back: the same bits
-    for variant in (5, 2, 5, 0):
+    # the other candidate kernel (2: first design, query fragments staged through LDS) and back: the same bits
+    for variant in (2, 0):
         ix.set_variant(variant)
         ix.set_tuning(0 if variant else 6, 0)
         idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
@@ -596,25 +589,25 @@ def test_repeatable_and_invariant_under_1_2_4_8_way_sharding(cuda_device, metric
 
 def test_phased_and_unphased_pool_searches_return_the_same_bits(cuda_device):
     """Pool searches (k > 32, use_fp16, small fp32 searches) are launched in phases whose boundaries hand every pool the union's k-th best
-    as a floor (hb_launch_knn); HBIRD_PHASES=0 (read once per process) runs them in one launch, HBIRD_KNN_VARIANT=6 keeps small fp32
-    searches on the sorted LDS lists.  Same ids and distances, bit for bit, in all three."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, torch, hashlib\n"
-        f"sys.path[:0] = [{os.path.join(root, 'open-hummingbird-eval_amd')!r}, {os.path.join(root, 'tests')!r}]\n"
-        "import golden_inputs as gi\n"
-        "from hbird_mi.nn.search_hip import HipFlatIndex\n"
-        "bank = gi.unit_bank(70001, 64, seed=5); q = torch.from_numpy(gi.vit_like_queries(1301, 64, seed=6)).cuda()\n"
-        "h = hashlib.sha256()\n"
-        "for k, fp16 in ((30, False), (90, False), (30, True)):\n"
-        "    ix = HipFlatIndex(64, 0, 0); ix.add(torch.from_numpy(bank).cuda()); ix.set_fp16(fp16)\n"
-        "    i, d = ix.search(q, k); h.update(i.cpu().numpy().tobytes()); h.update(d.cpu().numpy().tobytes())\n"
-        "print('DIGEST', h.hexdigest())\n")
-    digests = []
-    for extra in ({}, {"HBIRD_PHASES": "0"}, {"HBIRD_KNN_VARIANT": "6"}):
-        env = dict(os.environ); env.update(extra)
-        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-        assert out.returncode == 0, out.stderr[-2000:]
-        digests.append([l for l in out.stdout.splitlines() if l.startswith("DIGEST")][0])
-    assert digests[0] == digests[1] == digests[2]
+    as a floor (hb_launch_knn); hb_index_set_search_options(ix, 0, ...) runs them in one launch, variant 6 keeps small fp32 searches on
+    the sorted LDS lists, a small-search limit of 1 stage sends everything to the big-search instantiations.  Same ids and distances,
+    bit for bit, in all four."""
+    bank = gi.unit_bank(70001, 64, seed=5); q = torch.from_numpy(gi.vit_like_queries(1301, 64, seed=6)).cuda()
+    results = []
+    for setup in ("default", "unphased", "lists", "never_small"):
+        out = []
+        for k, fp16 in ((30, False), (90, False), (30, True)):
+            ix = HipFlatIndex(64, 0, 0); ix.add(torch.from_numpy(bank).cuda()); ix.set_fp16(fp16)
+            if setup == "unphased":
+                ix.set_search_options(phases=False)
+            elif setup == "lists":
+                ix.set_variant(6)
+            elif setup == "never_small":
+                ix.set_search_options(small_limit_stages=1)
+            out.append(ix.search(q, k))
+        results.append(out)
+    for other in results[1:]:
+        for (i0, d0), (i1, d1) in zip(results[0], other):
+            assert torch.equal(i0, i1) and torch.equal(d0.view(torch.int32), d1.view(torch.int32))
+    with pytest.raises(RuntimeError):
+        HipFlatIndex(8, 0, 0).set_search_options(small_limit_stages=-1)

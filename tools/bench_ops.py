@@ -44,14 +44,20 @@ for name, (B, S, ps, D, C, k) in {"cfg2": (64, 14, 16, 384, 21, 30), "cfg3": (16
     # K5 on a 1M-row bank
     M = 1_000_000
     bank = HipFlatIndex(D, 0, 0); bank.reserve(M); bank.use_current_stream()
+    cbank = HipFlatIndex(8, 0, 0); cbank.use_current_stream(); cbank.set_label_denominator(ps * ps)   # the same labels as uint16 counts
     for r0 in range(0, M, 250_000):
         bank.add(torch.randn((250_000, D), generator=g, device=dev), normalize=True)
-        bank.add_labels(torch.rand((250_000, C), generator=g, device=dev))
+        labs = torch.randint(0, ps * ps + 1, (250_000, C), generator=g, device=dev).float() / torch.tensor(float(ps * ps), device=dev)   # values j / P, like K2's
+        bank.add_labels(labs); cbank.add_labels(labs)
     bank.set_num_classes(C)
     q = 3 * torch.randn((B * N, D), generator=g, device=dev)
     idx, dist = bank.search(q, k)
-    ms = timeit(lambda: bank.aggregate(q, idx, dist)); res.append((name, "K5 aggregate (+query norms)", ms, (4 * k * C + 12 * k + 4 * C + 4 * D) * B * N))
+    ms = timeit(lambda: bank.aggregate(q, idx, dist)); res.append((name, "K5 aggregate (+query norms), fp32 labels", ms, (4 * k * C + 12 * k + 4 * C + 4 * D) * B * N))
     lh = bank.aggregate(q, idx, dist).view(B, N, C)
+    agg = HipFlatIndex(D, 0, 0); agg.use_current_stream(); agg.set_label_count_table(cbank.copy_label_counts(), bank.copy_norms(), ps * ps, 0)
+    ms = timeit(lambda: agg.aggregate(q, idx, dist)); res.append((name, "K5 aggregate (+query norms), uint16 label counts", ms, (2 * k * C + 12 * k + 4 * C + 4 * D) * B * N))
+    assert torch.equal(agg.aggregate(q, idx, dist).view(torch.int32), lh.reshape(-1, C).view(torch.int32))
+    del agg, cbank
     # K6
     ms = timeit(lambda: ops.upsample_argmax(lh, S, H, H)); res.append((name, "K6 upsample_argmax", ms, 4 * C * N * B + 8 * H * H * B))
     pred = ops.upsample_argmax(lh, S, H, H)
