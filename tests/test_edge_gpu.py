@@ -332,3 +332,22 @@ def test_full_cityscapes_frame_stitch(cuda_device):
     want_pred, want_acc = oracle.sliding_window_argmax(lhs, origins, S, win, H, W)            # acc as [B, C, H, W]
     assert np.array_equal(acc.cpu().numpy().view(np.uint32), np.ascontiguousarray(want_acc.transpose(0, 2, 3, 1)).view(np.uint32))
     assert np.array_equal(pred.cpu().numpy(), want_pred)
+
+
+@pytest.mark.parametrize("k,fp16", [(30, False), (30, True), (90, False)])
+def test_astronomically_large_scores_do_not_break_the_cold_start(cuda_device, k, fp16):
+    """one +inf / 1e38-sized score per query stretches the cold start's bisection interval beyond what twelve linear
+    halvings can cross; such queries bisect on the monotone keys instead.  Results are the oracle's either way (speed only)."""
+    M, D, nq = 30_000, 64, 300
+    bank = gi.unit_bank(M, D, seed=41)
+    bank[777] *= 1e30                                          # an unnormalised row of huge norm: scores of ~1e31 .. inf
+    bank[20_001] *= 3e37
+    q = gi.vit_like_queries(nq, D, seed=42)
+    q[5, 3] = np.inf                                           # and a query with an inf component: +inf / -inf / NaN scores
+    ix = HipFlatIndex(D, 0, 0)
+    ix.add(torch.from_numpy(bank).cuda())
+    ix.set_fp16(fp16)
+    idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
+    ridx, rdist = oracle.knn_chain_f32(q, bank, k)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(dist.cpu().numpy().view(np.uint32), rdist.view(np.uint32))
