@@ -774,6 +774,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // 1.51 / 1.67, 200 k 2.18 / 1.91; 1,369 x 768: 50 k 1.77 / 2.35, 100 k 2.81 / 2.67; 196 x 384: 200 k 1.33 / 1.37, 1 M 2.83 / 1.91.
     // Same results either way.
     bool f16 = ix->fp16 != 0 && k <= 128 && (ix->fp16 == 1 || (ix->ntotal >= 16384 && ix->ntotal * nq >= ((int64_t)1 << 27)));
+    if (!f16) ix->last_fp16_fallbacks = 0;      // a plain fp32 search: nothing fell back (the counter is not left over from an earlier search)
     // which candidate kernel: 2 = the second design (32x32x16 MFMA, register-resident query fragments: the default wherever its pools
     // fit, k' <= 128, i.e. k <= 64), 1 = the first design (variant 2, and pools beyond 256 entries).  (A third design on
     // v_mfma_f32_16x16x32_f16 -- same bits, same speed, rounds 3 / 4 -- was removed: profiles/r03/f16_mfma_shape_ab.md.)
@@ -1024,6 +1025,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
             ix->fp16 = 0; ix->time_kernels = 0;
             if (!rc) rc = hb_launch_knn(ix, d_q, nf, k, id_base, d_fi, d_fd);
             ix->fp16 = saved; ix->time_kernels = saved_t; ix->q_aux = saved_aux;
+            ix->last_fp16_fallbacks = nf;           // (the nested fp32 search cleared it)
             if (rc) return -1;
             if (hb_launch_scatter_rows(d_rows, nf, k, d_fi, d_fd, out_idx, out_dist, s)) return -1;
             HB_HIP(hipStreamSynchronize(s));         // `bad` and the workspace are reused by the next call

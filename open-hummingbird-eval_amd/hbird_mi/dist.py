@@ -32,9 +32,61 @@ def deal_round_robin(n_items: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_items, world))
 
 
-def allgather_rows(x: torch.Tensor) -> Tuple[torch.Tensor, List[int]]:
-    """All-gather of row blocks with ragged row counts: returns ([world, max_rows, ...] zero-padded, counts)."""
+def rank_batches(loader, keep: Callable[[int], bool]):
+    """One pass over `loader`, yielding `(ordinal, batch)` for the batches whose ordinal `keep` accepts -- WITHOUT decoding the others
+    when `loader` is a torch DataLoader over a map-style dataset (a sharded bank build must not decode ADE20K once per rank: rank r
+    of N touches 1 / N of the images).  The epoch's batch order is drawn from the loader's own batch sampler exactly as iter(loader)
+    draws it (same generator, same number and order of draws from the default CPU generator: ranks whose generators were aligned
+    agree on the order, and the stream the reference's single process would see afterwards is the same), then a second DataLoader
+    over the same dataset fetches only the kept index batches (same workers, collate_fn, pin_memory).  `loader` may offer its own
+    `rank_batches(keep)` (tiling.WindowedLoader).  Any other iterable is iterated and filtered."""
+    if hasattr(loader, "rank_batches"):
+        yield from loader.rank_batches(keep)
+        return
+    from torch.utils.data import DataLoader, IterableDataset
+    if (isinstance(loader, DataLoader) and loader.batch_sampler is not None and not isinstance(loader.dataset, IterableDataset)
+            and getattr(loader, "_auto_collation", True)):
+        # iter(loader) draws the iterator's base seed first, then (at the first fetch) whatever the sampler draws: same here
+        base_seed = int(torch.empty((), dtype=torch.int64).random_(generator=loader.generator).item())
+        index_batches = list(loader.batch_sampler)
+        owned = [(i, b) for i, b in enumerate(index_batches) if keep(i)]
+        if not owned:
+            return
+        g = torch.Generator()
+        g.manual_seed(base_seed)           # the sub-loader seeds its workers from a private generator: the default stream is untouched
+        kw = dict(num_workers=loader.num_workers, collate_fn=loader.collate_fn, pin_memory=loader.pin_memory,
+                  worker_init_fn=loader.worker_init_fn, timeout=loader.timeout, generator=g)
+        if loader.num_workers > 0:
+            kw.update(prefetch_factor=loader.prefetch_factor, multiprocessing_context=loader.multiprocessing_context)
+        sub = DataLoader(loader.dataset, batch_sampler=[b for _, b in owned], **kw)
+        for (i, _), batch in zip(owned, sub):
+            yield i, batch
+        return
+    for i, batch in enumerate(loader):
+        if keep(i):
+            yield i, batch
+
+
+def allgather_rows(x: torch.Tensor, max_rows: Optional[int] = None) -> Tuple[torch.Tensor, List[int]]:
+    """All-gather of row blocks with ragged row counts: returns ([world, max_rows, ...] zero-padded, counts).
+    With `max_rows` (an upper bound every rank knows, e.g. batch size x tokens) the gathered shape is FIXED: the row counts ride
+    in one extra trailing row of the payload, so a step costs ONE collective and no host round trip before it (the counts are read
+    back after the gather, together with whatever the caller synchronises on anyway); without it: an all-reduce of the counts and a
+    host read-back decide the padded shape first."""
     rank, world = rank_world()
+    if max_rows is not None:
+        assert x.shape[0] <= max_rows, f"allgather_rows: {x.shape[0]} rows exceed max_rows={max_rows}"
+        pad = torch.zeros((max_rows + 1,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        pad[:x.shape[0]] = x
+        pad[max_rows].view(-1)[0] = x.shape[0]             # exact in every dtype used here up to 2^24 rows (fp32) / 255 (uint8: not used)
+        out = torch.empty((world * (max_rows + 1),) + tuple(pad.shape[1:]), dtype=x.dtype, device=x.device)
+        if world > 1:
+            td.all_gather_into_tensor(out, pad)
+        else:
+            out.copy_(pad)
+        out = out.view((world, max_rows + 1) + tuple(pad.shape[1:]))
+        counts = [int(v) for v in out[:, max_rows].reshape(world, -1)[:, 0].cpu().tolist()]
+        return out[:, :max_rows], counts
     n = torch.zeros(world, dtype=torch.int64, device=x.device)
     n[rank] = x.shape[0]
     if world > 1:

@@ -186,23 +186,26 @@ class HbirdEvaluation:
             own_lo, own_hi = 0, float("inf")
         if self.memory_size is not None:
             self.index.reserve(max(1, self._planned_rows // max(1, self.world if self.sharded else 1)))
-        rows_before_me = 0
-        flat = 0
         presized = self.memory_size is not None
+        # Which batches this rank must actually LOAD.  Unbounded sharded build: only its own (hdist.rank_batches fetches just those
+        # index batches from a DataLoader: rank r of N decodes 1 / N of the images).  Bounded memory: every batch, because the
+        # reference's one random stream (500) is consumed for every batch by an amount that depends on its masks -- all ranks
+        # replay it -- and the masks only come with their images.
+        need_all = self.memory_size is not None or not self.sharded
+        self.batches_loaded = 0
         with torch.no_grad():
-            for _ in tqdm(range(self.augmentation_epoch), desc="Augmentation loop"):
-                for x, y in tqdm(train_loader, desc="Memory Creation loop"):
+            for ep in tqdm(range(self.augmentation_epoch), desc="Augmentation loop"):
+                base = ep * (n_batches or 0)
+                batches = enumerate(train_loader) if need_all else hdist.rank_batches(train_loader, lambda i, b=base: own_lo <= b + i < own_hi)
+                for bi, (x, y) in tqdm(batches, desc="Memory Creation loop"):
+                    flat = base + bi if n_batches is not None else self.batches_loaded
                     mine = own_lo <= flat < own_hi
-                    flat += 1
+                    self.batches_loaded += 1
                     y = y.to(self.gpu_device)
                     y = (y * 255).long()                                   # hbird_eval.py:309
                     bs = y.shape[0]
                     input_size = x.shape[-1]
                     patch_size = input_size // S                          # 313-314
-                    if not mine and self.memory_size is None:
-                        if flat - 1 < own_lo:
-                            rows_before_me += bs * S * S
-                        continue
                     if self.index.ntotal == 0:
                         self._set_label_denominator(patch_size * patch_size)
                     # K2: `y[y == 255] = 0` (310) + patchify (317) + one-hot mean (319-320)
@@ -228,8 +231,6 @@ class HbirdEvaluation:
                         # stay aligned with the single-process stream of the reference (500)
                         r = torch.rand(total_nz) if total_nz > 0 else torch.zeros(0)
                         if not mine:
-                            if flat - 1 < own_lo:
-                                rows_before_me += bs * K
                             continue
                         r_off = torch.tensor([0] + nz_host[:-1], dtype=torch.int64).cumsum(0)
                         sidx = ops.patch_select(scores, nonempty, r.to(self.gpu_device), r_off.to(self.gpu_device), K)
@@ -240,7 +241,7 @@ class HbirdEvaluation:
                         self.index.use_current_stream()
                         self.index.add(sampled, normalize=True)                                # 335, 352-353
                         self.index.add_labels(ops.gather_rows(lab.reshape(-1, num_classes), rows))   # 344-354
-        self.id_base = rows_before_me if self.sharded else 0
+        self.id_base = 0          # a sharded build learns its id base from the ranks' row counts (_finalize_shards)
         return self.index.ntotal
 
     def _set_label_denominator(self, P: int) -> None:
@@ -471,9 +472,10 @@ class HbirdEvaluation:
                 self._evaluate_sharded(val_loader, S, metric, return_knn_details, knns, knns_labels, knns_ca_labels,
                                        window)
             else:
-                for bi, (x, y) in enumerate(tqdm(val_loader, desc="Evaluation loop")):
-                    if self.world > 1 and bi % self.world != self.rank:
-                        continue      # replica mode (idx_shard=False): validation batches are data-parallel
+                # replica mode (idx_shard=False) under torch.distributed: validation batches are data-parallel, and a rank loads only its own
+                batches = (enumerate(val_loader) if self.world == 1
+                           else hdist.rank_batches(val_loader, lambda i: i % self.world == self.rank))
+                for bi, (x, y) in tqdm(batches, desc="Evaluation loop"):
                     _, _, h, w = x.shape
                     y = (y.to(self.gpu_device) * 255).long()                       # 219 (255 is NOT remapped here)
                     if window is not None:
@@ -511,21 +513,23 @@ class HbirdEvaluation:
         """Validation batches are dealt round-robin; all ranks step together so that every search sees all
         shards.  A rank that has run out of batches contributes zero queries.  With sliding windows the ranks also
         step window by window (all frames of a step must have the same size)."""
-        it = iter(val_loader)
         n_batches = len(val_loader)
         D = self.index.d
         steps = (n_batches + self.world - 1) // self.world
         k = self.n_neighbours
-        bi = 0
-        for _ in range(steps):
-            mine, last = None, None
-            for r in range(self.world):
-                if bi < n_batches:
-                    last = next(it)
-                    if r == self.rank:
-                        mine = last
-                    bi += 1
-            fh, fw = last[0].shape[-2:]
+        # every rank LOADS only the batches it is dealt (hdist.rank_batches: a DataLoader fetches just those index batches), and the
+        # ragged query all-gather has a fixed shape when the loader's batch size is known: one collective per step, no host round
+        # trip before it
+        own = iter(hdist.rank_batches(val_loader, lambda i: i % self.world == self.rank))
+        bsz = getattr(val_loader, "batch_size", None)
+        max_rows = int(bsz) * S * S if isinstance(bsz, int) and bsz > 0 else None
+        for step in range(steps):
+            mine = next(own)[1] if step * self.world + self.rank < n_batches else None
+            fh = fw = 0
+            if window is not None:      # all ranks step through the same windows: agree on the step's frame size
+                hw = torch.tensor([mine[0].shape[-2], mine[0].shape[-1]] if mine is not None else [0, 0], dtype=torch.int64, device=self.gpu_device)
+                torch.distributed.all_reduce(hw, op=torch.distributed.ReduceOp.MAX)
+                fh, fw = (int(v) for v in hw.cpu().tolist())
             origins = [(0, 0)] if window is None else tiling.window_origins(fh, fw, window[0], window[1])
             acc, cluster_map = None, None
             for y0, x0 in origins:
@@ -539,11 +543,11 @@ class HbirdEvaluation:
                     q = feats.reshape(B * N, D)
                 else:
                     q = torch.zeros((0, D), dtype=torch.float32, device=self.gpu_device)
-                qall, nq = hdist.allgather_rows(q)      # ragged query batches, zero-padded to the largest
+                qall, nq = hdist.allgather_rows(q, max_rows)      # ragged query batches, zero-padded (to the loader's batch size x tokens)
                 mx = qall.shape[1]
                 if mx == 0:
                     continue
-                q_flat_all = qall.view(self.world * mx, D)
+                q_flat_all = qall.reshape(self.world * mx, D)
                 idx, dist = self.find_neighbours(q_flat_all, k)   # collective inside
                 lh_all = None
                 if self.label_shard:

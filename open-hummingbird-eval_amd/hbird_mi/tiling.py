@@ -51,3 +51,15 @@ class WindowedLoader:
             for y0, x0 in window_origins(H, W, self.win, self.stride):
                 yield (x[..., y0:y0 + self.win, x0:x0 + self.win].contiguous(),
                        y[..., y0:y0 + self.win, x0:x0 + self.win].contiguous())
+
+    def rank_batches(self, keep):
+        """hdist.rank_batches for window crops: ordinal = frame batch x windows-per-frame + window; a frame batch is fetched (through the
+        inner loader's own rank-aware pass) only when one of its windows is kept."""
+        from hbird_mi import dist as hdist
+        npf = self.windows_per_frame()
+        for fi, (x, y) in hdist.rank_batches(self.loader, lambda f: any(keep(f * npf + j) for j in range(npf))):
+            H, W = x.shape[-2:]
+            for j, (y0, x0) in enumerate(window_origins(H, W, self.win, self.stride)):
+                if keep(fi * npf + j):
+                    yield fi * npf + j, (x[..., y0:y0 + self.win, x0:x0 + self.win].contiguous(),
+                                         y[..., y0:y0 + self.win, x0:x0 + self.win].contiguous())

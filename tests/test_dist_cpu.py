@@ -98,3 +98,61 @@ def test_shard_range_properties():
             assert ranges[0][0] == 0 and ranges[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:]))
             assert sorted(sum((hdist.deal_round_robin(n % 50, r, world) for r in range(world)), [])) == list(range(n % 50))
+
+
+def test_rank_batches_fetches_only_the_kept_index_batches():
+    """hdist.rank_batches on a DataLoader: the kept batches, in the order and with the content the plain loader would deliver
+    (shuffled loaders included), only their items fetched from the dataset, and the default CPU generator left exactly where a
+    plain pass leaves it (a sharded build replays the reference's single random stream behind it)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [os.path.join(root, "open-hummingbird-eval_amd")]
+    from torch.utils.data import DataLoader, Dataset
+    from hbird_mi import dist as hdist
+    from hbird_mi.tiling import WindowedLoader
+
+    class DS(Dataset):
+        def __init__(self): self.calls = []
+        def __len__(self): return 23
+        def __getitem__(self, i):
+            self.calls.append(i)
+            return torch.full((3, 8, 8), float(i)), torch.full((1, 8, 8), float(i))
+
+    for shuffle in (False, True):
+        ds = DS(); L = DataLoader(ds, batch_size=4, shuffle=shuffle)
+        torch.manual_seed(5); ref = [b[0][:, 0, 0, 0].tolist() for b in L]; after_ref = torch.rand(3)
+        ds.calls.clear()
+        torch.manual_seed(5); got = list(hdist.rank_batches(L, lambda i: i % 3 == 1)); after = torch.rand(3)
+        assert [(i, b[0][:, 0, 0, 0].tolist()) for i, b in got] == [(i, ref[i]) for i in range(len(ref)) if i % 3 == 1]
+        assert len(ds.calls) == 8 and torch.equal(after, after_ref)
+    # any other iterable: iterate and filter; a WindowedLoader: only the frame batches with a kept window are fetched
+    assert [i for i, _ in hdist.rank_batches([("a",), ("b",), ("c",)], lambda i: i != 1)] == [0, 2]
+    ds = DS(); W = WindowedLoader(DataLoader(ds, batch_size=4), 4, 4, frame_hw=(8, 8))      # 4 windows per frame batch
+    kept = list(hdist.rank_batches(W, lambda i: 8 <= i < 12))                                    # = frame batch 2, all its windows
+    assert [i for i, _ in kept] == [8, 9, 10, 11] and sorted(set(ds.calls)) == [8, 9, 10, 11]
+    assert all(b[0].shape[-2:] == (4, 4) for _, b in kept)
+
+
+def _gather_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [os.path.join(root, "open-hummingbird-eval_amd")]
+    from hbird_mi import dist as hdist
+    x = torch.arange((3 + 2 * rank) * 5, dtype=torch.float32).view(-1, 5) + 100 * rank       # 3 rows on rank 0, 5 on rank 1
+    a, ca = hdist.allgather_rows(x)                       # ragged: count all-reduce + read-back, padded to the largest
+    b, cb = hdist.allgather_rows(x, max_rows=7)           # fixed shape: ONE collective, the counts ride in the payload
+    e, ce = hdist.allgather_rows(x[:0], max_rows=7)
+    ok = ca == cb == [3, 5] and ce == [0, 0] and tuple(a.shape) == (2, 5, 5) and tuple(b.shape) == (2, 7, 5)
+    for r in range(2):
+        ok = ok and torch.equal(a[r, :ca[r]], b[r, :cb[r]]) and bool((b[r, cb[r]:] == 0).all())
+    ret[rank] = bool(ok)
+    td.destroy_process_group()
+
+
+def test_allgather_rows_fixed_shape_equals_ragged():
+    world, port = 2, _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_gather_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret[0] and ret[1]

@@ -1,3 +1,7 @@
+#!/bin/bash
+export TMPDIR=/tmp
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd $ROOT
 OUT=gpurun_out/r3final_b; mkdir -p $OUT
 for cfg in "cfg1 50176 384 21 12544 30" "cfg2 2074072 384 21 12544 30"; do set -- $cfg
   python bench.py --rows $2 --dim $3 --classes $4 --nq $5 --k $6 --steps 10 --warmup 3 --no-cpu-baseline --no-traffic > $OUT/bench_$1.json 2>/dev/null
