@@ -162,6 +162,12 @@ int hb_gather_rows(const float* src, int64_t src_rows, int width, const int64_t*
  * out[B, 1, h, w] int64. */
 int hb_upsample_argmax(const float* label_hat, int64_t B, int S, int C, int h, int w, int64_t* out,
                        void* hip_stream);
+/* The two steps fused (hbird_eval.py:235-243 + eval_metrics.py:73-104): label_hat[B, S*S, C] is upsampled, its argmax is counted
+ * straight into conf[num_gt, num_pred] against the masks gt[B, 1, h, w] (gt == ignore_index and out-of-range pairs dropped, as
+ * hb_confusion_update) -- the int64 class map is never written unless out_map_opt asks for it. */
+int hb_upsample_argmax_confusion(const float* label_hat, int64_t B, int S, int C, int h, int w, const int64_t* gt, int num_gt,
+                                 int num_pred, int64_t ignore_index, int has_ignore, uint64_t* conf, int64_t* out_map_opt,
+                                 void* hip_stream);
 /* Sliding-window frames (BASELINE cfg-5; the reference has no tiler): one window's label_hat[B, S*S, C] is upsampled
  * like hbird_eval.py:240 (bilinear, align_corners=False) to win_h x win_w and added into acc[B, H, W, C] (fp32,
  * channels last, zeroed by the caller) at (y0, x0).  Windows of one frame must be accumulated in a fixed order

@@ -642,6 +642,14 @@ extern "C" int hb_upsample_argmax(const float* label_hat, int64_t B, int S, int 
     hb_range range("hbird:upsample_argmax");
     return hb_launch_upsample_argmax(label_hat, B, S, C, h, w, out, (hipStream_t)stream);
 }
+extern "C" int hb_upsample_argmax_confusion(const float* label_hat, int64_t B, int S, int C, int h, int w, const int64_t* gt, int num_gt,
+                                            int num_pred, int64_t ignore_index, int has_ignore, uint64_t* conf, int64_t* out_map_opt,
+                                            void* stream) {
+    hb_range range("hbird:upsample_argmax_confusion");
+    if (!gt || !conf) return hb_fail("hb_upsample_argmax_confusion: gt / conf is NULL");
+    return hb_launch_upsample_argmax_confusion(label_hat, B, S, C, h, w, out_map_opt, gt, num_gt, num_pred, ignore_index, has_ignore,
+                                               reinterpret_cast<unsigned long long*>(conf), (hipStream_t)stream);
+}
 extern "C" int hb_upsample_accumulate(const float* label_hat, int64_t B, int S, int C, int win_h, int win_w, float* acc,
                                       int H, int W, int y0, int x0, void* stream) {
     hb_range range("hbird:upsample_accumulate");

@@ -168,6 +168,8 @@ int hb_launch_gather_rows(const float* src, int64_t src_rows, int width, const i
                           hipStream_t s);
 int hb_launch_upsample_argmax(const float* label_hat, int64_t B, int S, int C, int h, int w, int64_t* out,
                               hipStream_t s);
+int hb_launch_upsample_argmax_confusion(const float* label_hat, int64_t B, int S, int C, int h, int w, int64_t* out, const int64_t* gt,
+                                        int num_gt, int num_pred, int64_t ignore, int has_ignore, unsigned long long* conf, hipStream_t s);
 int hb_launch_upsample_accumulate(const float* label_hat, int64_t B, int S, int C, int win_h, int win_w, float* acc, int H,
                                   int W, int y0, int x0, hipStream_t s);
 int hb_launch_argmax_channels(const float* acc, int64_t n, int C, int64_t* out, hipStream_t s);

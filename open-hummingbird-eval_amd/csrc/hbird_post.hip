@@ -36,10 +36,19 @@ __device__ __forceinline__ int k6_band_begin(float scale, int j, int S, int n) {
     return g;
 }
 
+// K6 + K7 fused (row f1 of SURVEY.md 8: "upsample + argmax + confusion matrix"): with `conf` the kernel also counts its pixels into the
+// confusion matrix conf[gt, pred] (PredsmIoU.update, eval_metrics.py:73-104: gt == ignore_index and out-of-range pairs dropped) and
+// `out` may be NULL -- the int64 class map (8 B per pixel written, 16 B per pixel re-read by K7 with the masks) then never exists.
+// A wave holds 64 neighbouring pixels of one row: segmentation maps are piecewise constant, so the wave first groups equal (gt, pred)
+// pairs (leader election by ballot: usually one or two groups) and issues ONE 64-bit global atomic per group -- K7's per-pixel LDS
+// atomics serialise exactly there (64 lanes on one bin).
+#define K6_HASH_BITS 8
+#define K6_HASH (1 << K6_HASH_BITS)                  // entries of the fused kernel's (pair, count) table: 2 KiB of the staging area
 template <int K6_R>
 __global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* __restrict__ lh, int S, int C, int h, int w,
                                                               float sy, float sx, int chunks, int cmax,
-                                                              int64_t* __restrict__ out) {
+                                                              int64_t* __restrict__ out, const int64_t* __restrict__ gt, int G, int P,
+                                                              int64_t ignore, int has_ignore, unsigned long long* __restrict__ conf) {
     extern __shared__ __attribute__((aligned(16))) float k6_sm[];
     const int j = blockIdx.y / chunks, rc = blockIdx.y % chunks;
     const int64_t b = blockIdx.z;
@@ -105,17 +114,68 @@ __global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* __res
             }
         }
     }
-    if (xs + (int)threadIdx.x < w) {
+    if (out && xs + (int)threadIdx.x < w) {
 #pragma unroll
         for (int r = 0; r < K6_R; ++r)
             if (r0 + r < r1) out[(b * h + (r0 + r)) * (int64_t)w + x] = arg[r];
+    }
+    if (conf) {
+        // counts go through a small per-workgroup table in LDS ((pair, count) entries, open addressing) and reach the matrix as ONE
+        // global atomic per distinct pair of the workgroup's <= 16 x 256 pixels: same-address global atomics from every wave would
+        // serialise at the L2 (uniform regions send most pixels to one bin), and a full [G, P] histogram (91 KB at C = 151) does not
+        // fit beside the staged source rows.  A pair that finds no slot in 8 probes (noise-like maps) adds to the matrix directly.
+        __syncthreads();                                    // the staging area is free now
+        int* hkey = reinterpret_cast<int*>(k6_sm);
+        unsigned* hcnt = reinterpret_cast<unsigned*>(k6_sm) + K6_HASH;
+        for (int e = threadIdx.x; e < K6_HASH; e += blockDim.x) { hkey[e] = -1; hcnt[e] = 0u; }
+        __syncthreads();
+        const int lane = threadIdx.x & 63;
+        auto count = [&](int key, unsigned n) {
+            unsigned slot = ((unsigned)key * 2654435761u) >> (32 - K6_HASH_BITS);
+            for (int probe = 0; probe < 8; ++probe) {
+                const int old = atomicCAS(&hkey[slot], -1, key);
+                if (old == -1 || old == key) { atomicAdd(&hcnt[slot], n); return; }
+                slot = (slot + 1) & (K6_HASH - 1);
+            }
+            atomicAdd(&conf[key], (unsigned long long)n);
+        };
+#pragma unroll
+        for (int r = 0; r < K6_R; ++r) {
+            if (r0 + r >= r1) break;                        // block-uniform
+            bool valid = xs + (int)threadIdx.x < w;
+            const int64_t g = valid ? gt[(b * h + (r0 + r)) * (int64_t)w + x] : -1;
+            valid = valid && !(has_ignore && g == ignore) && g >= 0 && g < G && arg[r] < P;
+            const int key = valid ? (int)g * P + arg[r] : -1;
+            // a wave's 64 neighbouring pixels of one row mostly share one or two pairs: up to three groups are counted by their
+            // leaders, whatever is left (noise) lane by lane
+            unsigned long long todo = __ballot(valid);
+#pragma unroll 1
+            for (int round = 0; round < 3 && todo; ++round) {
+                const int leader = __builtin_ctzll(todo);
+                const int k0 = __builtin_amdgcn_readlane(key, leader);
+                const unsigned long long same = __ballot(key == k0) & todo;
+                if (lane == leader) count(k0, (unsigned)__popcll(same));
+                todo &= ~same;
+            }
+            if ((todo >> lane) & 1ull) count(key, 1u);
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < K6_HASH; e += blockDim.x)
+            if (hkey[e] >= 0 && hcnt[e]) atomicAdd(&conf[hkey[e]], (unsigned long long)hcnt[e]);
     }
 }
 
 int hb_launch_upsample_argmax(const float* label_hat, int64_t B, int S, int C, int h, int w, int64_t* out,
                               hipStream_t s) {
+    return hb_launch_upsample_argmax_confusion(label_hat, B, S, C, h, w, out, nullptr, 0, 0, 0, 0, nullptr, s);
+}
+
+int hb_launch_upsample_argmax_confusion(const float* label_hat, int64_t B, int S, int C, int h, int w, int64_t* out, const int64_t* gt,
+                                        int num_gt, int num_pred, int64_t ignore, int has_ignore, unsigned long long* conf, hipStream_t s) {
     if (B == 0) return 0;
     if (S < 1 || C < 1 || h < 1 || w < 1) return hb_fail("hb_upsample_argmax: bad shape");
+    if (!out && !conf) return hb_fail("hb_upsample_argmax_confusion: neither a class map nor a confusion matrix was asked for");
+    if (conf && (!gt || num_gt < 1 || num_pred < 1 || (long long)num_gt * num_pred > 0x7FFFFFFFLL)) return hb_fail("hb_upsample_argmax_confusion: bad confusion-matrix arguments");
     const float sy = (float)S / (float)h, sx = (float)S / (float)w;
     // tallest band (same fp32 arithmetic as the kernel: this file is compiled with contraction off on both sides)
     int maxband = 1, run = 0, prev = -1;
@@ -151,9 +211,9 @@ int hb_launch_upsample_argmax(const float* label_hat, int64_t B, int S, int C, i
     // widest column window of a block, and the classes per LDS pass that keep it within 64 KiB
     const int ncols = std::min(S, (int)std::ceil((double)bw * S / w) + 2);
     const int cmax = std::max(1, std::min(C, (64 * 1024) / (2 * ncols * 4)));
-    const size_t lds = (size_t)2 * ncols * cmax * 4;
+    const size_t lds = std::max<size_t>((size_t)2 * ncols * cmax * 4, conf ? (size_t)K6_HASH * 8 : 0);
     const dim3 grid((unsigned)blocks_x, (unsigned)(S * chunks), (unsigned)B);
-#define K6_LAUNCH(RR) upsample_argmax_kernel<RR><<<grid, dim3(bw), lds, s>>>(label_hat, S, C, h, w, sy, sx, chunks, cmax, out)
+#define K6_LAUNCH(RR) upsample_argmax_kernel<RR><<<grid, dim3(bw), lds, s>>>(label_hat, S, C, h, w, sy, sx, chunks, cmax, out, gt, num_gt, num_pred, ignore, has_ignore, conf)
     switch (R) {
         case 8: K6_LAUNCH(8); break;
         case 10: K6_LAUNCH(10); break;
@@ -247,12 +307,32 @@ __global__ __launch_bounds__(256) void confusion_kernel(const int64_t* __restric
         for (int e = threadIdx.x; e < bins; e += 256) hist[e] = 0;
         __syncthreads();
     }
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int64_t g = gt[i], p = pred[i];
-        if (has_ignore && g == ignore) continue;
-        if (g < 0 || g >= G || p < 0 || p >= P) continue;
-        if (use_lds) atomicAdd(&hist[g * P + p], 1u);
-        else atomicAdd(&conf[g * P + p], 1ull);
+    // a wave's 64 neighbouring pixels mostly share one or two (gt, pred) pairs (piecewise-constant maps), and 64 per-pixel atomics on
+    // one bin serialise: up to two groups of equal pairs are counted by their leaders, whatever is left (noise-like maps: conflict-free
+    // bins anyway) lane by lane
+    const int lane = threadIdx.x & 63;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63); i0 < n; i0 += (int64_t)gridDim.x * 256) {
+        const int64_t i = i0 + lane;
+        bool valid = i < n;
+        const int64_t g = valid ? gt[i] : -1, p = valid ? pred[i] : -1;
+        valid = valid && !(has_ignore && g == ignore) && g >= 0 && g < G && p >= 0 && p < P;
+        const int key = valid ? (int)(g * P + p) : -1;
+        unsigned long long todo = __ballot(valid);
+#pragma unroll 1
+        for (int round = 0; round < 2 && todo; ++round) {
+            const int leader = __builtin_ctzll(todo);
+            const int k0 = __builtin_amdgcn_readlane(key, leader);
+            const unsigned long long same = __ballot(key == k0) & todo;
+            if (lane == leader) {
+                if (use_lds) atomicAdd(&hist[k0], (unsigned)__popcll(same));
+                else atomicAdd(&conf[k0], (unsigned long long)__popcll(same));
+            }
+            todo &= ~same;
+        }
+        if ((todo >> lane) & 1ull) {
+            if (use_lds) atomicAdd(&hist[key], 1u);
+            else atomicAdd(&conf[key], 1ull);
+        }
     }
     if (use_lds) {
         __syncthreads();
@@ -264,6 +344,7 @@ __global__ __launch_bounds__(256) void confusion_kernel(const int64_t* __restric
 int hb_launch_confusion(const int64_t* gt, const int64_t* pred, int64_t n, int num_gt, int num_pred, int64_t ignore,
                         int has_ignore, unsigned long long* conf, hipStream_t s) {
     if (n == 0) return 0;
+    if ((long long)num_gt * num_pred > 0x7FFFFFFFLL) return hb_fail("hb_confusion_update: too many classes");
     const size_t bins = (size_t)num_gt * num_pred;
     const int use_lds = bins * 4 <= 120 * 1024;
     const size_t sh = use_lds ? bins * 4 : 0;

@@ -59,6 +59,8 @@ SIGNATURES = {
                                 c_void_p]),
     "hb_gather_rows": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "hb_upsample_argmax": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "hb_upsample_argmax_confusion": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int64, c_int,
+                                             c_void_p, c_void_p, c_void_p]),
     "hb_upsample_accumulate": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                        c_void_p]),
     "hb_argmax_channels": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),

@@ -486,8 +486,7 @@ class HbirdEvaluation:
                     if return_knn_details:
                         kf, kl = self._gather_details(idx, feats.shape[0], feats.shape[1])
                         knns.append(kf.cpu()); knns_labels.append(kl.cpu()); knns_ca_labels.append(label_hat.cpu())
-                    cluster_map = ops.upsample_argmax(label_hat, S, h, w)           # 235-243
-                    metric.update(y, cluster_map)                                   # 252 (streamed per batch)
+                    metric.update_from_label_hat(y, label_hat, S)                   # 235-243 + 252: upsample + argmax + confusion counts, one kernel
         jac, tp, fp, fn, _, _ = metric.compute(is_global_zero=True, sync_distributed=self.world > 1,
                                                return_reordered=False)            # 253
         if return_knn_details:
@@ -587,7 +586,7 @@ class HbirdEvaluation:
                     knns_labels.append(kl.cpu())
                     knns_ca_labels.append(label_hat.cpu())
                 if window is None:
-                    cluster_map = ops.upsample_argmax(label_hat, S, h, w)
+                    metric.update_from_label_hat((mine[1].to(self.gpu_device) * 255).long(), label_hat, S)   # K6 + K7 fused
                 else:
                     if acc is None:
                         acc = torch.zeros((B, fh, fw, self.num_classes), dtype=torch.float32, device=self.gpu_device)
@@ -595,8 +594,7 @@ class HbirdEvaluation:
             if mine is None:
                 continue
             if window is not None:
-                cluster_map = ops.argmax_channels(acc)
-            metric.update((mine[1].to(self.gpu_device) * 255).long(), cluster_map)
+                metric.update((mine[1].to(self.gpu_device) * 255).long(), ops.argmax_channels(acc))
         if want_details and not knns:
             z = torch.zeros(0)
             knns.append(z); knns_labels.append(z); knns_ca_labels.append(z)

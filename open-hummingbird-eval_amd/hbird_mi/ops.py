@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import ctypes
 
+from typing import Optional
+
 import torch
 
 from hbird_mi import _lib
@@ -96,6 +98,27 @@ def upsample_argmax(label_hat: torch.Tensor, S: int, h: int, w: int) -> torch.Te
     out = torch.empty((B, 1, h, w), dtype=torch.int64, device=label_hat.device)
     _lib.check(_lib.lib().hb_upsample_argmax(_p(label_hat), B, int(S), C, int(h), int(w), _p(out),
                                              _stream(label_hat)))
+    return out
+
+
+def upsample_argmax_confusion(label_hat: torch.Tensor, S: int, gt: torch.Tensor, conf: torch.Tensor, ignore_index,
+                              want_map: bool = False) -> Optional[torch.Tensor]:
+    """K6 + K7 fused: label_hat [B, S*S, C] upsampled to gt's [B,1,h,w], its argmax counted into conf [G,P] int64 against gt
+    (reference hbird_eval.py:235-243 + eval_metrics.py:73-104).  The class map is only materialised when `want_map`."""
+    _need_cuda(label_hat, gt, conf)
+    label_hat = label_hat.contiguous().float()
+    gt = gt.contiguous().to(torch.int64)
+    B, N, C = label_hat.shape
+    if N != S * S:
+        raise ValueError(f"label_hat has {N} patches, expected {S}x{S}")
+    if gt.dim() != 4 or gt.shape[0] != B or gt.shape[1] != 1:
+        raise ValueError(f"gt must be [B,1,h,w] with B = {B}, got {tuple(gt.shape)}")
+    h, w = int(gt.shape[2]), int(gt.shape[3])
+    G, P = conf.shape
+    has = ignore_index is not None
+    out = torch.empty((B, 1, h, w), dtype=torch.int64, device=label_hat.device) if want_map else None
+    _lib.check(_lib.lib().hb_upsample_argmax_confusion(_p(label_hat), B, int(S), C, h, w, _p(gt), G, P, int(ignore_index) if has else 0,
+                                                       int(has), _p(conf), _p(out) if want_map else None, _stream(label_hat)))
     return out
 
 

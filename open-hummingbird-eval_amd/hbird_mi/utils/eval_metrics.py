@@ -60,6 +60,22 @@ class PredsmIoU:
             keep &= (gt >= 0) & (gt < self.num_gt_classes) & (pred >= 0) & (pred < self.num_pred_classes)
             self._pred_chunks.append(pred[keep].to("cpu", dtype=torch.int32))
 
+    @torch.no_grad()
+    def update_from_label_hat(self, gt: torch.Tensor, label_hat: torch.Tensor, S: int) -> None:
+        """`update(gt, upsample_argmax(label_hat))` without the class map (the fused K6 + K7 kernel): label_hat [B, S*S, C] soft
+        predictions, gt [B,1,h,w].  The same confusion counts as the two-step path; with store_reordered_preds the map is kept."""
+        if gt.numel() == 0:
+            return
+        gt = gt.to(self.device, non_blocking=True).long()
+        pred = ops.upsample_argmax_confusion(label_hat, S, gt, self._conf_mat, self.ignore_index, want_map=self.store_reordered_preds)
+        if self.store_reordered_preds:
+            g, p = gt.reshape(-1), pred.reshape(-1)
+            keep = torch.ones_like(g, dtype=torch.bool)
+            if self.ignore_index is not None:
+                keep &= g.ne(self.ignore_index)
+            keep &= (g >= 0) & (g < self.num_gt_classes) & (p >= 0) & (p < self.num_pred_classes)
+            self._pred_chunks.append(p[keep].to("cpu", dtype=torch.int32))
+
     # ---- O(C^2) host tail --------------------------------------------------------------------------
     def _conf_np(self) -> np.ndarray:
         return self._conf_mat.to("cpu").numpy().astype(np.int64)

@@ -218,6 +218,31 @@ def test_k7_predsmiou_golden(cuda_device, golden_dir):
         assert m.compute(is_global_zero=False) == (0.0, [], [], [], [], 0.0)
 
 
+@pytest.mark.parametrize("B,S,C,h,w,ign", [(2, 14, 21, 224, 224, 255), (3, 37, 151, 518, 518, 0), (1, 7, 5, 100, 61, None), (2, 16, 300, 130, 70, 255)])
+def test_k6_k7_fused_equals_the_two_kernels(cuda_device, B, S, C, h, w, ign):
+    """hb_upsample_argmax_confusion (row f1: upsample + argmax + confusion matrix in one kernel): the confusion counts of K6 followed
+    by K7 -- piecewise-constant masks (wave-aggregated atomics: one per group of equal pairs), ignore values, out-of-range gt,
+    ragged right borders, more classes than an LDS histogram holds -- and, on request, K6's class map bit for bit."""
+    rng = np.random.default_rng(S * C + h)
+    lh = torch.from_numpy(rng.random((B, S * S, C), dtype=np.float32)).cuda()
+    gt = gi.random_masks(B, h, w, C, seed=h + w, with_255=True)
+    gt[0, 0, :3, :5] = C + 3                                   # out of range: dropped
+    gt = torch.from_numpy(gt).cuda()
+    pred = ops.upsample_argmax(lh, S, h, w)
+    conf2 = torch.zeros((C, C), dtype=torch.int64, device="cuda"); ops.confusion_update(conf2, gt, pred, ign)
+    conf1 = torch.zeros((C, C), dtype=torch.int64, device="cuda")
+    out = ops.upsample_argmax_confusion(lh, S, gt, conf1, ign, want_map=True)
+    assert torch.equal(out, pred) and torch.equal(conf1, conf2) and int(conf1.sum()) > 0
+    conf3 = torch.zeros((C, C), dtype=torch.int64, device="cuda")
+    assert ops.upsample_argmax_confusion(lh, S, gt, conf3, ign) is None and torch.equal(conf3, conf2)
+    ref = oracle.confusion_matrix(gt.cpu().numpy().reshape(-1), pred.cpu().numpy().reshape(-1), C, C, ign) if hasattr(oracle, "confusion_matrix") else None
+    if ref is not None:
+        assert np.array_equal(conf1.cpu().numpy(), ref)
+    m1 = PredsmIoU(C, C, ignore_index=ign, store_reordered_preds=True); m2 = PredsmIoU(C, C, ignore_index=ign, store_reordered_preds=True)
+    m1.update(gt, pred); m2.update_from_label_hat(gt, lh, S)
+    assert m1.compute(True, many_to_one=True) == m2.compute(True, many_to_one=True)
+
+
 def test_k7_large_class_count_global_path(cuda_device):
     rng = np.random.default_rng(0)
     C = 200                                        # 200*200*4 B > LDS budget -> global-atomic path

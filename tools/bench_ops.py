@@ -44,7 +44,7 @@ for name, (B, S, ps, D, C, k) in {"cfg2": (64, 14, 16, 384, 21, 30), "cfg3": (16
     # K5 on a 1M-row bank
     M = 1_000_000
     bank = HipFlatIndex(D, 0, 0); bank.reserve(M); bank.use_current_stream()
-    cbank = HipFlatIndex(8, 0, 0); cbank.use_current_stream(); cbank.set_label_denominator(ps * ps)   # the same labels as uint16 counts
+    cbank = HipFlatIndex(8, 0, 0); cbank.use_current_stream(); cbank.set_label_denominator(ps * ps); cbank.set_num_classes(C)   # the same labels as uint16 counts
     for r0 in range(0, M, 250_000):
         bank.add(torch.randn((250_000, D), generator=g, device=dev), normalize=True)
         labs = torch.randint(0, ps * ps + 1, (250_000, C), generator=g, device=dev).float() / torch.tensor(float(ps * ps), device=dev)   # values j / P, like K2's
@@ -62,7 +62,17 @@ for name, (B, S, ps, D, C, k) in {"cfg2": (64, 14, 16, 384, 21, 30), "cfg3": (16
     ms = timeit(lambda: ops.upsample_argmax(lh, S, H, H)); res.append((name, "K6 upsample_argmax", ms, 4 * C * N * B + 8 * H * H * B))
     pred = ops.upsample_argmax(lh, S, H, H)
     conf = torch.zeros((C, C), dtype=torch.int64, device=dev)
-    ms = timeit(lambda: ops.confusion_update(conf, y, pred, 255)); res.append((name, "K7 confusion", ms, 16 * H * H * B))
+    ms = timeit(lambda: ops.confusion_update(conf, y, pred, 255)); res.append((name, "K7 confusion, noise masks", ms, 16 * H * H * B))
+    ms = timeit(lambda: ops.upsample_argmax_confusion(lh, S, y, conf, 255)); res.append((name, "K6 + K7 fused (no class map), noise masks", ms, 4 * C * N * B + 8 * H * H * B))
+    # piecewise-constant masks and predictions (what segmentation data looks like): rectangles of one class, label_hat peaked per patch
+    import sys as _s; _s.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_inputs as gi
+    yr = torch.from_numpy(gi.random_masks(B, H, H, C, seed=3, with_255=True)).to(dev)
+    lhr = ops.patch_label_hist(yr, ps, C, map255=True).view(B, N, C)
+    predr = ops.upsample_argmax(lhr, S, H, H)
+    ms = timeit(lambda: ops.confusion_update(conf, yr, predr, 255)); res.append((name, "K7 confusion, rectangle masks", ms, 16 * H * H * B))
+    ms = timeit(lambda: ops.upsample_argmax_confusion(lhr, S, yr, conf, 255)); res.append((name, "K6 + K7 fused (no class map), rectangle masks", ms, 4 * C * N * B + 8 * H * H * B))
+    ms = timeit(lambda: ops.upsample_argmax(lhr, S, H, H)); res.append((name, "K6 upsample_argmax, rectangle masks", ms, 4 * C * N * B + 8 * H * H * B))
     del bank, ix
 rows = []
 for name, op, ms, nbytes in res:
