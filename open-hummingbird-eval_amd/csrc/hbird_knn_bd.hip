@@ -35,7 +35,11 @@
 // (Rounds 2 / 3 carried timing-only ablation builds of this loop -- no bank copies / no query-fragment loads / no epilogue / no
 // fragment reads -- and placement experiments -- every wave copying its own row tile, static wave priorities, the requests in the Y
 // half, floors requested at a tile's start: their numbers are in DESIGN.md section 4 and profiles/r02, the switches are gone.)
-#define BD_BLOAD(B) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(B) : "v"(lane_off), "s"(qsrc + (size_t)fks * 1024) : "memory");
+#define BD_BLOAD(B) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(B) : "v"(lane_off), "s"(qfp) : "memory");
+// one 1 KiB LDS-DMA piece in the saddr form: wave-uniform 64-bit base + 32-bit lane offset -> LDS (wave-uniform address in M0 + 16 * lane);
+// the builtin takes a per-lane flat address (a 64-bit VALU add per piece).  M0 is clobbered on purpose (hbird_knn_f16.hip: F2_DMA)
+#define BD_DMA(SRC, LDS_ADDR, VOFF)                                                                                      \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(VOFF), "s"(SRC), "s"(LDS_ADDR) : "memory", "m0");
 #define BD_RD(DST, SRC) DST = SRC;
 
 // WIDE: k > HB_KL, candidate pools in global memory; CL: member of an L2-sharing cluster (strided segments on a common
@@ -56,6 +60,8 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
     const int g8 = a.g8, k = a.k;
     const int myq = w * 32 + (lane & 31);
     const unsigned lane_off = (unsigned)lane * 16u;
+    const unsigned lane_off_hi = lane_off + 4u * (unsigned)g8 * 1024u;      // the same lane's piece of row tile w + 4
+    const unsigned lds_0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     cl_sync cs;
     if constexpr (CL) cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + BD_CLWORDS);
 
@@ -86,31 +92,46 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
         f32x4 fa[4], fy[4];   // X-half / Y-half bank fragments
         f32x4 bq[4];          // query fragments of four stages
 
+        // The fetch position as running wave-uniform pointers (round 4, as in hbird_knn_f16.hip: the per-stage address arithmetic -- a
+        // 64-bit multiply chain and per-lane 64-bit adds for every copy -- was the largest part of the stage loop's scalar skeleton):
+        // qfp = this wave's query fragment, bf = bank row tile w (row tile w + 4 through a second lane offset), bi = the tile's row-init
+        // values, all of the NEXT stage to request.  A stage advances qfp and bf by 1 KiB; at a tile's end qfp returns to the wave's
+        // first fragment and bf jumps from the end of row tile w to row tile w of the segment's next tile.
         // waves 0-3 copy the bank row tiles w and w + 4 of a stage (their SIMD partners 4-7 issue no copies, hbird_knn.hip)
-        auto issue_a = [&](int bt, int ks, int slot) {
+        // (what only a tile's end needs -- the wrap distances, the row-init base -- is recomputed / re-read there: fewer live scalars)
+        const char* qfp = qsrc;
+        const char* bf = reinterpret_cast<const char*>(a.bank_tiles) + ((size_t)seg.b_tile0 * 8 + w) * g8 * 1024;
+        int bt = seg.b_tile0, ks = 0;          // tile / stage being computed
+        int fbt = seg.b_tile0, fks = 0;        // tile / stage being fetched
+        int slot_c = 0, left = total;
+        unsigned slot_f = 0, fpar = 0;         // ring slot being filled (byte offset), row-init buffer being filled (byte offset)
+        int cpar = 0;                          // row-init double buffer: parity of the tile being computed
+        auto issue_a = [&]() {
             if (w < 4) {
-                const float* src = a.bank_tiles + ((size_t)(bt * 8 + w) * g8 + ks) * HB_BLK + lane * 4;
-                glds16(src, smem + slot * BD_SLOT + w * 1024);
-                glds16(src + (size_t)4 * g8 * HB_BLK, smem + slot * BD_SLOT + (w + 4) * 1024);
+                BD_DMA(bf, lds_0 + slot_f + (unsigned)w * 1024u, lane_off)
+                BD_DMA(bf, lds_0 + slot_f + (unsigned)(w + 4) * 1024u, lane_off_hi)
             }
         };
-        int bt = seg.b_tile0, ks = 0;          // tile / stage being computed
-        int fbt = seg.b_tile0, fks = 0;        // next stage to fetch
-        int slot_c = 0, slot_f = 0, left = total;
-        int fpar = 0, cpar = 0;                // row-init double buffer: parity of the tile being fetched / computed
         auto advance_fetch = [&]() {
-            if (fks == 0 && w == 0) glds16(a.binit + (size_t)fbt * HB_BT + lane * 4, smem + BD_BINIT + fpar * 1024);
-            if (--left > 0) { if (++fks == g8) { fks = 0; fbt += bstride; fpar ^= 1; } }
-            if (++slot_f == BD_RING) slot_f = 0;
+            if (fks == 0 && w == 0) BD_DMA(reinterpret_cast<const char*>(HB_KARG(knn_args, binit) + (size_t)fbt * HB_BT), lds_0 + BD_BINIT + fpar, lane_off)
+            if (--left > 0) {
+                qfp += 1024; bf += 1024;
+                if (++fks == g8) {
+                    fks = 0; fbt += bstride; fpar ^= 1024u;
+                    qfp -= (size_t)g8 * 1024;
+                    bf += ((long long)bstride * 8 - 1) * g8 * 1024;
+                }
+            }
+            slot_f = (slot_f + BD_SLOT) & (BD_RING * BD_SLOT - 1);
         };
         // vmcnt by hand.  Per stage a wave requests, in this order: (waves 0-3) two bank pieces, then its query fragment
         // (wave 0, first stage of a tile: the row-init values behind it, which only makes a wait stricter).  The requests
         // of stage j are issued during stage j - 3; at the top of stage s those of stage s + 1 must have landed, those of
         // stage s + 2 may be in flight: "all but the newest 3" (waves 4-7: 1).  Past the last stage the fetch position stays
         // put (same requests again, results unused), so the count never changes.
-        issue_a(fbt, fks, slot_f); BD_BLOAD(bq[0]) advance_fetch();
-        issue_a(fbt, fks, slot_f); BD_BLOAD(bq[1]) advance_fetch();
-        issue_a(fbt, fks, slot_f); BD_BLOAD(bq[2]) advance_fetch();
+        issue_a(); BD_BLOAD(bq[0]) advance_fetch();
+        issue_a(); BD_BLOAD(bq[1]) advance_fetch();
+        issue_a(); BD_BLOAD(bq[2]) advance_fetch();
         BD_WAIT(6, 2, bq[0])     // stage 0 landed; stages 1-2 in flight
         __syncthreads();
         {
@@ -119,7 +140,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
             for (int t = 0; t < 4; ++t) fa[t] = A[t * 64 + lane];
         }
         // the requests are issued in the X half of the stage (in the Y half: no gain, 5 M x 768 1149 / 1147 / 1161 ms)
-#define BD_REQ_X1 issue_a(fbt, fks, slot_f);
+#define BD_REQ_X1 issue_a();
 #define BD_REQ_X2(U) BD_BLOAD(bq[((U) + 3) & 3])
 #define BD_REQ_X3 advance_fetch();
 #define BD_REQ_Y1(U)
