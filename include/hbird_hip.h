@@ -196,11 +196,11 @@ int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_tiles);
 int hb_index_set_fp16(hb_index_t* ix, int enable);
 /* Number of queries of the last fp16-mode search that needed the exact fp32 re-search. */
 int hb_index_last_fp16_fallbacks(const hb_index_t* ix, int64_t* n);
-/* kNN kernel variant, for A/B runs and tests (same results): 0 = default; 2 = the first design of the fp16 candidate kernel (query
- * fragments staged through LDS; what pools beyond 256 entries run anyway); 3 = the fp32 kernel with register-resident query fragments
+/* kNN kernel variant, for A/B runs and tests (same results): 0 = default; 3 = the fp32 kernel with register-resident query fragments
  * wherever it applies (D padded to a multiple of 32: what the default does too); 4 = never that kernel (both operands staged through
  * LDS); 6 = small fp32 searches with k <= 32 on sorted LDS lists as until round 3 (the default runs them on phased candidate pools).
- * 1 (4-wave fp32 kernel) and 5 (16x16x32 fp16 kernel) no longer exist: same bits, not faster. */
+ * 1 (4-wave fp32 kernel), 2 (first design of the fp16 candidate kernel) and 5 (16x16x32 fp16 kernel) no longer exist: same bits,
+ * not faster. */
 int hb_index_set_variant(hb_index_t* ix, int variant);
 /* Two more A/B switches (same results): phases = 0 launches a pool search (k > 32, use_fp16, small fp32 searches) once instead of in
  * phases; small_limit_stages > 0 moves the size (k8 stages per workgroup) below which a search takes the small-search kernels (0 =

@@ -220,7 +220,8 @@ extern "C" int hb_index_set_cluster(hb_index_t* ix, int cluster_q, int cluster_b
 extern "C" int hb_index_set_variant(hb_index_t* ix, int variant) {
     if (!ix) return hb_fail("hb_index_set_variant: NULL index handle");
     if (variant < 0 || variant > 6) return hb_fail("hb_index_set_variant: unknown kernel variant");
-    if (variant == 1 || variant == 5) return hb_fail("hb_index_set_variant: variants 1 (4-wave fp32 kernel) and 5 (16x16x32 fp16 kernel) were removed in round 4 (same bits, not faster)");
+    if (variant == 1 || variant == 2 || variant == 5)
+        return hb_fail("hb_index_set_variant: variants 1 (4-wave fp32 kernel), 2 (first fp16 design) and 5 (16x16x32 fp16 kernel) were removed in round 4 (same bits, not faster)");
     ix->variant = variant;
     return 0;
 }

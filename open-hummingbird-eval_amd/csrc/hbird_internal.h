@@ -152,7 +152,7 @@ int hb_launch_bnorm_max(const float* bnorm, int64_t n, float* bmax, hipStream_t 
 int hb_launch_scatter_rows(const int64_t* rows, int64_t n, int k, const int64_t* src_idx, const float* src_dist,
                            int64_t* out_idx, float* out_dist, hipStream_t s);
 struct knn16_args;
-int hb_knn_f16_launch(const knn16_args& args, int grid, int design, hipStream_t s);
+int hb_knn_f16_launch(const knn16_args& args, int grid, hipStream_t s);
 // label storage: fp32 values, or uint16 counts of values j / P (exactly the fp32 value: K2 computes (float)j / (float)P)
 int hb_launch_labels_to_counts(const float* src, int64_t n, int P, uint16_t* dst, int* flag, hipStream_t s);
 int hb_launch_gather_label_counts(const uint16_t* src, int64_t src_rows, int c, int P, const int64_t* ids, int64_t n, float* out, hipStream_t s);

@@ -775,12 +775,6 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // Same results either way.
     bool f16 = ix->fp16 != 0 && k <= 128 && (ix->fp16 == 1 || (ix->ntotal >= 16384 && ix->ntotal * nq >= ((int64_t)1 << 27)));
     if (!f16) ix->last_fp16_fallbacks = 0;      // a plain fp32 search: nothing fell back (the counter is not left over from an earlier search)
-    // which candidate kernel: 2 = the second design (32x32x16 MFMA, register-resident query fragments: the default wherever its pools
-    // fit, k' <= 128, i.e. k <= 64), 1 = the first design (variant 2, and pools beyond 256 entries).  (A third design on
-    // v_mfma_f32_16x16x32_f16 -- same bits, same speed, rounds 3 / 4 -- was removed: profiles/r03/f16_mfma_shape_ab.md.)
-    const int kc_f16 = std::min(256, std::max(64, (2 * k + 63) / 64 * 64));
-    const int klw_f16 = std::min(HB_POOL_MAX, (std::max(2 * kc_f16, kc_f16 + 128) + 63) / 64 * 64);
-    const int f16_design = (ix->variant == 2 || klw_f16 > 256) ? 1 : 2;
     if (f16 && nq > 0 && ix->ntotal > 0) {
         // bring the fp16 copy of the bank fragment tiles up to date.  A finite value beyond the fp16 range (|x| > 65504) turns
         // into inf there and the scores into inf / NaN, which the exactness certificate cannot bound: such a bank stays on the
@@ -972,7 +966,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         }
         for (int ph = 0; ph < n_phases; ++ph) {
             h.wg_off = phase_begin(ph); h.wg_end = phase_end(ph);
-            if (hb_knn_f16_launch(h, sc.G, f16_design, s)) return -1;
+            if (hb_knn_f16_launch(h, sc.G, s)) return -1;
             if (ph + 1 < n_phases) {   // the k'-th best of all rows seen so far -> every slot's floor
                 if (seed_floors(kc, cand_idx, cand_dist)) return -1;
                 if (a.cl > 1) HB_HIP(hipMemsetAsync(a.prog, 0, prog_bytes - HB_CLUSTER_LINE * 4, s));   // progress words (not the statistics)

@@ -208,8 +208,11 @@ __device__ __forceinline__ unsigned pool_kth(const unsigned (&key)[EMAX], bool (
 // Compact the full pool (cap entries, cap <= 64 EMAX) at (gs, gi) to its best k in entries [0, k); returns the k-th best
 // score.  (A variant for partly filled pools -- per-lane validity masks -- cost the fp32 pool kernel its scalar registers:
 // reloads of spilled SGPRs in every stage, +10 % kernel time at k = 90.)
+// NOT inlined (round 4): a real function call on the rare compaction path.  Inlined at every call site its 4 x EMAX value registers and
+// the radix select's masks set the register budget of the whole kernel -- spilled SGPRs reloaded in the stage loops (fp16 candidate
+// kernel, pools of 384: 373 -> 328 ms at 10 M x 768, k = 90; every pool instantiation lost half of its spills or more).
 template <int EMAX = HB_POOL_MAX / 64>
-__device__ __forceinline__ float pool_compact(float* gs, unsigned* gi, int cap, int k, int lane) {
+__device__ __attribute__((noinline)) float pool_compact(float* gs, unsigned* gi, int cap, int k, int lane) {
     const int E = cap >> 6;
     float es[EMAX];
     unsigned ei[EMAX], key[EMAX];

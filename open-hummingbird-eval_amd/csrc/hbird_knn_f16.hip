@@ -8,24 +8,12 @@
 // top-k lie within the fp16 top-k' -- their fp16 scores would have to be off by more than the gap between rank k
 // and rank k' for that to fail.
 //
-// The candidate kernel is bound by LDS staging (128 FLOP per staged byte), not by the matrix pipe: a stage is
-// k = 32 (16 KiB of bank + 16 KiB of query fragments) in a 4-slot ring (128 KiB of LDS, three stages in flight); the
-// per-query candidate pools live in HBM (the WIDE path), only the thresholds stay in registers.
+// The per-query candidate pools live in HBM (the WIDE path of the fp32 kernels), only the thresholds stay in registers.
 #include "hbird_knn_dev.h"
 #include <algorithm>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-#define F16_GROUPS 2                                   // k16 fragment groups per stage (k = 32)
-#define F16_RING 4                                     // ring slots: one being read, three in flight
-#define F16_HALF (8 * F16_GROUPS * 1024)               // bank fragments of a stage, then as many bytes of query fragments
-#define F16_SLOT_BYTES (2 * F16_HALF)
-#define F16_BINIT (F16_RING * F16_SLOT_BYTES)
-#define F16_SCRATCH (F16_BINIT + 2048)
-#define F16_PCNT (F16_SCRATCH + 8192)                  // pool fill counts of the 256 queries
-#define F16_CLWORDS (F16_PCNT + 1024)                  // landing zone of the cluster progress poll
-#define F16_LDS_TOTAL (F16_CLWORDS + 64)
-static_assert(F16_LDS_TOTAL <= 160 * 1024, "LDS budget");
 
 // fp32 fragment tiles -> fp16 fragment tiles.  fp16 block(rt, g16) = 32 rows x 16 k = 1 KiB, element (i, kk) at half
 // index ((kk >> 3) * 32 + i) * 8 + (kk & 7): lane l = h*32 + i reads 8 halves = k = 16 g16 + 8h + 0..7, the A/B
@@ -64,153 +52,10 @@ int hb_launch_tiles_to_f16(const float* t32, int g8, _Float16* t16, int g16, int
     return 0;
 }
 
-// 8 waves (two per SIMD); wave w owns queries [32w, 32w + 32) against all 256 bank rows of the tile (8 accumulator
-// tiles).  A 32x32x16 f16 MFMA takes 32 cycles, so per k16 group a SIMD has 512 cycles of matrix work against 72 KiB of
-// fragment reads (576 LDS cycles for the workgroup) plus the copies: the loop only works if reads, copies and MFMAs
-// overlap completely.  Software pipeline: while the 8 MFMAs of a group run, the 9 fragments of the next group are read
-// into the other register set and -- in the second group of a k32 stage, waves 0-3 only -- the 8 copies of the stage four
-// ahead are issued, one filler per MFMA, pinned with sched_barrier.  The stage's barrier sits between its two groups:
-// after it everybody has read both groups of this stage (its slot is free for the new copies) and the next stage, whose
-// first fragments are read next, has landed for everyone.
-// Measured alternatives (10 M x 768, k = 30, kernel ms; this kernel: see DESIGN.md): unpipelined 8 waves with a 2-slot
-// k64 ring 388, 4-slot k32 ring 388-397, 9-slot k16 ring 440; 4 waves x (64 queries x 256 rows) with 256 AGPR
-// accumulators, compiler-scheduled 434, pipelined like this 404 (one wave per SIMD: every stall of the copies' issue
-// stalls the MFMA stream, there is no partner wave to cover it).
-__global__ __launch_bounds__(HB_THREADS, 2) void knn_f16_kernel(knn16_args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5;
-    float* sc = reinterpret_cast<float*>(smem + F16_SCRATCH) + w * 256;
-    int* pcnt = reinterpret_cast<int*>(smem + F16_PCNT);
-    const int g16 = a.g16, k = a.k, klw = a.klw;
-    const int NS = g16 / F16_GROUPS;   // k32 stages per bank tile
-    const int myq = w * 32 + (lane & 31);
-    cl_sync cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + F16_CLWORDS);
-
-    const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_end[blockIdx.x];   // this launch's share of the block's segments (phases: hb_launch_knn)
-    // "everything before my first segment is done" (a member without any work: everything)
-    if (w == 0) cl_publish(cs, seg_begin < seg_end ? a.segs[seg_begin].tile0 * NS : 0x7FFFFFFF, lane);
-    for (int si = seg_begin; si < seg_end; ++si) {
-        const hb_seg seg = a.segs[si];
-        const int bstride = seg.stride;
-        int fpar = 0, cpar = 0;   // row-init double buffer: parity of the tile being fetched / computed
-        float* wl_s = a.state_s + (size_t)seg.slot * HB_QT * klw;
-        unsigned* wl_i = a.state_i + (size_t)seg.slot * HB_QT * klw;
-        const knn_args_pool_view pv{a.state_cnt, a.state_thr};
-        float thr = pool_begin(pv, seg.slot, seg.first, pcnt, myq, lane);
-        thr = fmaxf(thr, floor_load(a.gthr, seg.q_tile * HB_QT + myq));
-        const int total = seg.n_tiles * NS;
-        f32x16 acc[8];
-
-        // stage (bt, ks): 16 bank blocks (8 row tiles x 2 k16 groups) + 16 query blocks of 1 KiB; waves 0-3 issue 8 copies
-        // each.  Copy i of wave w: row tile w + 4 (i >> 2), k16 group (i >> 1) & 1, bank (i even) or query (i odd).
-        // Addresses = wave-uniform 64-bit base + 32-bit lane offset.
-        const char* bank_w = reinterpret_cast<const char*>(a.bank16) + (size_t)w * g16 * 1024;
-        const char* query_w = reinterpret_cast<const char*>(a.q16) + (size_t)(seg.q_tile * 8 + w) * g16 * 1024;
-        const unsigned lane_off = (unsigned)lane * 16u;
-        auto issue_one = [&](int i, int bt, int ks, int slot) {
-            if (w < 4) {
-                const int r = i >> 2, g = (i >> 1) & 1;
-                char* dst = smem + slot * F16_SLOT_BYTES + ((w + 4 * r) * F16_GROUPS + g) * 1024;
-                const size_t off = ((size_t)4 * r * g16 + ks * F16_GROUPS + g) * 1024;
-                const char* qw = query_w;
-                if (i & 1) __builtin_amdgcn_global_load_lds((gbl_cvoid*)(qw + off + lane_off), (lds_void*)(dst + F16_HALF), 16, 0, 0);
-                else __builtin_amdgcn_global_load_lds((gbl_cvoid*)(bank_w + (size_t)bt * 8 * g16 * 1024 + off + lane_off), (lds_void*)dst, 16, 0, 0);
-            }
-        };
-        auto issue_binit = [&](int bt, int ks) {
-            if (ks == 0 && w == 0) glds16(a.binit + (size_t)bt * HB_BT + lane * 4, smem + F16_BINIT + fpar * 1024);
-        };
-
-        // vmcnt is counted by hand as in the fp32 kernel: an issuing wave has 8 copies per stage in flight (wave 0 a ninth,
-        // the row-init values, with the first stage of a tile; epilogue stores only make the wait stricter), so "all but
-        // the newest 16" = the next stage has landed, two more are in flight.  Past the last stage the fetch position
-        // stays put and re-fills a free slot; the fragment reads past the end are unused.
-        int bt = seg.b_tile0;                  // tile being computed
-        int fbt = seg.b_tile0, fks = 0;        // next stage to fetch
-        int slot_c = 0, slot_f = 0;
-        int left = total;
-        auto advance_fetch = [&]() {
-            if (--left > 0) { if (++fks == NS) { fks = 0; fbt += bstride; fpar ^= 1; } }
-            if (++slot_f == F16_RING) slot_f = 0;
-        };
-        for (int p = 0; p < F16_RING; ++p) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) issue_one(i, fbt, fks, slot_f);
-            issue_binit(fbt, fks);
-            advance_fetch();
-        }
-        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // stage 0 has landed; stages 1-3 in flight
-        __syncthreads();
-        f16x8 fa[8], ga[8], fb, gb;                         // fragments of the current / the next k16 group
-#define F16_MM(T, FA, FB) acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[T], FB, acc[T], 0, 0, 0);
-        for (int tl = 0; tl < seg.n_tiles; ++tl, bt += bstride, cpar ^= 1) {
-            {   // first fragments of the tile (read again rather than kept live across the epilogue: fewer registers)
-                const f16x8* A = reinterpret_cast<const f16x8*>(smem + slot_c * F16_SLOT_BYTES) + lane;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) fa[t] = A[(t * F16_GROUPS) * 64];
-                fb = A[F16_HALF / 16 + (w * F16_GROUPS) * 64];
-            }
-            {   // accumulators start from the bank rows' init values (landed with the tile's first stage)
-                const f32x4* bi = reinterpret_cast<const f32x4*>(smem + F16_BINIT + cpar * 1024);
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 v = bi[8 * t + 2 * g + h];
-                        acc[t][4 * g + 0] = v[0]; acc[t][4 * g + 1] = v[1];
-                        acc[t][4 * g + 2] = v[2]; acc[t][4 * g + 3] = v[3];
-                    }
-            }
-#pragma nounroll
-            for (int ks = 0; ks < NS; ++ks) {
-                int slot_n = slot_c + 1; if (slot_n == F16_RING) slot_n = 0;
-                const f16x8* Ac = reinterpret_cast<const f16x8*>(smem + slot_c * F16_SLOT_BYTES) + lane;
-                const f16x8* An = reinterpret_cast<const f16x8*>(smem + slot_n * F16_SLOT_BYTES) + lane;
-                // ---- group 0 of the stage; fillers: the fragments of group 1 ----
-                KN_FENCE F16_MM(0, fa, fb) KN_FENCE ga[0] = Ac[(0 * F16_GROUPS + 1) * 64]; gb = Ac[F16_HALF / 16 + (w * F16_GROUPS + 1) * 64];
-                KN_FENCE F16_MM(1, fa, fb) KN_FENCE ga[1] = Ac[(1 * F16_GROUPS + 1) * 64];
-                KN_FENCE F16_MM(2, fa, fb) KN_FENCE ga[2] = Ac[(2 * F16_GROUPS + 1) * 64];
-                KN_FENCE F16_MM(3, fa, fb) KN_FENCE ga[3] = Ac[(3 * F16_GROUPS + 1) * 64];
-                KN_FENCE F16_MM(4, fa, fb) KN_FENCE ga[4] = Ac[(4 * F16_GROUPS + 1) * 64];
-                KN_FENCE F16_MM(5, fa, fb) KN_FENCE ga[5] = Ac[(5 * F16_GROUPS + 1) * 64];
-                KN_FENCE F16_MM(6, fa, fb) KN_FENCE ga[6] = Ac[(6 * F16_GROUPS + 1) * 64];
-                KN_FENCE F16_MM(7, fa, fb) KN_FENCE ga[7] = Ac[(7 * F16_GROUPS + 1) * 64];
-                KN_FENCE
-                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // my copies of the next stage have landed
-                __syncthreads();                                      // ... everyone's have, and this stage's slot has been read
-                // ---- group 1; fillers: the first fragments of the next stage and the copies of the stage four ahead ----
-                KN_FENCE F16_MM(0, ga, gb) KN_FENCE fa[0] = An[(0 * F16_GROUPS) * 64]; fb = An[F16_HALF / 16 + (w * F16_GROUPS) * 64];
-                if (w == 0) cl_tick(cs, (seg.tile0 + tl) * NS + ks, lane);   // cluster soft sync, ahead of the stage's copies (vmcnt)
-                issue_one(0, fbt, fks, slot_f);
-                KN_FENCE F16_MM(1, ga, gb) KN_FENCE fa[1] = An[(1 * F16_GROUPS) * 64]; issue_one(1, fbt, fks, slot_f);
-                KN_FENCE F16_MM(2, ga, gb) KN_FENCE fa[2] = An[(2 * F16_GROUPS) * 64]; issue_one(2, fbt, fks, slot_f);
-                KN_FENCE F16_MM(3, ga, gb) KN_FENCE fa[3] = An[(3 * F16_GROUPS) * 64]; issue_one(3, fbt, fks, slot_f);
-                KN_FENCE F16_MM(4, ga, gb) KN_FENCE fa[4] = An[(4 * F16_GROUPS) * 64]; issue_one(4, fbt, fks, slot_f);
-                KN_FENCE F16_MM(5, ga, gb) KN_FENCE fa[5] = An[(5 * F16_GROUPS) * 64]; issue_one(5, fbt, fks, slot_f);
-                KN_FENCE F16_MM(6, ga, gb) KN_FENCE fa[6] = An[(6 * F16_GROUPS) * 64]; issue_one(6, fbt, fks, slot_f);
-                KN_FENCE F16_MM(7, ga, gb) KN_FENCE fa[7] = An[(7 * F16_GROUPS) * 64]; issue_one(7, fbt, fks, slot_f);
-                issue_binit(fbt, fks);
-                advance_fetch();
-                KN_FENCE
-                slot_c = slot_n;
-            }
-            tile_epilogue<true, true>(acc, thr, wl_s, wl_i, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
-        }
-#undef F16_MM
-        if (w == 0) cl_publish(cs, seg.next_tile0 == 0x7FFFFFFF ? 0x7FFFFFFF : seg.next_tile0 * NS, lane);   // covers idle units
-        pool_end(pv, seg.slot, pcnt, thr, myq, lane);
-        if (lane < 32) floor_publish(a.gthr, seg.q_tile * HB_QT + myq, thr);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    cl_finish(cs, a.cl_stats, w == 0, lane);
-}
-
-// ---- second design of the candidate kernel -----------------------------------------------------------------------------
-// What bounds the kernel above was measured in round 2 (profiles/r02): NOT the fabric -- the L2's average read latency
+// ---- the candidate kernel ---------------------------------------------------------------------------------------------
+// (Its first design staged BOTH operands through a 4-slot LDS ring of k32 stages and ran at 0.34 of the nominal fp16 peak; it served
+// pools beyond 256 entries until round 4 and is gone now -- this kernel's <8> instantiation compacts pools of up to 512.)
+// What bounded that first design was measured in round 2 (profiles/r02): NOT the fabric -- the L2's average read latency
 // at the memory side is ~610 cycles under this kernel's load (TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ), and 41 % fewer
 // fabric reads (L2-sharing clusters) bought 1.7 % -- but the LDS: per k16 group the workgroup reads 72 KiB of fragments
 // (>= 288 cycles) and takes in 16 KiB of LDS-DMA copies (281 cycles: an LDS-DMA byte costs the LDS about four times a
@@ -516,17 +361,12 @@ int hb_launch_rerank(const float* tiles, const float* binit, int g8, int d, cons
     return 0;
 }
 
-int hb_knn_f16_launch(const knn16_args& args, int grid, int design, hipStream_t s) {
-    if (design != 1 && args.klw <= 256) {   // second design (default); pools beyond 256 entries (k > 64): the compaction's
-        // registers do not fit beside the query-fragment buffers without spills, the first design serves those
-        void (*fn)(knn16_args) = knn_f16v2_kernel<4>;
-        if (hb_ensure_dyn_lds((const void*)fn, F2_LDS_TOTAL)) return -1;
-        fn<<<dim3((unsigned)grid), dim3(HB_THREADS), F2_LDS_TOTAL, s>>>(args);
-        HB_HIP(hipGetLastError());
-        return 0;
-    }
-    if (hb_ensure_dyn_lds((const void*)knn_f16_kernel, F16_LDS_TOTAL)) return -1;
-    knn_f16_kernel<<<dim3((unsigned)grid), dim3(HB_THREADS), F16_LDS_TOTAL, s>>>(args);
+int hb_knn_f16_launch(const knn16_args& args, int grid, hipStream_t s) {
+    // <4> compacts pools of up to 256 entries (k <= 64), <8> up to HB_POOL_MAX = 512 (its rare compaction path holds twice the registers)
+    void (*fn)(knn16_args) = args.klw <= 256 ? knn_f16v2_kernel<4> : knn_f16v2_kernel<8>;
+    if (args.klw > 512) return hb_fail("hb_index_search: candidate pools beyond 512 entries");
+    if (hb_ensure_dyn_lds((const void*)fn, F2_LDS_TOTAL)) return -1;
+    fn<<<dim3((unsigned)grid), dim3(HB_THREADS), F2_LDS_TOTAL, s>>>(args);
     HB_HIP(hipGetLastError());
     return 0;
 }

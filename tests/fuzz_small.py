@@ -24,7 +24,7 @@ for c in range(n_cases):
     if rng.integers(0, 3) == 0:                                                   # non-finite values (tests/test_edge_gpu.py): NaN rows, NaN / inf queries
         bank[rng.integers(0, M, size=max(1, M // 50))] = np.nan
         q[rng.integers(0, nq, size=max(1, nq // 100)), rng.integers(0, D)] = [np.nan, np.inf, -np.inf][int(rng.integers(0, 3))]
-    variant = int(rng.choice([0, 0, 2, 3, 4, 6])); cl = [(0, 0, -1), (0, 0, -1), (2, 2, 4), (2, 4, 16)][int(rng.integers(0, 4))]
+    variant = int(rng.choice([0, 0, 3, 4, 6])); cl = [(0, 0, -1), (0, 0, -1), (2, 2, 4), (2, 4, 16)][int(rng.integers(0, 4))]
     ix = HipFlatIndex(D, metric, 0); ix.add(torch.from_numpy(bank).cuda()); ix.set_fp16(fp16); ix.set_tuning(G, 0)
     ix.set_variant(variant); ix.set_cluster(*cl)
     idx, dist = ix.search(torch.from_numpy(q).cuda(), k)

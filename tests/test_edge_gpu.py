@@ -50,8 +50,7 @@ _PATHS = [
     (20_000, 64, 700, 30, "l2", False, 0, None),             # L2: NaN row init (-0.5 |b|^2)
     (20_000, 64, 300, 90, "dot_product", False, 0, None),    # candidate pools (k > 32)
     (20_000, 64, 700, 30, "dot_product", True, 0, None),     # fp16 candidate kernel (second design) + re-rank
-    (20_000, 64, 300, 100, "dot_product", True, 0, None),    # fp16 candidate kernel, pools beyond 256 entries (first design)
-    (20_000, 64, 700, 30, "dot_product", 2, 0, None),        # fp16 candidate kernel, first design forced (variant 2)
+    (20_000, 64, 300, 100, "dot_product", True, 0, None),    # fp16 candidate kernel, pools beyond 256 entries (its <8> instantiation)
     (70_001, 64, 1300, 30, "dot_product", False, 64, (2, 4, 4)),   # clustered schedule
     (1_600_000, 64, 2048, 30, "dot_product", False, 1, None),      # 400 k stages per workgroup: the plain instantiation
     (150, 64, 70, 30, "dot_product", True, 0, None),         # fewer finite rows than candidates: nothing to certify
@@ -67,8 +66,6 @@ def test_nan_bank_rows_never_enter_a_list(cuda_device, M, D, nq, k, metric, fp16
     if fp16 == -6:
         ix.set_variant(6); fp16 = False
     ix.set_fp16(bool(fp16))
-    if fp16 == 2:
-        ix.set_variant(2)
     if G:
         ix.set_tuning(G, 0)
     if cluster:

@@ -355,12 +355,12 @@ def test_wide_k_aggregate(cuda_device):
 
 
 def test_removed_kernel_variants_are_rejected(cuda_device):
-    """Variants 1 (4-wave fp32 kernel) and 5 (16x16x32 fp16 kernel) left the library in round 4 (same bits, not faster)."""
+    """Variants 1 (4-wave fp32 kernel), 2 (first fp16 design) and 5 (16x16x32 fp16 kernel) left the library in round 4 (same bits, not faster)."""
     ix = HipFlatIndex(32, 0, 0)
-    for v in (1, 5, 7, -1):
+    for v in (1, 2, 5, 7, -1):
         with pytest.raises(RuntimeError):
             ix.set_variant(v)
-    ix.set_variant(2); ix.set_variant(0)
+    ix.set_variant(3); ix.set_variant(0)
 
 
 @pytest.mark.parametrize("variant", [3, 4, 6])   # 6: small searches on sorted LDS lists (the default runs them on pools since round 3)
@@ -489,12 +489,9 @@ def test_use_fp16_candidate_pass_with_exact_rerank(cuda_device, M, D, nq, k, met
     ix.add(bank[:100] * 0.5)                    # appending after a search re-converts the touched tiles
     idx, dist = ix.search(q, k)
     _check_exact(idx, dist, q, np.concatenate([bank, bank[:100] * 0.5]), k, metric)
-    # the other candidate kernel (2: first design, query fragments staged through LDS) and back: the same bits
-    for variant in (2, 0):
-        ix.set_variant(variant)
-        ix.set_tuning(0 if variant else 6, 0)
-        idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
-        _check_exact(idx, dist, q, np.concatenate([bank, bank[:100] * 0.5]), k, metric)
+    ix.set_tuning(0, 0)
+    idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
+    _check_exact(idx, dist, q, np.concatenate([bank, bank[:100] * 0.5]), k, metric)
 
 
 def test_use_fp16_certificate_and_exact_fallback(cuda_device):
