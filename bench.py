@@ -181,7 +181,7 @@ def cpu_baseline(D, k, M_total):
     oracle.set_num_threads(threads)
     _t.set_num_threads(threads)
     rng = np.random.default_rng(0)
-    ms, nqs = 400_000, 2048            # ~10-25 s of CPU work on 16 granted cores
+    ms, nqs = 400_000, 6144            # ~15 s of CPU work on the 16 cores this pool grants (oracle 6 + 3 s, BLAS legs ~5 s)
     bank = rng.standard_normal((ms, D), dtype=np.float32)
     bank /= np.linalg.norm(bank, axis=1, keepdims=True)
     q = 3.0 * rng.standard_normal((nqs, D), dtype=np.float32)
