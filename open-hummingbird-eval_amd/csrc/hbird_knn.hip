@@ -934,7 +934,10 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         const int* qo = reinterpret_cast<const int*>(ix->sched_dev + o_qo);
         const int* qs = reinterpret_cast<const int*>(ix->sched_dev + o_qs);
         const size_t per_wave = (size_t)sc.max_slots_per_qt * klw;
-        if (per_wave * 16 <= 48 * 1024) {
+        // (up to 144 KiB of the CU's 160: 32 slots per query tile x pools of 256, 16 x 512 -- the merge path below costs a phase boundary
+        // ten times as much: 10 M x 768, k = 90 with 16 slots per query tile: 2.9 -> 44.7 ms per search, profiles/r04/cluster_tail_rows_ab.txt)
+        if (per_wave * 16 <= 144 * 1024) {
+            if (per_wave * 16 > 48 * 1024 && hb_ensure_dyn_lds((const void*)pool_floor_kernel, 144 * 1024)) return -1;
             pool_floor_kernel<<<dim3((unsigned)((nq + 3) / 4)), dim3(256), per_wave * 16, s>>>(a.state_s, a.state_cnt, a.state_thr, qo, qs, nq, kk,
                                                                                                klw, (int)per_wave, a.gthr);
             HB_HIP(hipGetLastError());

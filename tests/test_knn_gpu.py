@@ -74,6 +74,7 @@ def test_search_any_work_partition(cuda_device, G, panel):
     (2, 2, 6, 32, 0, 30, False, "dot_product"), (2, 2, 0, 64, 6, 30, False, "l2"), (4, 2, 3, 64, 0, 30, False, "dot_product"),
     (2, 4, 1, 64, 5, 90, False, "dot_product"), (1, 4, 6, 32, 3, 30, True, "dot_product"), (8, 1, 2, 64, 0, 30, True, "l2"),
     (2, 2, 6, 256, 0, 30, False, "dot_product"), (2, 2, 4, 256, 0, 64, True, "dot_product"), (2, 4, 16, 256, 0, 30, False, "l2"),
+    (4, 2, 3, 128, 0, 90, True, "dot_product"),      # 16 slots per query tile x pools of 512: the floor kernel with 128 KiB of LDS
 ])
 def test_clustered_schedules_bit_exact(cuda_device, cq, cb, lag, G, panel, k, fp16, metric, D):
     """L2-sharing clusters (strided segments, common cluster clock, soft sync on progress words) are a speed feature: the
