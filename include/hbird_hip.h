@@ -206,6 +206,13 @@ int hb_index_set_variant(hb_index_t* ix, int variant);
  * phases; small_limit_stages > 0 moves the size (k8 stages per workgroup) below which a search takes the small-search kernels (0 =
  * the built-in 400,000). */
 int hb_index_set_search_options(hb_index_t* ix, int phases, int64_t small_limit_stages);
+/* use_fp16 searches re-rank their candidates in exact fp32 arithmetic.  In the fragment tiles a bank row is 2 x D/8 sixteen-byte pieces
+ * 512 B apart, so that pass pulls eight times the bytes it uses; a second, row-major fp32 copy of the bank lets it read whole lines (a
+ * use_fp16 search at 300,000 x 768: 8.0 -> 6.6 ms, k = 90: 18.0 -> 12.4; results identical).  mode 0 = automatic: the copy is made at the first use_fp16
+ * search if the device then still has a third of its memory free; 1 = always (an error if the allocation fails); 2 = never (an
+ * existing copy is released).  hb_index_rerank_copy_bytes: what the copy occupies now (0 = none). */
+int hb_index_set_rerank_copy(hb_index_t* ix, int mode);
+int hb_index_rerank_copy_bytes(const hb_index_t* ix, int64_t* bytes);
 /* Work-list statistics of the last search: out[0]=workgroups, [1]=segments, [2]=slots, [3]=panel tiles,
  * [4]=max slots per query tile, [5]=query tiles, [6]=bank tiles, [7]=cluster shape (query ways * 16 + bank ways). */
 int hb_index_schedule_info(const hb_index_t* ix, int64_t out[8]);

@@ -84,7 +84,7 @@ extern "C" int hb_index_free(hb_index_t* ix) {
     (void)hipSetDevice(ix->device);
     (void)hipStreamSynchronize(ix->stream);
     void* ptrs[] = {ix->tiles, ix->binit, ix->bnorm, ix->labels, ix->q_tiles, ix->q_aux, ix->state, ix->sched_dev, ix->tmp,
-                    ix->tiles16, ix->q16, ix->cand, ix->bmax, ix->fb, ix->mtmp, ix->f16_flag, ix->labels16, ix->lab_flag};
+                    ix->tiles16, ix->q16, ix->cand, ix->bmax, ix->fb, ix->mtmp, ix->f16_flag, ix->labels16, ix->lab_flag, ix->rows32};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ix->ev0) (void)hipEventDestroy(ix->ev0);
     if (ix->ev1) (void)hipEventDestroy(ix->ev1);
@@ -231,6 +231,23 @@ extern "C" int hb_index_set_search_options(hb_index_t* ix, int phases, int64_t s
     ix->phases_on = phases ? 1 : 0; ix->small_limit = small_limit_stages; ix->sched = hb_schedule();
     return 0;
 }
+extern "C" int hb_index_set_rerank_copy(hb_index_t* ix, int mode) {
+    if (!ix) return hb_fail("hb_index_set_rerank_copy: NULL index handle");
+    if (mode < 0 || mode > 2) return hb_fail("hb_index_set_rerank_copy: mode must be 0 (automatic), 1 (always) or 2 (never)");
+    ix->rerank_copy = mode;
+    if (mode == 2 && ix->rows32) {
+        (void)hipSetDevice(ix->device);
+        HB_HIP(hipStreamSynchronize(ix->stream));
+        HB_HIP(hipFree(ix->rows32));
+        ix->rows32 = nullptr; ix->rows32_cap_rows = 0; ix->rows32_rows = 0;
+    }
+    return 0;
+}
+extern "C" int hb_index_rerank_copy_bytes(const hb_index_t* ix, int64_t* bytes) {
+    if (!ix || !bytes) return hb_fail("hb_index_rerank_copy_bytes: NULL argument");
+    *bytes = ix->rows32 ? ix->rows32_cap_rows * (int64_t)ix->rows32_rs * 4 : 0;
+    return 0;
+}
 extern "C" int hb_index_schedule_info(const hb_index_t* ix, int64_t out[8]) {
     if (!ix) return hb_fail("hb_index_schedule_info: NULL index handle");
     const hb_schedule& s = ix->sched;
@@ -287,7 +304,7 @@ extern "C" int hb_index_reset(hb_index_t* ix) {
         HB_HIP(hipStreamSynchronize(s));
     }
     HB_HIP(hipMemsetAsync(ix->bmax, 0, 4, s));
-    ix->ntotal = 0; ix->nlabels = 0; ix->lab_checked = 0; ix->f16_rows = 0; ix->f16_overflow = 0;
+    ix->ntotal = 0; ix->nlabels = 0; ix->lab_checked = 0; ix->f16_rows = 0; ix->f16_overflow = 0; ix->rows32_rows = 0;
     if (ix->lab_flag) HB_HIP(hipMemsetAsync(ix->lab_flag, 0, 4, s));
     if (ix->f16_flag) HB_HIP(hipMemsetAsync(ix->f16_flag, 0, 4, s));
     return 0;

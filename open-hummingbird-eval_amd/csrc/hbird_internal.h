@@ -106,6 +106,9 @@ struct hb_index {
     int fp16 = 0, dp16 = 0;
     void* tiles16 = nullptr; int64_t f16_cap_rows = 0, f16_rows = 0;
     int* f16_flag = nullptr; int f16_overflow = 0;       // a finite bank value overflowed fp16: the fp32 kernel serves this bank
+    // ... and, where memory allows, the bank once more as plain fp32 rows [row][rows32_rs] for the exact re-rank (hbird_knn_f16.hip)
+    float* rows32 = nullptr; int64_t rows32_cap_rows = 0, rows32_rows = 0; int rows32_rs = 0;
+    int rerank_copy = 0;                                 // 0 = automatic, 1 = always, 2 = never (hb_index_set_rerank_copy)
     void* q16 = nullptr; size_t q16_bytes = 0;
     char* cand = nullptr; size_t cand_bytes = 0;
     float* bmax = nullptr;                               // device scalar: max bank-row norm
@@ -144,6 +147,11 @@ int hb_launch_tiles_to_rows(const float* tiles, int g8, int d, const int64_t* id
 int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t id_base, int64_t* out_idx, float* out_dist);
 int hb_launch_tiles_to_f16(const float* t32, int g8, _Float16* t16, int g16, int64_t n_row_tiles, int64_t rt0, int* overflow,
                            hipStream_t s);
+int hb_launch_tiles_to_rows(const float* t32, int g8, float* rows, int rs, int64_t n_row_tiles, int64_t rt0, hipStream_t s);
+int hb_launch_rerank_rows(const float* rows, int rs, const float* binit, int d, const float* q, const float* qn2,
+                          const int64_t* cand, const float* cand_score, const float* qnorm, const float* bmax,
+                          unsigned char* certified, int kc, int64_t nq, int k, int64_t id_base, int metric, int out_metric,
+                          int64_t ntotal, int64_t* out_idx, float* out_dist, hipStream_t s);
 int hb_launch_rerank(const float* tiles, const float* binit, int g8, int d, const float* q, const float* qn2,
                      const int64_t* cand, const float* cand_score, const float* qnorm, const float* bmax,
                      unsigned char* certified, int kc, int64_t nq, int k, int64_t id_base, int metric, int out_metric, int64_t ntotal, int64_t* out_idx,

@@ -796,6 +796,29 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
             HB_HIP(hipStreamSynchronize(s0));
         }
         if (ix->f16_overflow) { f16 = false; ix->last_fp16_fallbacks = nq; }
+        // ... and the row-major fp32 copy for the re-rank (hbird_knn_f16.hip).  Automatic: only while the device keeps a third of its
+        // memory free beyond it (a 10 M x 768 bank: 30.7 GB of tiles + 15.4 GB of fp16 tiles + 30.7 GB of rows, of 288)
+        if (f16 && ix->rerank_copy != 2) {
+            const int rs = (ix->g8 * 8 + 31) / 32 * 32;
+            if (ix->rows32 && (ix->rows32_cap_rows != ix->cap_rows || ix->rows32_rs != rs)) {
+                HB_HIP(hipFree(ix->rows32));
+                ix->rows32 = nullptr; ix->rows32_cap_rows = 0; ix->rows32_rows = 0;
+            }
+            if (!ix->rows32) {
+                const size_t need = (size_t)ix->cap_rows * rs * 4;
+                size_t free_b = 0, total_b = 0;
+                HB_HIP(hipMemGetInfo(&free_b, &total_b));
+                if (ix->rerank_copy == 1 || (free_b > need && free_b - need > total_b / 3)) {
+                    if (hipMalloc((void**)&ix->rows32, need) == hipSuccess) { ix->rows32_cap_rows = ix->cap_rows; ix->rows32_rs = rs; ix->rows32_rows = 0; }
+                    else { (void)hipGetLastError(); ix->rows32 = nullptr; if (ix->rerank_copy == 1) return hb_fail("hb_index_search: no memory for the re-rank copy of the bank"); }
+                }
+            }
+            if (ix->rows32 && ix->rows32_rows < ix->ntotal) {
+                const int64_t rt0 = ix->rows32_rows / 32, need_rt = (ix->ntotal + 31) / 32;
+                if (hb_launch_tiles_to_rows(ix->tiles, ix->g8, ix->rows32, rs, need_rt - rt0, rt0, s0)) return -1;
+                ix->rows32_rows = ix->ntotal;
+            }
+        }
     }
     // fp16 mode: the fused kernel collects kc >= 2k candidates, the fp32 chain arithmetic re-ranks them
     const int kc = f16 ? std::min(256, std::max(64, (2 * k + 63) / 64 * 64)) : k;
@@ -981,8 +1004,11 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
                          cand_idx, cand_dist, s)) return -1;
         if (ensure_bytes(&ix->fb, &ix->fb_bytes, (size_t)nq + 64)) return -1;
         unsigned char* cert = reinterpret_cast<unsigned char*>(ix->fb);
-        if (hb_launch_rerank(ix->tiles, ix->binit, ix->g8, ix->d, q_dev, ix->q_aux, cand_idx, cand_dist, ix->q_aux + nq, ix->bmax,
-                             cert, kc, nq, k, id_base, ix->metric, out_metric, ix->ntotal, out_idx, out_dist, s)) return -1;
+        if (ix->rows32 && ix->rerank_copy != 2 && ix->rows32_rows >= ix->ntotal) {
+            if (hb_launch_rerank_rows(ix->rows32, ix->rows32_rs, ix->binit, ix->d, q_dev, ix->q_aux, cand_idx, cand_dist, ix->q_aux + nq, ix->bmax,
+                                      cert, kc, nq, k, id_base, ix->metric, out_metric, ix->ntotal, out_idx, out_dist, s)) return -1;
+        } else if (hb_launch_rerank(ix->tiles, ix->binit, ix->g8, ix->d, q_dev, ix->q_aux, cand_idx, cand_dist, ix->q_aux + nq, ix->bmax,
+                                    cert, kc, nq, k, id_base, ix->metric, out_metric, ix->ntotal, out_idx, out_dist, s)) return -1;
         if (ix->time_kernels) {
             HB_HIP(hipEventSynchronize(ix->ev1));
             float ms = 0.f;

@@ -361,6 +361,178 @@ int hb_launch_rerank(const float* tiles, const float* binit, int g8, int d, cons
     return 0;
 }
 
+// ---- the re-rank on a row-major copy of the bank ---------------------------------------------------------------------
+// In the fragment tiles a row is 2 x D/8 sixteen-byte pieces 512 B apart: the re-rank above pulls a 128-byte line for every piece it
+// uses (FETCH_SIZE of the kernel at 300,000 x 768, 12,544 queries: 11.6 GB for 1.35 GB of rows, 1.72 of the search's 8.05 ms; k = 90:
+// a third of the search).  Where memory allows (hb_launch_knn) the bank is kept a second time as plain rows [row][rs] and the
+// re-rank reads whole lines: eight lanes fetch one candidate row's 128 B (32 k) with one instruction, eight rows per instruction;
+// the pieces go through a padded LDS image from which lane t takes row t's 32 values for its serial chain (same chain, same order, same
+// bits as rerank_kernel).  The next 32 k of every row are in flight while a chunk is consumed; the query's chunk travels as one more
+// row of the image.
+__global__ __launch_bounds__(256) void tiles_to_rows_kernel(const float* __restrict__ t32, int g8, float* __restrict__ rows, int rs,
+                                                            int64_t rt0) {
+    __shared__ float s[4 * HB_BLK];
+    const int64_t rt = rt0 + blockIdx.x;
+    const int g0 = blockIdx.y * 4, ng = min(4, g8 - g0);
+    const int t = threadIdx.x;
+    if (t < ng * 64) reinterpret_cast<f32x4*>(s)[t] = reinterpret_cast<const f32x4*>(t32 + (rt * g8 + g0) * HB_BLK)[t];
+    __syncthreads();
+    const int i = t >> 3, c = t & 7;          // row of the tile, four consecutive k
+    f32x4 out;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int kq = 4 * c + j, gl = kq >> 3, kk = kq & 7;
+        out[j] = gl < ng ? s[gl * HB_BLK + ((kk & 1) * 32 + i) * 4 + (kk >> 1)] : 0.0f;
+    }
+    if (8 * g0 + 4 * c < rs) *reinterpret_cast<f32x4*>(rows + (rt * 32 + i) * (int64_t)rs + 8 * g0 + 4 * c) = out;
+}
+
+int hb_launch_tiles_to_rows(const float* t32, int g8, float* rows, int rs, int64_t n_row_tiles, int64_t rt0, hipStream_t s) {
+    if (n_row_tiles <= 0) return 0;
+    tiles_to_rows_kernel<<<dim3((unsigned)n_row_tiles, (unsigned)((rs / 8 + 3) / 4)), dim3(256), 0, s>>>(t32, g8, rows, rs, rt0);
+    HB_HIP(hipGetLastError());
+    return 0;
+}
+
+#define RRW_STRIDE 36      // dwords per row of the LDS image: 128 B of values + 16 B (lane t's b128 reads of row t: no bank conflicts)
+__global__ __launch_bounds__(256) void rerank_rows_kernel(const float* __restrict__ rows, int rs, const float* __restrict__ binit,
+                                                          int d, const float* __restrict__ q, const float* __restrict__ qn2,
+                                                          const int64_t* __restrict__ cand, const float* __restrict__ cand_score,
+                                                          const float* __restrict__ qnorm, const float* __restrict__ bmax,
+                                                          unsigned char* __restrict__ certified, int kc, int64_t nq, int k,
+                                                          int64_t id_base, int metric, int out_metric, int64_t ntotal,
+                                                          int64_t* __restrict__ out_idx, float* __restrict__ out_dist) {
+    __shared__ float s_sc[4][256];
+    __shared__ int64_t s_id[4][256];
+    __shared__ int s_act[4][256];
+    __shared__ __attribute__((aligned(16))) float s_img[4][72 * RRW_STRIDE];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + wv;
+    if (qi >= nq) return;   // wave-uniform
+    const float* qr = q + qi * (int64_t)d;
+    // (E and the skip rule: rerank_kernel)
+    const float E = qnorm[qi] * bmax[0] * (1.05f / 1024.0f + (float)d * 2.4e-7f)
+                    + (qnorm[qi] + bmax[0]) * sqrtf((float)d) * 6e-8f
+                    + (metric == 1 ? (float)d * 1.2e-7f * 0.5f * bmax[0] * bmax[0] : 0.0f)
+                    + 1e-30f;
+    const float cut = (k <= kc && cand[qi * (int64_t)kc + (k - 1)] >= 0) ? cand_score[qi * (int64_t)kc + (k - 1)] - 2.0f * E : -INFINITY;
+    // the candidates that need an exact score, compacted: s_act[0 .. n_act)
+    int n_act = 0;
+    for (int c0 = 0; c0 < kc; c0 += 64) {
+        const int c = c0 + lane;
+        int64_t row = -1;
+        bool act = false;
+        if (c < kc) {
+            row = cand[qi * (int64_t)kc + c];
+            act = row >= 0 && !(c >= k && cand_score[qi * (int64_t)kc + c] < cut);
+            s_sc[wv][c] = -INFINITY;
+            s_id[wv][c] = row;
+        }
+        const unsigned long long m = __ballot(act);
+        if (act) s_act[wv][n_act + __popcll(m & ((1ull << lane) - 1ull))] = c;
+        n_act += __popcll(m);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    float* img = s_img[wv];
+    const int rr = lane >> 3, chn = lane & 7;           // loader role: row rr of an instruction's eight, 16-byte piece chn of its 128 B
+    const int nch = (d + 31) >> 5;
+    for (int b0 = 0; b0 < n_act; b0 += 64) {
+        const int nb = min(64, n_act - b0);             // rows of this batch; image row nb is the query's chunk
+        const int nj = (nb + 1 + 7) >> 3;               // load instructions per chunk
+        const int c = lane < nb ? s_act[wv][b0 + lane] : -1;
+        const int64_t myrow = c >= 0 ? s_id[wv][c] : -1;
+        float acc = c >= 0 ? binit[myrow] : 0.0f;
+        const float* src[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int li = 8 * j + rr;
+            src[j] = li < nb ? rows + s_id[wv][s_act[wv][b0 + li]] * (int64_t)rs + 4 * chn : (li == nb ? qr + 4 * chn : nullptr);
+        }
+        f32x4 R[9];
+        // chunk `ch` of every row of the batch -> R (the query's last chunk may end inside the piece: d need not be a multiple of 4)
+#define RRW_LOAD(CH)                                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 9; ++j) {                                                                      \
+            if (j < nj) {                                                                                                    \
+                R[j] = f32x4{0.f, 0.f, 0.f, 0.f};                                                                            \
+                if (src[j]) {                                                                                                \
+                    const int k0 = 32 * (CH) + 4 * chn;                                                                      \
+                    if (8 * j + rr < nb || k0 + 4 <= d) R[j] = *reinterpret_cast<const f32x4*>(src[j] + 32 * (CH));          \
+                    else { _Pragma("unroll") for (int e = 0; e < 4; ++e) if (k0 + e < d) R[j][e] = src[j][32 * (CH) + e]; }   \
+                }                                                                                                            \
+            }                                                                                                                \
+        }
+        RRW_LOAD(0)
+        for (int ch = 0; ch < nch; ++ch) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j)
+                if (j < nj) *reinterpret_cast<f32x4*>(img + (8 * j + rr) * RRW_STRIDE + 4 * chn) = R[j];
+            if (ch + 1 < nch) { RRW_LOAD(ch + 1) }
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the image is written
+            __builtin_amdgcn_wave_barrier();
+            if (c >= 0) {
+                const f32x4* xr = reinterpret_cast<const f32x4*>(img + lane * RRW_STRIDE);
+                const f32x4* qv = reinterpret_cast<const f32x4*>(img + nb * RRW_STRIDE);
+                if (32 * ch + 32 <= d) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const f32x4 x = xr[i], y = qv[i];
+                        acc = fmaf(y[0], x[0], acc); acc = fmaf(y[1], x[1], acc); acc = fmaf(y[2], x[2], acc); acc = fmaf(y[3], x[3], acc);
+                    }
+                } else {
+                    for (int i = 0; 32 * ch + i < d; ++i) acc = fmaf(img[nb * RRW_STRIDE + i], img[lane * RRW_STRIDE + i], acc);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();      // everyone has read the image before the next chunk overwrites it
+        }
+#undef RRW_LOAD
+        if (c >= 0) s_sc[wv][c] = acc;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are visible to its lanes
+    __builtin_amdgcn_wave_barrier();
+    for (int c = lane; c < kc; c += 64) {
+        const float s = s_sc[wv][c];
+        const int64_t id = s_id[wv][c];
+        int rank = 0;
+        for (int j = 0; j < kc; ++j) {
+            const float sj = s_sc[wv][j];
+            const int64_t ij = s_id[wv][j];
+            bool better;
+            if (ij < 0 || id < 0) better = (ij >= 0 && id < 0) || (ij < 0 && id < 0 && j < c);
+            else better = (sj > s) || (sj == s && (ij < id || (ij == id && j < c)));
+            rank += better;
+        }
+        if (rank == k - 1) {   // the certificate: rerank_kernel
+            const int64_t last = cand[qi * (int64_t)kc + kc - 1];
+            const bool finite_q = qnorm[qi] <= 65504.0f;
+            bool ok = last < 0 && ntotal < kc && finite_q;
+            if (last >= 0 && id >= 0 && finite_q) ok = s > cand_score[qi * (int64_t)kc + kc - 1] + E;
+            certified[qi] = ok ? 1 : 0;
+        }
+        if (rank < k) {
+            const int64_t o = qi * (int64_t)k + rank;
+            if (id < 0) { out_idx[o] = -1; out_dist[o] = out_metric == 1 ? INFINITY : -INFINITY; }
+            else {
+                out_idx[o] = id + id_base;
+                if (out_metric == 1) { const float d2 = fmaf(-2.0f, s, qn2[qi]); out_dist[o] = d2 > 0.0f ? d2 : 0.0f; }
+                else out_dist[o] = s;
+            }
+        }
+    }
+}
+
+int hb_launch_rerank_rows(const float* rows, int rs, const float* binit, int d, const float* q, const float* qn2,
+                          const int64_t* cand, const float* cand_score, const float* qnorm, const float* bmax,
+                          unsigned char* certified, int kc, int64_t nq, int k, int64_t id_base, int metric, int out_metric,
+                          int64_t ntotal, int64_t* out_idx, float* out_dist, hipStream_t s) {
+    if (nq == 0) return 0;
+    if (kc > 256) return hb_fail("hb_index_search: too many candidates for the re-rank kernel");
+    rerank_rows_kernel<<<dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s>>>(rows, rs, binit, d, q, qn2, cand, cand_score, qnorm, bmax,
+                                                                          certified, kc, nq, k, id_base, metric, out_metric, ntotal, out_idx, out_dist);
+    HB_HIP(hipGetLastError());
+    return 0;
+}
+
 int hb_knn_f16_launch(const knn16_args& args, int grid, hipStream_t s) {
     // <4> compacts pools of up to 256 entries (k <= 64), <8> up to HB_POOL_MAX = 512 (its rare compaction path holds twice the registers)
     void (*fn)(knn16_args) = args.klw <= 256 ? knn_f16v2_kernel<4> : knn_f16v2_kernel<8>;

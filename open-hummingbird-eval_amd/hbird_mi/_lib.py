@@ -83,6 +83,8 @@ SIGNATURES = {
     "hb_index_cluster_stats": (c_int, [c_void_p, POINTER(c_int64)]),
     "hb_index_set_variant": (c_int, [c_void_p, c_int]),
     "hb_index_set_search_options": (c_int, [c_void_p, c_int, c_int64]),
+    "hb_index_set_rerank_copy": (c_int, [c_void_p, c_int]),
+    "hb_index_rerank_copy_bytes": (c_int, [c_void_p, POINTER(c_int64)]),
     "hb_index_schedule_info": (c_int, [c_void_p, POINTER(c_int64)]),
 }
 

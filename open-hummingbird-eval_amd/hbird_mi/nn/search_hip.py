@@ -278,6 +278,16 @@ class HipFlatIndex:
         """A/B switches (same results): pool searches in one launch instead of phases; the size below which a search is "small"."""
         _lib.check(_lib.lib().hb_index_set_search_options(self._h, int(bool(phases)), int(small_limit_stages)))
 
+    def set_rerank_copy(self, mode: int = 0):
+        """use_fp16 searches: a second, row-major fp32 copy of the bank for the exact re-rank (speed only; 0 automatic -- made when the
+        device keeps a third of its memory free --, 1 always, 2 never)."""
+        _lib.check(_lib.lib().hb_index_set_rerank_copy(self._h, int(mode)))
+
+    def rerank_copy_bytes(self) -> int:
+        n = ctypes.c_int64(0)
+        _lib.check(_lib.lib().hb_index_rerank_copy_bytes(self._h, ctypes.byref(n)))
+        return int(n.value)
+
     def set_cluster(self, cluster_q: int = 0, cluster_b: int = 0, sync_lag: int = -1):
         """L2-sharing clusters of the work list (speed only, opt-in): 0 x 0 / 1 x 1 off, e.g. 2 x 2; sync_lag in stages."""
         _lib.check(_lib.lib().hb_index_set_cluster(self._h, int(cluster_q), int(cluster_b), int(sync_lag)))

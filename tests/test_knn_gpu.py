@@ -495,6 +495,48 @@ def test_use_fp16_candidate_pass_with_exact_rerank(cuda_device, M, D, nq, k, met
     _check_exact(idx, dist, q, np.concatenate([bank, bank[:100] * 0.5]), k, metric)
 
 
+@pytest.mark.parametrize("M,D,nq,k,metric", [
+    (6000, 50, 200, 30, "dot_product"),        # D = 50: query rows 8 B aligned, the last 32-k chunk holds 18 values
+    (6000, 33, 130, 90, "l2"),                 # one value in the last chunk; k' = 192: three batches of candidates
+    (9000, 96, 150, 128, "dot_product"),       # k' = 256
+    (20000, 384, 300, 30, "l2"),
+    (40, 24, 70, 30, "dot_product"),           # fewer rows than k
+])
+def test_use_fp16_rerank_on_the_row_major_copy(cuda_device, M, D, nq, k, metric):
+    """The exact re-rank of use_fp16 searches reads a second, row-major fp32 copy of the bank when there is one (hb_index_set_rerank_copy:
+    automatic / always / never) and the fragment tiles otherwise: the oracle's bits either way, also after rows were appended behind a
+    partly filled row tile and after a reset."""
+    bank = gi.unit_bank(M, D, seed=M + 7)
+    q = gi.vit_like_queries(nq, D, seed=nq + 7)
+    ix = HipFlatIndex(D, 0 if metric == "dot_product" else 1, 0)
+    ix.add(torch.from_numpy(bank).cuda())
+    ix.set_fp16(True)
+    qd = torch.from_numpy(q).cuda()
+    ix.set_rerank_copy(2)
+    i0, d0 = ix.search(qd, k)
+    assert ix.rerank_copy_bytes() == 0
+    _check_exact(i0, d0, q, bank, k, metric)
+    ix.set_rerank_copy(1)
+    i1, d1 = ix.search(qd, k)
+    assert ix.rerank_copy_bytes() >= M * D * 4
+    assert torch.equal(i0, i1) and torch.equal(d0.view(torch.int32), d1.view(torch.int32))
+    more = gi.unit_bank(77, D, seed=5) * 1.5
+    ix.add(torch.from_numpy(more).cuda())       # 77 rows behind a partly filled row tile: the copy follows
+    both = np.concatenate([bank, more])
+    i2, d2 = ix.search(qd, k)
+    _check_exact(i2, d2, q, both, k, metric)
+    ix.set_rerank_copy(2)                       # released
+    assert ix.rerank_copy_bytes() == 0
+    i3, d3 = ix.search(qd, k)
+    assert torch.equal(i2, i3) and torch.equal(d2.view(torch.int32), d3.view(torch.int32))
+    ix.set_rerank_copy(0)                       # automatic: a small bank on an empty device gets its copy
+    ix.reset()
+    ix.add(torch.from_numpy(more).cuda())
+    i4, d4 = ix.search(qd, k)
+    assert ix.rerank_copy_bytes() > 0
+    _check_exact(i4, d4, q, more, k, metric)
+
+
 def test_use_fp16_certificate_and_exact_fallback(cuda_device):
     """Near-duplicate bank rows cannot be ranked by fp16 scores: the per-query certificate must fail for them and the
     exact fp32 re-search must deliver the fp32 answer anyway; well-separated queries stay on the fast path."""
