@@ -821,7 +821,9 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         }
     }
     // fp16 mode: the fused kernel collects kc >= 2k candidates, the fp32 chain arithmetic re-ranks them
-    const int kc = f16 ? std::min(256, std::max(64, (2 * k + 63) / 64 * 64)) : k;
+    // k' = 2k, at least 64 (rounded up to 8, not to 64 as until round 4: the candidate kernel's time is linear in k' -- 300,000 x 768, 21,904
+    // queries: k' = 64 / 128 / 192 / 256 -> 12.95 / 15.85 / 20.7 / 25.0 ms -- so k = 33 paid for 128 candidates where it needs 66)
+    const int kc = f16 ? std::min(256, std::max(64, (2 * k + 7) / 8 * 8)) : k;
     // Small searches (few stages per workgroup) on the kernel with register-resident query fragments run on POOLS even for k <= 32:
     // phased, with the bisection cold start and the scan epilogue (hbird_knn_bd.hip <WIDE, COLD>) a pool takes a tile's survivors in one
     // drain, a sorted LDS list one wave-cooperative insertion each.  Same box, kernel ms, lists / pools, k = 30: 50,176 x 384 x 12,544

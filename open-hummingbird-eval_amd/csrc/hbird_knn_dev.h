@@ -439,7 +439,7 @@ __device__ __forceinline__ float hb_max3(float a, float b, float c) {
 // unrolled scan would take its 128 out-of-line branches only to find a queue overflowing.  The mode ends when a tile flags at most
 // HB_BULK_QUADS of its 32 quarters and comes back when a queue overflows.  (The quarter loop for EVERY tile measured 1-5 % slower
 // at 50 k - 2 M rows and 0.5 % faster at 10 M x 768: its test is four compares per quarter against the scan's max tree.)
-#define HB_BULK_QUADS 12
+#define HB_BULK_QUADS 12   // (18 / 24 / 30 measure the same from 50 k to 10 M rows, k = 30 and 90: profiles/r04/bulk_threshold_ab.txt)
 template <int EMAX>
 __device__ __forceinline__ void pool_epilogue_scan(f32x16 (&acc)[8], float& thr, float* pool_s, unsigned* pool_i, float* sc, int qb,
                                                    int lane, int k, unsigned bt, int klw, int* cnt, bool& bulk) {

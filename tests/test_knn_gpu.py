@@ -470,7 +470,7 @@ def test_headline_size_10m_x_768(cuda_device):
     (20000, 384, 520, 30, "dot_product"),
     (20000, 384, 520, 30, "l2"),
     (9000, 768, 300, 10, "dot_product"),
-    (3000, 40, 100, 90, "dot_product"),        # D padded to 64, k' = 192
+    (3000, 40, 100, 90, "dot_product"),        # D padded to 64, k' = 184
     (100, 16, 20, 30, "dot_product"),          # fewer rows than k'
 ])
 def test_use_fp16_candidate_pass_with_exact_rerank(cuda_device, M, D, nq, k, metric):
@@ -497,7 +497,7 @@ def test_use_fp16_candidate_pass_with_exact_rerank(cuda_device, M, D, nq, k, met
 
 @pytest.mark.parametrize("M,D,nq,k,metric", [
     (6000, 50, 200, 30, "dot_product"),        # D = 50: query rows 8 B aligned, the last 32-k chunk holds 18 values
-    (6000, 33, 130, 90, "l2"),                 # one value in the last chunk; k' = 192: three batches of candidates
+    (6000, 33, 130, 90, "l2"),                 # one value in the last chunk; k' = 184: three batches of candidates
     (9000, 96, 150, 128, "dot_product"),       # k' = 256
     (20000, 384, 300, 30, "l2"),
     (40, 24, 70, 30, "dot_product"),           # fewer rows than k
