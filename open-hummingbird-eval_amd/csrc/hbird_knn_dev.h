@@ -205,14 +205,26 @@ __device__ __forceinline__ unsigned pool_kth(const unsigned (&key)[EMAX], bool (
     return prefix;
 }
 
-// Compact the full pool (cap entries, cap <= 64 EMAX) at (gs, gi) to its best k in entries [0, k); returns the k-th best
-// score.  (A variant for partly filled pools -- per-lane validity masks -- cost the fp32 pool kernel its scalar registers:
+// Compact the full pool (cap entries, cap <= 64 EMAX) at (gs, gi): afterwards entries [0, n) hold every entry above a new threshold t,
+// k <= n <= k + (cap - k) / 4 wherever the scores allow it; returns (n << 32) | bits of t.  `thr` = the query's current threshold (every
+// entry that matters exceeds it; entries at or below it -- a floor raised since they were appended -- are dropped, and if fewer than k
+// remain, that is the whole compaction).  A pool is a SUPERSET of its query's best k of the rows its slot has seen: it need not hold
+// exactly k after a compaction, only never lose one of them, and its threshold need only be a lower bound on its k-th best.  So t comes
+// from a bisection over the monotone keys between the threshold and the largest one (a compare, a ballot and a count per entry register
+// and round; it stops as soon as the count above the midpoint is within the slack: five to eight rounds) instead of the exact radix
+// select (32 rounds, and 32 more among tied scores) that this function ran until round 4 -- that one is still the way out when the
+// bisection does not get there in 24 rounds (a pool of equal scores).  300,000 x 768, k = 90, use_fp16: compactions were 5 % of the wave
+// cycles (profiles/r04/f16_epilogue_counts.txt).
+// (A variant for partly filled pools -- per-lane validity masks -- cost the fp32 pool kernel its scalar registers:
 // reloads of spilled SGPRs in every stage, +10 % kernel time at k = 90.)
 // NOT inlined (round 4): a real function call on the rare compaction path.  Inlined at every call site its 4 x EMAX value registers and
-// the radix select's masks set the register budget of the whole kernel -- spilled SGPRs reloaded in the stage loops (fp16 candidate
+// the select's masks set the register budget of the whole kernel -- spilled SGPRs reloaded in the stage loops (fp16 candidate
 // kernel, pools of 384: 373 -> 328 ms at 10 M x 768, k = 90; every pool instantiation lost half of its spills or more).
+__device__ __forceinline__ float pool_unkey(unsigned key) {   // the float whose pool_key is `key`
+    return __builtin_bit_cast(float, (key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key);
+}
 template <int EMAX = HB_POOL_MAX / 64>
-__device__ __attribute__((noinline)) float pool_compact(float* gs, unsigned* gi, int cap, int k, int lane) {
+__device__ __attribute__((noinline)) unsigned long long pool_compact(float* gs, unsigned* gi, int cap, int k, int lane, float thr) {
     const int E = cap >> 6;
     float es[EMAX];
     unsigned ei[EMAX], key[EMAX];
@@ -228,6 +240,45 @@ __device__ __attribute__((noinline)) float pool_compact(float* gs, unsigned* gi,
             act[e] = true;
         }
     }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // keys above `cut` survive: count them ...
+    auto above_cut = [&](unsigned cut) {
+        int c = 0;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e)
+            if (e < E) c += __popcll(__ballot(key[e] > cut));
+        return c;
+    };
+    // ... and move them to the front
+    auto keep_above = [&](unsigned cut) {
+        int base = 0;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e)
+            if (e < E) {
+                const bool keep = key[e] > cut;
+                const unsigned long long m = __ballot(keep);
+                if (keep) { const int p = base + __popcll(m & lt); gs[p] = es[e]; gi[p] = ei[e]; }
+                base += __popcll(m);
+            }
+        return base;
+    };
+    const int slack = (cap - k) >> 2;
+    unsigned lo = pool_key(thr);       // -inf for a query without a threshold yet: below every score a pool can hold
+    int clo = above_cut(lo);
+    if (clo > k + slack) {
+        unsigned hi = 0xFFFFFFFFu;     // invariant: at least k keys above lo, fewer than k above hi
+        for (int r = 0; r < 24 && hi - lo > 1u; ++r) {
+            const unsigned mid = lo + ((hi - lo) >> 1);
+            const int c = above_cut(mid);
+            if (c >= k) { lo = mid; clo = c; if (c <= k + slack) break; }
+            else hi = mid;
+        }
+    }
+    if (clo <= k + slack) {
+        const int n = keep_above(lo);
+        return ((unsigned long long)(unsigned)n << 32) | (unsigned long long)__builtin_bit_cast(unsigned, fmaxf(thr, pool_unkey(lo)));
+    }
+    // the exact way: the best k by (score desc, id asc)
     const unsigned kt = pool_kth<EMAX>(key, act, E, k);   // key of the k-th best score
     int above = 0, tied = 0;
 #pragma unroll
@@ -242,7 +293,6 @@ __device__ __attribute__((noinline)) float pool_compact(float* gs, unsigned* gi,
     }
     float kth = 0.f;
     int base = 0;
-    const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
     for (int e = 0; e < EMAX; ++e)
         if (e < E) {
@@ -253,7 +303,7 @@ __device__ __attribute__((noinline)) float pool_compact(float* gs, unsigned* gi,
             const unsigned long long mk = __ballot(key[e] == kt);
             if (mk) kth = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, es[e]), __builtin_ctzll(mk)));
         }
-    return kth;
+    return ((unsigned long long)(unsigned)k << 32) | (unsigned long long)__builtin_bit_cast(unsigned, kth);
 }
 
 // Append the register queues of a wave (at most four (score, row code) entries per lane; np = how many this lane holds) to the
@@ -286,9 +336,10 @@ __device__ __forceinline__ void pool_drain(int np, float q0v, float q1v, float q
                 const int n = __builtin_ctzll(full) & 31;
                 full &= full - 1;
                 const size_t off = (size_t)(qb + n) * klw;
-                const float kth = pool_compact<EMAX>(pool_s + off, pool_i + off, klw, k, lane);
-                if (lane == 0) cnt[qb + n] = k;
-                if ((lane & 31) == n) thr = fmaxf(thr, kth);
+                const float tq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, thr), n));   // query n's threshold (both lane halves hold it)
+                const unsigned long long r = pool_compact<EMAX>(pool_s + off, pool_i + off, klw, k, lane, tq);
+                if (lane == 0) cnt[qb + n] = (int)(r >> 32);
+                if ((lane & 31) == n) thr = fmaxf(thr, __builtin_bit_cast(float, (unsigned)r));
             }
         }
     }
