@@ -270,12 +270,23 @@ __global__ __launch_bounds__(64) void knn_merge_kernel(const float* __restrict__
         const int sl = fixed_ng > 0 ? s0 + j : qt_slots[s0 + j];
         const int valid = cnts ? min(per, cnts[(size_t)sl * HB_QT + ql]) : per;
         const size_t off = ((size_t)sl * HB_QT + ql) * klw;
-        for (int e0 = 0; e0 < valid; e0 += 64) {
-            const int e = e0 + lane;
-            const float v = e < valid ? state_s[off + e] : -INFINITY;
-            const bool keep = e < valid && (v >= tstar || tstar == -INFINITY);
+        // all of a slot's entries (at most HB_POOL_MAX = 8 x 64) are requested before the first is looked at: the loop used to wait for a
+        // score, then for its id, 64 entries at a time -- two memory round trips per 64 entries, 1.18 of a 15.6 ms search at k = 90
+        float vv[HB_POOL_MAX / 64];
+        unsigned vi[HB_POOL_MAX / 64];
+#pragma unroll
+        for (int u = 0; u < HB_POOL_MAX / 64; ++u) {
+            const int e = u * 64 + lane;
+            vv[u] = -INFINITY; vi[u] = 0u;
+            if (e < valid) { vv[u] = state_s[off + e]; vi[u] = state_i[off + e]; }
+        }
+#pragma unroll
+        for (int u = 0; u < HB_POOL_MAX / 64; ++u) {
+            if (u * 64 >= valid) break;
+            const int e = u * 64 + lane;
+            const bool keep = e < valid && (vv[u] >= tstar || tstar == -INFINITY);
             const unsigned long long m = __ballot(keep);
-            if (keep) { const int pos = n + __popcll(m & ((1ull << lane) - 1ull)); cs[pos] = v; ci[pos] = state_i[off + e]; }
+            if (keep) { const int pos = n + __popcll(m & ((1ull << lane) - 1ull)); cs[pos] = vv[u]; ci[pos] = vi[u]; }
             n += __popcll(m);
         }
     }
@@ -285,7 +296,7 @@ __global__ __launch_bounds__(64) void knn_merge_kernel(const float* __restrict__
     // until round 4 a radix select of the exact k-th key ran here, always 32 rounds: 1.18 of a 15.6 ms use_fp16 search at 300,000 x 768,
     // k = 90) -- every candidate that can rank below k lies above the cut, ties of the k-th included.  Scores that the bisection cannot
     // separate (24 rounds) go through the radix select.
-    if (n > 2 * k + 64) {
+    if (n > k + 64) {                // (the ranking below is quadratic: from k + 64 candidates on a cut pays)
         unsigned cut = 0;            // keep keys > cut
         {
             unsigned lo = 0, hi = 0xFFFFFFFFu;     // at least k keys above lo (all n: no score has key 0), fewer than k above hi
@@ -300,7 +311,7 @@ __global__ __launch_bounds__(64) void knn_merge_kernel(const float* __restrict__
                 if (c >= k) { lo = mid; clo = c; } else hi = mid;
             }
             cut = lo;
-            if (clo > 2 * k + 64) {   // not separated: the exact k-th key (its ties stay)
+            if (clo > k + 64 && clo > 2 * k) {   // not separated: the exact k-th key (its ties stay)
                 unsigned prefix = 0;
                 int kk = k;
                 for (int b = 31; b >= 0; --b) {
@@ -750,9 +761,17 @@ __global__ __launch_bounds__(256) void pool_floor_kernel(const float* __restrict
     for (int j = 0; j < ns; ++j) {
         const size_t oq = (size_t)qt_slots[s0 + j] * HB_QT + ql;
         const int valid = min(klw, cnts[oq]);
-        for (int e0 = 0; e0 < valid; e0 += 64) {
-            const int e = e0 + lane;
-            const float v = e < valid ? state_s[oq * klw + e] : -INFINITY;
+        float vv[HB_POOL_MAX / 64];   // (all of the slot's scores in flight at once: knn_merge_kernel)
+#pragma unroll
+        for (int u = 0; u < HB_POOL_MAX / 64; ++u) {
+            const int e = u * 64 + lane;
+            vv[u] = e < valid ? state_s[oq * klw + e] : -INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < HB_POOL_MAX / 64; ++u) {
+            if (u * 64 >= valid) break;
+            const int e = u * 64 + lane;
+            const float v = vv[u];
             const bool keep = e < valid && (v >= tstar || tstar == -INFINITY);
             const unsigned long long m = __ballot(keep);
             if (keep) { cs[n + __popcll(m & ((1ull << lane) - 1ull))] = v; hi = fmaxf(hi, v); mn = fminf(mn, v); }
