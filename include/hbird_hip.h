@@ -191,7 +191,7 @@ int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_tiles);
  * returned indices / distances are those of the fp32 search.  Every query carries a certificate (exact k-th score >
  * k'-th fp16 score + rounding bound); queries that fail it are searched again with the fp32 kernel, so the result is
  * ALWAYS the fp32 result.  Applies to k <= 128; larger k use the fp32 kernel.  2 = the same, but only for banks of at
- * least 16,384 rows with rows x queries >= 2^27 -- below that the fp32 kernel is the faster way to the same result (what the
+ * least 4,096 rows with rows x queries x D >= 1.5e10 x (k' / 64)^2, k' = 2k -- below that the fp32 kernel is the faster way to the same result (what the
  * plugin's use_fp16 sets). */
 int hb_index_set_fp16(hb_index_t* ix, int enable);
 /* Number of queries of the last fp16-mode search that needed the exact fp32 re-search. */

@@ -807,13 +807,16 @@ __global__ __launch_bounds__(256) void pool_floor_kernel(const float* __restrict
 int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t id_base, int64_t* out_idx, float* out_dist) {
     if (k < 1 || k > 256) return hb_fail("hb_index_search: k must be in [1, 256]");
     // fp16 mode 2 (what the plugin's use_fp16=True selects): the candidate pass only where it pays.  Its fixed costs are per query
-    // (fp16 query tiles, re-rank, a second merge) and per search (the phases' launches and floor kernels), so the crossover is a
-    // bank size that grows as the queries get few: at least 16,384 rows and rows x queries >= 2^27.  Same box, whole search, fp32 /
-    // use_fp16 ms (phased pools): 12,544 x 384 queries: 8 k rows 1.27 / 0.83, 16 k 2.04 / 1.08, 50 k 4.54 / 1.81, 131 k 10.13 / 2.88,
-    // 2,074,072 140.4 / 22.4; 21,904 x 768: 8 k 2.87 / 3.34, 16 k 4.89 / 4.41, 50 k 12.72 / 7.24, 131 k 31.3 / 11.1; 784 x 384: 100 k
-    // 1.51 / 1.67, 200 k 2.18 / 1.91; 1,369 x 768: 50 k 1.77 / 2.35, 100 k 2.81 / 2.67; 196 x 384: 200 k 1.33 / 1.37, 1 M 2.83 / 1.91.
-    // Same results either way.
-    bool f16 = ix->fp16 != 0 && k <= 128 && (ix->fp16 == 1 || (ix->ntotal >= 16384 && ix->ntotal * nq >= ((int64_t)1 << 27)));
+    // (fp16 query tiles, re-rank of k' = 2k candidates, a second merge) and per search (the phases' launches and floor kernels), what it
+    // saves is proportional to the matrix work rows x queries x D: the pass runs from rows x queries x D >= 1.5e10 x (k' / 64)^2 on, and
+    // never below 4,096 rows.  Whole searches, fp32 / use_fp16 ms, same box, after round 4's changes (tools/exp_fp16_crossover.py): 196 x 384
+    // queries: 65 k rows 0.28 / 0.34, 131 k 0.47 / 0.45, 1 M 1.93 / 0.95; 784 x 384: 16 k 0.28 / 0.34, 32 k 0.46 / 0.46, 65 k 0.64 / 0.51; 3,136 x
+    // 384: 8 k 0.41 / 0.45, 16 k 0.65 / 0.47; 1,369 x 768: 4 k 0.30 / 0.23, 16 k 0.59 / 0.48; 12,544 x 384: 4 k 0.61 / 0.52, 50 k 3.9 / 1.5, 1 M
+    // 69.3 / 10.6; 21,904 x 768: 4 k 1.43 / 1.09, 1 M 242.7 / 34.3; k = 90, 12,544 x 384: 16 k 1.74 / 2.04, 32 k 3.00 / 2.49, 1 M 70.4 / 13.8.
+    // (Until round 4: at least 16,384 rows and rows x queries >= 2^27.)  Same results either way.
+    const double kc_rel = std::min(256, std::max(64, (2 * k + 7) / 8 * 8)) / 64.0;
+    bool f16 = ix->fp16 != 0 && k <= 128 &&
+               (ix->fp16 == 1 || (ix->ntotal >= 4096 && (double)ix->ntotal * (double)nq * (double)ix->d >= 1.5e10 * kc_rel * kc_rel));
     if (!f16) ix->last_fp16_fallbacks = 0;      // a plain fp32 search: nothing fell back (the counter is not left over from an earlier search)
     if (f16 && nq > 0 && ix->ntotal > 0) {
         // bring the fp16 copy of the bank fragment tiles up to date.  A finite value beyond the fp16 range (|x| > 65504) turns

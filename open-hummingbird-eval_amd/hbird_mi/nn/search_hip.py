@@ -262,7 +262,7 @@ class HipFlatIndex:
 
     def set_fp16(self, enable):
         """fp16 candidate pass + exact fp32 re-rank (GpuIndexFlatConfig.useFloat16 of the reference).  True / 1: always;
-        2: only where it is faster than the fp32 kernel -- banks of at least 16,384 rows with rows x queries >= 2^27 (same results
+        2: only where it is faster than the fp32 kernel -- banks of at least 4,096 rows with rows x queries x D >= 1.5e10 x (k' / 64)^2 (same results
         either way)."""
         _lib.check(_lib.lib().hb_index_set_fp16(self._h, 2 if enable == 2 and enable is not True else int(bool(enable))))
 

@@ -295,8 +295,8 @@ def test_evaluator_drives_several_gpus_in_one_process(cuda_device, golden_dir, n
 
 
 def test_use_fp16_through_the_evaluator_only_where_it_pays(cuda_device):
-    """nn_params['use_fp16'] selects fp16 mode 2 (like the plugin): the candidate pass only where it is faster (from 16,384 rows
-    with rows x queries >= 2^27: this 50 k-row bank since the phased pools of round 3), so the flag can only make a search
+    """nn_params['use_fp16'] selects fp16 mode 2 (like the plugin): the candidate pass only where it is faster (from rows x
+    queries x D >= 1.5e10 (k' / 64)^2: this 50 k-row bank since the phased pools of round 3), so the flag can only make a search
     faster.  Same bits either way."""
     import time
     from hbird_mi.nn.search_hip import HipFlatIndex

@@ -479,7 +479,7 @@ def test_use_fp16_candidate_pass_with_exact_rerank(cuda_device, M, D, nq, k, met
     q = gi.vit_like_queries(nq, D, seed=nq + 1)
     nn = NearestNeighborSearchHIP(torch.from_numpy(bank), n_neighbors=k, distance_measure=metric, use_fp16=True, gpu_ids=[0])
     idx, dist = nn.find_nearest_neighbors(torch.from_numpy(q))      # the plugin's mode: the candidate pass only where it pays
-    _check_exact(idx, dist, q, bank, k, metric)                     # (>= 16,384 rows and rows x queries >= 2^27; the fp32 kernel here)
+    _check_exact(idx, dist, q, bank, k, metric)                     # (rows x queries x D >= 1.5e10 (k' / 64)^2; the fp32 kernel for most of these)
     ix = nn.index
     ix.set_fp16(True)                                               # always: these small banks go through the fp16 kernels
     idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
