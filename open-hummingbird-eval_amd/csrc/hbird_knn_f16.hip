@@ -394,6 +394,7 @@ int hb_launch_tiles_to_rows(const float* t32, int g8, float* rows, int rs, int64
     return 0;
 }
 
+#define RRW_NONE 0xFFFFFFFFu
 #define RRW_STRIDE 36      // dwords per row of the LDS image: 128 B of values + 16 B (lane t's b128 reads of row t: no bank conflicts)
 __global__ __launch_bounds__(256) void rerank_rows_kernel(const float* __restrict__ rows, int rs, const float* __restrict__ binit,
                                                           int d, const float* __restrict__ q, const float* __restrict__ qn2,
@@ -403,9 +404,9 @@ __global__ __launch_bounds__(256) void rerank_rows_kernel(const float* __restric
                                                           int64_t id_base, int metric, int out_metric, int64_t ntotal,
                                                           int64_t* __restrict__ out_idx, float* __restrict__ out_dist) {
     __shared__ float s_sc[4][256];
-    __shared__ int64_t s_id[4][256];
+    __shared__ unsigned s_id[4][256];                    // bank rows (below 2^32); RRW_NONE: no candidate
     __shared__ int s_act[4][256];
-    __shared__ __attribute__((aligned(16))) float s_img[4][72 * RRW_STRIDE];
+    __shared__ __attribute__((aligned(16))) float s_img[4][66 * RRW_STRIDE];   // 64 rows + the query's + one of padding: 50 KB per workgroup, three per CU
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t qi = (int64_t)blockIdx.x * 4 + wv;
     if (qi >= nq) return;   // wave-uniform
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(256) void rerank_rows_kernel(const float* __restric
             row = cand[qi * (int64_t)kc + c];
             act = row >= 0 && !(c >= k && cand_score[qi * (int64_t)kc + c] < cut);
             s_sc[wv][c] = -INFINITY;
-            s_id[wv][c] = row;
+            s_id[wv][c] = row >= 0 ? (unsigned)row : RRW_NONE;
         }
         const unsigned long long m = __ballot(act);
         if (act) s_act[wv][n_act + __popcll(m & ((1ull << lane) - 1ull))] = c;
@@ -441,13 +442,12 @@ __global__ __launch_bounds__(256) void rerank_rows_kernel(const float* __restric
         const int nb = min(64, n_act - b0);             // rows of this batch; image row nb is the query's chunk
         const int nj = (nb + 1 + 7) >> 3;               // load instructions per chunk
         const int c = lane < nb ? s_act[wv][b0 + lane] : -1;
-        const int64_t myrow = c >= 0 ? s_id[wv][c] : -1;
-        float acc = c >= 0 ? binit[myrow] : 0.0f;
+        float acc = c >= 0 ? binit[s_id[wv][c]] : 0.0f;
         const float* src[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const int li = 8 * j + rr;
-            src[j] = li < nb ? rows + s_id[wv][s_act[wv][b0 + li]] * (int64_t)rs + 4 * chn : (li == nb ? qr + 4 * chn : nullptr);
+            src[j] = li < nb ? rows + (int64_t)s_id[wv][s_act[wv][b0 + li]] * rs + 4 * chn : (li == nb ? qr + 4 * chn : nullptr);
         }
         f32x4 R[9];
         // chunk `ch` of every row of the batch -> R (the query's last chunk may end inside the piece: d need not be a multiple of 4)
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256) void rerank_rows_kernel(const float* __restric
         for (int ch = 0; ch < nch; ++ch) {
 #pragma unroll
             for (int j = 0; j < 9; ++j)
-                if (j < nj) *reinterpret_cast<f32x4*>(img + (8 * j + rr) * RRW_STRIDE + 4 * chn) = R[j];
+                if (j < nj && 8 * j + rr <= nb) *reinterpret_cast<f32x4*>(img + (8 * j + rr) * RRW_STRIDE + 4 * chn) = R[j];
             if (ch + 1 < nch) { RRW_LOAD(ch + 1) }
             __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the image is written
             __builtin_amdgcn_wave_barrier();
@@ -492,11 +492,11 @@ __global__ __launch_bounds__(256) void rerank_rows_kernel(const float* __restric
     __builtin_amdgcn_wave_barrier();
     for (int c = lane; c < kc; c += 64) {
         const float s = s_sc[wv][c];
-        const int64_t id = s_id[wv][c];
+        const int64_t id = s_id[wv][c] == RRW_NONE ? -1 : (int64_t)s_id[wv][c];
         int rank = 0;
         for (int j = 0; j < kc; ++j) {
             const float sj = s_sc[wv][j];
-            const int64_t ij = s_id[wv][j];
+            const int64_t ij = s_id[wv][j] == RRW_NONE ? -1 : (int64_t)s_id[wv][j];
             bool better;
             if (ij < 0 || id < 0) better = (ij >= 0 && id < 0) || (ij < 0 && id < 0 && j < c);
             else better = (sj > s) || (sj == s && (ij < id || (ij == id && j < c)));
