@@ -1,3 +1,4 @@
+# (Applies to the tree of commit ccb971c: pool_compact has changed since -- the bisection compaction came out of these counts.)
 # The temporary patch behind lib/abl/libhbird_hip_x_stamps.so (tools/exp_stamps.py): run from csrc/, build with
 #   make varu UNIT=hbird_knn_f16 NAME=x_stamps EXTRA="-Wno-unused-variable", then restore hbird_knn_dev.h / hbird_knn_f16.hip with git checkout.
 p='hbird_knn_dev.h'
