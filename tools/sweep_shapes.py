@@ -2,7 +2,7 @@
 """A sweep over search shapes to find performance cliffs: for every bank (rows x dim) built once, searches with nq in {12544, 21904},
 k in {30, 90}, fp32 and use_fp16: kernel ms (HIP events inside the library), whole-search ms (HIP events around 2 searches), the kernel's
 fraction of its MFMA peak (157.3 TFLOP/s fp32, 2516.6 fp16) and the share of the search spent outside the kNN kernel.
-usage: sweep_shapes.py out.json [rows,dim ...]"""
+usage: sweep_shapes.py out.json [rows,dim ...]   (SWEEP_NQ="196,1369": other query counts)"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "open-hummingbird-eval_amd"), ROOT]
@@ -15,7 +15,7 @@ out = []
 for M, D in banks:
     ix = HipFlatIndex(D, 0, 0); ix.set_num_classes(21); ix.use_current_stream()
     bench.build_bank(ix, 0, M, D, 21, dev)
-    for nq in (12544, 21904):
+    for nq in [int(x) for x in os.environ.get("SWEEP_NQ", "12544,21904").split(",")]:
         g = torch.Generator(device=dev); g.manual_seed(7)
         q = 3.0 * torch.randn((nq, D), generator=g, device=dev)
         for k in (30, 90):
