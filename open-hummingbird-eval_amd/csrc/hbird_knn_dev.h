@@ -175,8 +175,8 @@ __device__ __forceinline__ void list_insert(float* lst_s, unsigned* lst_i, int q
 // A query's running best-k does not fit the LDS lists, so it lives in global memory as an UNSORTED pool of
 // `cap` entries (cap >= 2k, multiple of 64): a score above the query's threshold is simply appended (one store per
 // lane, all 32 queries of a wave in parallel, the fill count in LDS).  When a pool is full the wave compacts it to
-// its best k by (score desc, id asc) -- a radix select over the wave, no sorting -- and raises the threshold to the
-// k-th score.  The threshold is therefore only as fresh as the last compaction: a few more scores pass than with
+// about its best k -- every entry above a cut that at least k entries exceed, found by bisection over the wave (pool_compact) -- and
+// raises the threshold to that cut.  The threshold is therefore only as fresh as the last compaction: a few more scores pass than with
 // sorted lists, but an append costs one store instead of a serialised read-modify-write of the list.
 // Only the owning wave ever touches a pool; pool loads bypass the L1 and follow an s_waitcnt vmcnt(0).
 
@@ -309,7 +309,7 @@ __device__ __attribute__((noinline)) unsigned long long pool_compact(float* gs, 
 // Append the register queues of a wave (at most four (score, row code) entries per lane; np = how many this lane holds) to the
 // pools of its 32 queries: queue entry i of every lane, one lane half at a time (the two halves hold different rows of the SAME
 // query and would race on its fill count; an LDS-atomic variant that drained both at once measured the same and needed a compaction
-// of partly filled pools).  A pool that fills up is compacted to its k best on the spot, which raises the query's threshold.
+// of partly filled pools).  A pool that fills up is compacted on the spot (pool_compact: to k .. k + slack entries), which raises the query's threshold.
 template <int EMAX>
 __device__ __forceinline__ void pool_drain(int np, float q0v, float q1v, float q2v, float q3v, int q0c, int q1c, int q2c, int q3c, float& thr,
                                            float* pool_s, unsigned* pool_i, int qb, int lane, int k, unsigned row0, int klw, int* cnt) {

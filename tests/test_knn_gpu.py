@@ -324,7 +324,7 @@ def test_wide_k_bit_exact(cuda_device, M, D, nq, k, metric):
 @pytest.mark.parametrize("k,metric,fp16", [(40, "dot_product", False), (100, "dot_product", False), (64, "l2", False),
                                            (30, "dot_product", True)])
 def test_candidate_pool_exact_ties_across_compactions(cuda_device, k, metric, fp16):
-    """k > 32 keeps unsorted candidate pools that are compacted by a radix select whenever they fill up: hundreds of
+    """k > 32 keeps unsorted candidate pools that are compacted whenever they fill up (by bisection; by an exact radix select when the scores cannot be separated): hundreds of
     bit-identical scores (duplicate rows, zero rows under L2: scores of -0/+0) must still leave by ascending id."""
     M, D, nq = 9000, 32, 70
     bank = gi.unit_bank(M, D, seed=21)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """End-to-end evaluator timing with a zero-cost token source: what the engine adds around the kernels.
-usage: exp_e2e.py n_train n_val batch input patch D C [memory_size]"""
+usage: exp_e2e.py n_train n_val batch input patch D C [memory_size]   (E2E_FP16=1: nn_params use_fp16)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "open-hummingbird-eval_amd"), ROOT]
@@ -23,7 +23,7 @@ train = dm.get_train_dataloader() if hasattr(dm, "get_train_dataloader") else dm
 val = dm.get_val_dataloader() if hasattr(dm, "get_val_dataloader") else dm.val_dataloader()
 torch.cuda.synchronize(); t0 = time.time()
 kw = dict(memory_size=mem) if mem else {}
-ev = HbirdEvaluation(ext, train, num_classes=C, n_neighbours=30, augmentation_epoch=1, device="cuda", nn_method="hip", dataset_size=n_train, **kw)
+ev = HbirdEvaluation(ext, train, num_classes=C, n_neighbours=30, augmentation_epoch=1, device="cuda", nn_method="hip", dataset_size=n_train, nn_params={"use_fp16": bool(os.environ.get("E2E_FP16"))}, **kw)
 torch.cuda.synchronize(); t1 = time.time()
 print(f"bank build: {t1 - t0:.3f} s for {n_train} images ({(t1 - t0) / max(1, (n_train + B - 1) // B) * 1e3:.1f} ms per batch of {B})", flush=True)
 for rep in range(2):
