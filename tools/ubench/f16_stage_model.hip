@@ -25,7 +25,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 #define FENCE __builtin_amdgcn_sched_barrier(0);
 
-template <int NW, int QT, int SHAPE, bool R, bool Q, bool C, bool B, int DEPTH>
+template <int NW, int QT, int SHAPE, bool R, bool Q, bool C, bool B, int DEPTH, int STREAM = 0>
 __global__ __launch_bounds__(NW * 64, NW / 4) void model(const char* __restrict__ bank, const char* __restrict__ qsrc, float* out,
                                                           unsigned long long* clk, int groups) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -48,6 +48,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void model(const char* __restrict_
     if (threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     int slot = 0;
     size_t boff = 0; unsigned qoff = 0;
+    // STREAM 0: every workgroup copies the same 64 MiB (L2-resident, like a clustered search at its best); 1: every workgroup its own
+    // 48 MiB region of a 12 GiB buffer (HBM: an unclustered search); 2: eight neighbouring workgroups share a region (8 x 1 clusters)
+    constexpr size_t REGION = (size_t)48 << 20;
+    // (blocks b, b + 8, ... sit on one XCD: a cluster = eight such neighbours)
+    const char* const bsrc = STREAM == 0 ? bank : bank + (size_t)(STREAM == 1 ? blockIdx.x : (blockIdx.x & 7) * 4 + (blockIdx.x >> 6)) * REGION;
 #define MM(J, T, BQ)                                                                                                          \
     if (SHAPE == 0) acc[J][T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[T], BQ, acc[J][T], 0, 0, 0);                          \
     else { acc4[(J) * 32 + 4 * (T)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[T], BQ, acc4[(J) * 32 + 4 * (T)], 0, 0, 0);     \
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void model(const char* __restrict_
             _Pragma("unroll") for (int j = 0; j < QT; ++j) { FENCE MM(j, t, bq[U][j]) FENCE }                                  \
             if (R) fa[t] = A[((t * 2 + ((U) & 1)) * 64)];                                                                      \
             if (C && t >= 2 && t < 2 + CPW)                                                                                   \
-                __builtin_amdgcn_global_load_lds((gbl_cvoid*)(bank + boff + (size_t)(w * CPW + t - 2) * 1024 + lane_off),     \
+                __builtin_amdgcn_global_load_lds((gbl_cvoid*)(bsrc + boff + (size_t)(w * CPW + t - 2) * 1024 + lane_off),     \
                                                  (lds_void*)(smem + ((slot + 4) & 7) * 16384 + (w * CPW + t - 2) * 1024 + ((U) & 1) * 8192), 16, 0, 0); \
             if (Q && t == 0) {                                                                                                \
                 _Pragma("unroll") for (int j = 0; j < QT; ++j)                                                                \
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void model(const char* __restrict_
             }                                                                                                                 \
         }                                                                                                                     \
         FENCE                                                                                                                 \
-        boff = (boff + 8192) & ((size_t)(64 << 20) - 1);                                                                      \
+        boff += 8192; if (boff >= (STREAM == 0 ? (size_t)(64 << 20) : REGION)) boff = 0;                                                                      \
         qoff += QT * 1024u; if (qoff >= 49152u * QT) qoff = 0;                                                                \
         if ((U) & 1) {                                                                                                        \
             /* everything but the newest (DEPTH - 1) groups' requests has landed */                                            \
@@ -96,9 +101,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void model(const char* __restrict_
 
 static const char* g_bank; static const char* g_q; static float* g_out; static unsigned long long* g_clk;
 
-template <int NW, int QT, int SHAPE, bool R, bool Q, bool C, bool B, int DEPTH>
+template <int NW, int QT, int SHAPE, bool R, bool Q, bool C, bool B, int DEPTH, int STREAM = 0>
 void run(const char* name, int groups) {
-    auto fn = model<NW, QT, SHAPE, R, Q, C, B, DEPTH>;
+    auto fn = model<NW, QT, SHAPE, R, Q, C, B, DEPTH, STREAM>;
     hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     fn<<<256, NW * 64, 131072>>>(g_bank, g_q, g_out, g_clk, groups / 8);
     hipDeviceSynchronize();
@@ -119,7 +124,15 @@ void run(const char* name, int groups) {
            err == hipSuccess ? "" : "  LAUNCH FAILED");
 }
 
-int main() {
+__global__ void fill_kernel(_Float16* p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u + 12345u; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+        p[i] = (_Float16)(((x & 0xFFFF) / 65535.0f - 0.5f) * 0.2f);
+    }
+}
+
+int main(int argc, char** argv) {
+    const bool streams_only = argc > 1;
     const size_t bank_bytes = (size_t)64 << 20, q_bytes = (size_t)256 * 8 * 49152 * 3;
     std::vector<_Float16> h((bank_bytes + q_bytes) / 2);
     srand(1);
@@ -128,6 +141,19 @@ int main() {
     g_bank = buf; g_q = buf + bank_bytes;
     hipMalloc(&g_out, 256 * 512 * 4); hipMalloc(&g_clk, 512 * 8);
     const int G = 48 * 4000;   // groups per workgroup: 4,000 bank tiles of 24 k32 stages
+    if (streams_only) {   // `f16_stage_model streams`: the full loop on a bank stream that comes from L2 / from HBM per workgroup / from HBM per cluster of 8
+        char* big; const size_t big_bytes = (size_t)256 * ((size_t)48 << 20);
+        if (hipMalloc(&big, big_bytes) != hipSuccess) { printf("no memory for the 12 GiB stream buffer\n"); return 1; }
+        fill_kernel<<<4096, 256>>>((_Float16*)big, big_bytes / 2); hipDeviceSynchronize();
+        const char* shared = g_bank;
+        for (int rep = 0; rep < 2; ++rep) {
+            g_bank = shared; run<8, 1, 0, true, true, true, true, 8, 0>("full loop, bank stream shared by all workgroups (L2)", G);
+            g_bank = big;    run<8, 1, 0, true, true, true, true, 8, 2>("full loop, one bank stream per 8 workgroups (HBM, 8 x 1 clusters)", G);
+            g_bank = big;    run<8, 1, 0, true, true, true, true, 8, 1>("full loop, one bank stream per workgroup (HBM, unclustered)", G);
+            g_bank = big;    run<8, 1, 0, false, false, true, false, 8, 1>("MFMAs + copies only, one stream per workgroup", G);
+        }
+        return 0;
+    }
     for (int rep = 0; rep < 2; ++rep) {
         printf("--- 8 waves x (32 q x 256 rows), 128 accumulators (the shipped tile) ---\n");
         run<8, 1, 0, false, false, false, false, 8>("32x32x16 bare", G);
