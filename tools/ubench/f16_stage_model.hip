@@ -52,7 +52,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void model(const char* __restrict_
     // 48 MiB region of a 12 GiB buffer (HBM: an unclustered search); 2: eight neighbouring workgroups share a region (8 x 1 clusters)
     constexpr size_t REGION = (size_t)48 << 20;
     // (blocks b, b + 8, ... sit on one XCD: a cluster = eight such neighbours)
-    const char* const bsrc = STREAM == 0 ? bank : bank + (size_t)(STREAM == 1 ? blockIdx.x : (blockIdx.x & 7) * 4 + (blockIdx.x >> 6)) * REGION;
+    const char* const bsrc = STREAM == 0 ? bank : bank + (size_t)(STREAM == 1 ? blockIdx.x : STREAM == 2 ? (blockIdx.x & 7) * 4 + (blockIdx.x >> 6)
+                                                                  : STREAM == 3 ? (blockIdx.x & 7) * 2 + (blockIdx.x >> 7) : (blockIdx.x & 7)) * REGION;   // 3: sixteen share, 4: an XCD's 32
 #define MM(J, T, BQ)                                                                                                          \
     if (SHAPE == 0) acc[J][T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[T], BQ, acc[J][T], 0, 0, 0);                          \
     else { acc4[(J) * 32 + 4 * (T)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[T], BQ, acc4[(J) * 32 + 4 * (T)], 0, 0, 0);     \
@@ -149,6 +150,8 @@ int main(int argc, char** argv) {
         for (int rep = 0; rep < 2; ++rep) {
             g_bank = shared; run<8, 1, 0, true, true, true, true, 8, 0>("full loop, bank stream shared by all workgroups (L2)", G);
             g_bank = big;    run<8, 1, 0, true, true, true, true, 8, 2>("full loop, one bank stream per 8 workgroups (HBM, 8 x 1 clusters)", G);
+            g_bank = big;    run<8, 1, 0, true, true, true, true, 8, 3>("full loop, one bank stream per 16 workgroups (HBM)", G);
+            g_bank = big;    run<8, 1, 0, true, true, true, true, 8, 4>("full loop, one bank stream per XCD (32 workgroups, HBM)", G);
             g_bank = big;    run<8, 1, 0, true, true, true, true, 8, 1>("full loop, one bank stream per workgroup (HBM, unclustered)", G);
             g_bank = big;    run<8, 1, 0, false, false, true, false, 8, 1>("MFMAs + copies only, one stream per workgroup", G);
         }
