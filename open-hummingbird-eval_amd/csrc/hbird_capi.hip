@@ -234,7 +234,7 @@ extern "C" int hb_index_set_search_options(hb_index_t* ix, int phases, int64_t s
 extern "C" int hb_index_set_rerank_copy(hb_index_t* ix, int mode) {
     if (!ix) return hb_fail("hb_index_set_rerank_copy: NULL index handle");
     if (mode < 0 || mode > 2) return hb_fail("hb_index_set_rerank_copy: mode must be 0 (automatic), 1 (always) or 2 (never)");
-    ix->rerank_copy = mode;
+    ix->rerank_copy = mode; ix->rows32_declined_cap = -1;
     if (mode == 2 && ix->rows32) {
         (void)hipSetDevice(ix->device);
         HB_HIP(hipStreamSynchronize(ix->stream));

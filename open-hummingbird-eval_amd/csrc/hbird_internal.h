@@ -109,6 +109,7 @@ struct hb_index {
     // ... and, where memory allows, the bank once more as plain fp32 rows [row][rows32_rs] for the exact re-rank (hbird_knn_f16.hip)
     float* rows32 = nullptr; int64_t rows32_cap_rows = 0, rows32_rows = 0; int rows32_rs = 0;
     int rerank_copy = 0;                                 // 0 = automatic, 1 = always, 2 = never (hb_index_set_rerank_copy)
+    int64_t rows32_declined_cap = -1;                    // automatic mode found no room for the copy at this capacity: not asked again per search
     void* q16 = nullptr; size_t q16_bytes = 0;
     char* cand = nullptr; size_t cand_bytes = 0;
     float* bmax = nullptr;                               // device scalar: max bank-row norm

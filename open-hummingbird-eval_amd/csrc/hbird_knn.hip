@@ -847,12 +847,13 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
                 HB_HIP(hipFree(ix->rows32));
                 ix->rows32 = nullptr; ix->rows32_cap_rows = 0; ix->rows32_rows = 0;
             }
-            if (!ix->rows32) {
+            if (!ix->rows32 && (ix->rerank_copy == 1 || ix->rows32_declined_cap != ix->cap_rows)) {
                 const size_t need = (size_t)ix->cap_rows * rs * 4;
                 size_t free_b = 0, total_b = 0;
                 HB_HIP(hipMemGetInfo(&free_b, &total_b));
+                ix->rows32_declined_cap = ix->cap_rows;     // (cleared below when the copy is made)
                 if (ix->rerank_copy == 1 || (free_b > need && free_b - need > total_b / 3)) {
-                    if (hipMalloc((void**)&ix->rows32, need) == hipSuccess) { ix->rows32_cap_rows = ix->cap_rows; ix->rows32_rs = rs; ix->rows32_rows = 0; }
+                    if (hipMalloc((void**)&ix->rows32, need) == hipSuccess) { ix->rows32_cap_rows = ix->cap_rows; ix->rows32_rs = rs; ix->rows32_rows = 0; ix->rows32_declined_cap = -1; }
                     else { (void)hipGetLastError(); ix->rows32 = nullptr; if (ix->rerank_copy == 1) return hb_fail("hb_index_search: no memory for the re-rank copy of the bank"); }
                 }
             }
