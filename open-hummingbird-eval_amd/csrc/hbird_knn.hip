@@ -655,13 +655,15 @@ void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out, int
         // bound k ln(N / n0), g = 1.5 1.23 x.  Measured (kernel ms, 2,074,072 x 384 fp16): first cut at 1 / 2 / 4 / 8 tiles
         // 23.6 / 24.0 / 24.0 / 24.4, growth 1.5 / 2 / 3 flat within 0.3; at 50,176 x 384 the first cut is what matters (fp32 k = 90:
         // 7.85 with cuts from 2 tiles, 6.2 from 1).
+        // Short searches (at most 64 tiles per workgroup) grow threefold: every launch costs about 40 us beyond its tiles (cfg-1, fp32: 132 /
+        // 224 / 321 / 410 / 579 / 1983 us for 1 / 2 / 3 / 4 / 6 / 21.5 tiles per workgroup), four launches instead of six there: 3.78 -> 3.72 ms.
         const long long per_wg_tiles = total_pairs / G;
         long long t = 0, step = 1;
         while (out.phase_clock.size() < HB_PHASE_CUTS) {
             t += step;
             if (t * 2 > per_wg_tiles) break;
             out.phase_clock.push_back((int)t);
-            step = std::max<long long>(step + 1, step < 128 ? step * 3 / 2 : step * 2);
+            step = std::max<long long>(step + 1, per_wg_tiles <= 64 ? step * 3 : step < 128 ? step * 3 / 2 : step * 2);
         }
     }
     if (cq < 1 || cb < 1 || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
