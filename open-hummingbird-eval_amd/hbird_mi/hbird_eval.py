@@ -151,6 +151,7 @@ class HbirdEvaluation:
         self.index.set_num_classes(num_classes)
         if nn_params.get("use_fp16", False):          # search_faiss.py:40; certified-exact fast mode, only where it pays
             self.index.set_fp16(2)                    # (rows x queries x D >= 1.5e10 (k' / 64)^2), like the plugin: never slower than fp32
+            self.index.set_rerank_copy(int(nn_params.get("rerank_copy", 0)))   # 0 automatic (when memory allows), 1 always, 2 never
         self.id_base = 0            # global id of this rank's first bank row
         self.total_rows = 0         # bank rows over all ranks
         self._label_table = None    # all-gathered labels / norms in sharded mode

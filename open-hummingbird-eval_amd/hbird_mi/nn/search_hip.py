@@ -405,6 +405,10 @@ class HipMultiIndex:
         for ix in self.indexes:
             ix.set_fp16(enable)
 
+    def set_rerank_copy(self, mode: int = 0):
+        for ix in self.indexes:
+            ix.set_rerank_copy(mode)
+
     def last_fp16_fallbacks(self) -> int:
         return self._fallbacks
 
@@ -704,6 +708,7 @@ class NearestNeighborSearchHIP(NearestNeighborSearchBase):
         self.distance_measure = distance_measure.lower()
         self.idx_shard = idx_shard
         self.use_fp16 = use_fp16
+        self.rerank_copy = int(kwargs.pop("rerank_copy", 0))     # use_fp16 only: the re-rank's row-major copy of the bank (0 automatic, 1 always, 2 never)
         self.embed_d = feature_memory.size(1)
 
         self.n_gpus = _lib.device_count()
@@ -744,6 +749,7 @@ class NearestNeighborSearchHIP(NearestNeighborSearchBase):
             out = [HipFlatIndex(self.embed_d, _METRICS[self.distance_measure], self.local_gpus[0])]
         for index in out:
             index.set_fp16(2 if self.use_fp16 else 0)                                   # search_faiss.py:40; only where it pays
+            index.set_rerank_copy(self.rerank_copy)
         return out
 
     def _add_features_to_index(self, feature_memory):
