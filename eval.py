@@ -56,6 +56,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--timm-model", type=str, default=None)
     p.add_argument("--dinov2", type=str, choices=["vits14", "vitb14", "vitl14", "vitg14"], default=None)
     p.add_argument("--checkpoint", type=str, default=None)
+    p.add_argument("--f-mem-p", type=str, default=None, help="feature-memory file: saved after the bank build; with --l-mem-p "
+                   "and both files present the bank is loaded instead of rebuilt (the reference's f_mem_p, never reachable from its CLI)")
+    p.add_argument("--l-mem-p", type=str, default=None, help="label-memory file (see --f-mem-p)")
     p.add_argument("--seed", type=int, default=123)
     p.add_argument("--out", type=str, default=None)
     p.add_argument("--log-level", choices=["DEBUG", "INFO", "WARNING", "ERROR"], default="INFO")
@@ -154,9 +157,10 @@ def main(argv: Optional[List[str]] = None) -> None:
                               num_workers=args.num_workers, ignore_index=args.ignore_index,
                               train_fs_path=args.train_fs_path, val_fs_path=args.val_fs_path,
                               frame_size=tuple(args.frame_size) if args.frame_size else None,
-                              window_stride=args.window_stride)
+                              window_stride=args.window_stride, f_mem_p=args.f_mem_p, l_mem_p=args.l_mem_p)
+    from hbird_mi import hbird_eval as _he
     summary = {"miou": float(result), "seconds": round(time.time() - t0, 3), "nn_method": args.nn_method,
-               "dataset": args.dataset_name, "n_neighbours": args.n_neighbours}
+               "dataset": args.dataset_name, "n_neighbours": args.n_neighbours, **_he.last_run_info}
     print(json.dumps(summary))
     if args.out:
         with open(args.out, "w") as f:

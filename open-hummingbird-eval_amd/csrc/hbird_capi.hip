@@ -352,6 +352,15 @@ extern "C" int hb_index_set_label_denominator(hb_index_t* ix, int P) {
     if (!ix) return hb_fail("hb_index_set_label_denominator: NULL index handle");
     if (P < 0 || P > 65535) return hb_fail("hb_index_set_label_denominator: the denominator must be in [0, 65535]");
     if (ix->nlabels > 0 && P != ix->label_P) return hb_fail("hb_index_set_label_denominator: the index already holds label rows");
+    // fp32 values <-> uint16 counts: `lab_cap` describes the buffer of ONE form.  After hb_index_reset (which keeps allocations) a change
+    // of form would leave it describing the other form's buffer -- a null or smaller one: drop both and start from no capacity.
+    if ((P == 0) != (ix->label_P == 0) && (ix->labels || ix->labels16)) {
+        HB_HIP(hipSetDevice(ix->device));
+        HB_HIP(hipStreamSynchronize(ix->stream));
+        if (ix->labels) HB_HIP(hipFree(ix->labels));
+        if (ix->labels16) HB_HIP(hipFree(ix->labels16));
+        ix->labels = nullptr; ix->labels16 = nullptr; ix->lab_cap = 0;
+    }
     ix->label_P = P;
     return 0;
 }

@@ -44,6 +44,8 @@ if not logger.handlers:
     logger.setLevel(getattr(logging, os.environ.get("HBIRD_LOG_LEVEL", "WARNING").upper(), logging.WARNING))
 
 _NN_METHODS = ("hip", "faiss", "scann")
+# what the last hbird_evaluation() call did about its bank (the CLI prints it): bank_loaded, bank_build_s, bank_rows, train_batches_loaded
+last_run_info: Dict[str, Any] = {}
 
 
 class HbirdEvaluation:
@@ -54,13 +56,18 @@ class HbirdEvaluation:
     re-implemented; the exact HIP search is used and a warning is logged).  `nn_params` keeps the Faiss
     keywords: distance_measure, idx_shard, use_fp16, gpu_ids (search_faiss.py:7); ScaNN-only keywords are
     accepted and ignored.
+
+    `reuse_memory` (trailing keyword, not in the reference, whose constructor always rebuilds and overwrites the files,
+    hbird_eval.py:165-172): when both `f_mem_p` and `l_mem_p` name existing files the bank is LOADED from them
+    (`load_memory`) and the training loader is never touched; otherwise the bank is built and saved there as in the reference.
+    `bank_loaded` / `bank_build_s` say which happened and how long it took.
     """
 
     def __init__(self, feature_extractor: torch.nn.Module, train_loader, num_classes: int, n_neighbours: int = 30,
                  augmentation_epoch: int = 1, device: torch.device | str = "cpu", nn_method: str = "scann",
                  nn_params: Optional[Dict[str, Any]] = None, memory_size: Optional[int] = None,
                  dataset_size: Optional[int] = None, f_mem_p: Optional[str] = None,
-                 l_mem_p: Optional[str] = None) -> None:
+                 l_mem_p: Optional[str] = None, reuse_memory: bool = False) -> None:
         if nn_params is None:
             nn_params = {}
         self.nn_params = nn_params
@@ -155,12 +162,22 @@ class HbirdEvaluation:
         self.id_base = 0            # global id of this rank's first bank row
         self.total_rows = 0         # bank rows over all ranks
         self._label_table = None    # all-gathered labels / norms in sharded mode
+        self.bank_loaded = False
+        import time as _time
+        t0 = _time.perf_counter()
         with torch.cuda.device(self.gpu_device):
-            filled = self._create_memory(train_loader, num_classes=self.num_classes,
-                                         eval_spatial_resolution=eval_spatial_resolution)
-            logger.info("Memory rows: %s", filled)
-            self._save_memory()
-            self._finalize_shards()
+            if reuse_memory and self._memory_files_exist():
+                # the saved bank of an earlier run: every rank takes its row range of the one file pair
+                self.batches_loaded = 0
+                self.bank_loaded = self.load_memory()
+            if not self.bank_loaded:
+                filled = self._create_memory(train_loader, num_classes=self.num_classes,
+                                             eval_spatial_resolution=eval_spatial_resolution)
+                logger.info("Memory rows: %s", filled)
+                self._save_memory()
+                self._finalize_shards()
+            torch.cuda.synchronize(self.gpu_device)
+        self.bank_build_s = _time.perf_counter() - t0
 
     def _align_cpu_rng(self) -> None:
         """Sharded bank build: every rank replays the reference's single CPU random stream (the sampling noise of
@@ -209,6 +226,11 @@ class HbirdEvaluation:
                     patch_size = input_size // S                          # 313-314
                     if self.index.ntotal == 0:
                         self._set_label_denominator(patch_size * patch_size)
+                    elif self.index.label_denominator not in (0, patch_size * patch_size):
+                        # the reference recomputes patch_size per batch (313-314); the compressed table holds counts of ONE denominator
+                        raise ValueError(f"training batches of different input sizes (patch {patch_size} x {patch_size} after a bank "
+                                         f"with label denominator {self.index.label_denominator}): the compressed label table needs one "
+                                         "patch size -- pass nn_params={'compress_labels': False} to keep fp32 label rows")
                     # K2: `y[y == 255] = 0` (310) + patchify (317) + one-hot mean (319-320)
                     label = ops.patch_label_hist(y, patch_size, num_classes, map255=True)   # [bs,S,S,C]
                     if self.memory_size is None:
@@ -296,9 +318,15 @@ class HbirdEvaluation:
             self._label_table = (None, norms)          # label rows stay with their owners
             return
         # every rank agrees on the storage form (an empty shard never saw a batch: it takes the others' denominator)
-        pden = torch.tensor([self.index.label_denominator], dtype=torch.int64, device=self.gpu_device)
+        # (ranks WITH rows that disagree -- one on fp32, one on counts, or two denominators -- fall back to fp32 rows together: a MAX alone
+        # would send the fp32 rank into copy_label_counts, which fails there while its peers wait in the all-gather)
+        own_P = self.index.label_denominator
+        pden = torch.tensor([own_P, -own_P if n_local else -(1 << 40)], dtype=torch.int64, device=self.gpu_device)
         torch.distributed.all_reduce(pden, op=torch.distributed.ReduceOp.MAX)
-        P = int(pden.item())
+        p_max, p_min = int(pden[0].item()), -int(pden[1].item())
+        P = p_max if (p_min == p_max or p_min == (1 << 40)) else 0
+        if P == 0 and p_max > 0:
+            logger.warning("ranks disagree on the label denominator (%d .. %d): the replicated label table stays fp32", p_min, p_max)
         if P > 0:      # the replicated table travels and stays as uint16 counts: half the bytes on the wire and per rank
             if n_local == 0 and self.index.label_denominator != P:
                 self.index.set_label_denominator(P)
@@ -379,11 +407,14 @@ class HbirdEvaluation:
         if self.sharded and (self.f_mem_p is not None or self.l_mem_p is not None):
             torch.distributed.barrier()
 
+    def _memory_files_exist(self) -> bool:
+        return (self.f_mem_p is not None and self.l_mem_p is not None and os.path.isfile(self.f_mem_p)
+                and os.path.isfile(self.l_mem_p))
+
     def load_memory(self) -> bool:
         """Load a bank saved by `_save_memory` (or by the reference) and rebuild the index from it; under a
         row-sharded bank every rank takes its contiguous row range of the one file."""
-        if (self.f_mem_p is not None and self.l_mem_p is not None and os.path.isfile(self.f_mem_p)
-                and os.path.isfile(self.l_mem_p)):
+        if self._memory_files_exist():
             fm = torch.load(self.f_mem_p, mmap=True)
             lm = torch.load(self.l_mem_p, mmap=True)
             lo, hi = hdist.shard_range(fm.shape[0], self.rank, self.world) if self.sharded else (0, fm.shape[0])
@@ -607,12 +638,16 @@ def hbird_evaluation(model, d_model: int, patch_size: int, dataset_name: str, da
                      nn_params: Optional[Dict[str, Any]] = None, ftr_extr_fn=None,
                      memory_size: Optional[int] = None, num_workers: int = 8, ignore_index: int = 255,
                      train_fs_path: Optional[str] = None, val_fs_path: Optional[str] = None,
-                     frame_size: Optional[Tuple[int, int]] = None, window_stride: Optional[int] = None):
+                     frame_size: Optional[Tuple[int, int]] = None, window_stride: Optional[int] = None,
+                     f_mem_p: Optional[str] = None, l_mem_p: Optional[str] = None):
     """High-level entry point with the reference's signature (hbird_eval.py:640-660).
 
-    Two trailing keywords are not in the reference: `frame_size=(H, W)` makes the datasets deliver H x W frames that
+    Four trailing keywords are not in the reference: `frame_size=(H, W)` makes the datasets deliver H x W frames that
     are processed through `input_size` windows with stride `window_stride` (default: input_size, i.e. no overlap) --
-    bank build from the window crops, evaluation stitched over the windows (BASELINE cfg-5, hbird_mi/tiling.py)."""
+    bank build from the window crops, evaluation stitched over the windows (BASELINE cfg-5, hbird_mi/tiling.py).
+    `f_mem_p` / `l_mem_p`: the bank's file pair (the constructor arguments the reference never passes, hbird_eval.py:701-712):
+    a first run builds the bank and saves it there, a later run with both files present loads it and skips the build --
+    one bank reused across runs, for any number of ranks."""
     if nn_params is None:
         nn_params = {}
     eval_spatial_resolution = input_size // patch_size                                   # 671
@@ -641,7 +676,11 @@ def hbird_evaluation(model, d_model: int, patch_size: int, dataset_name: str, da
         dataset_size *= train_loader.windows_per_frame()       # every window is a bank image
     evaluator = HbirdEvaluation(feature_extractor, train_loader, num_classes=num_classes, n_neighbours=n_neighbours,
                                 augmentation_epoch=augmentation_epoch, device=device, nn_method=nn_method,
-                                nn_params=nn_params, memory_size=memory_size, dataset_size=dataset_size)
+                                nn_params=nn_params, memory_size=memory_size, dataset_size=dataset_size,
+                                f_mem_p=f_mem_p, l_mem_p=l_mem_p, reuse_memory=True)
     effective_ignore = ignore_index if ignore_index != 255 else ignore_index_local        # 715
+    last_run_info.clear()
+    last_run_info.update(bank_loaded=bool(evaluator.bank_loaded), bank_build_s=float(evaluator.bank_build_s),
+                         bank_rows=int(evaluator.total_rows), train_batches_loaded=int(evaluator.batches_loaded))
     return evaluator.evaluate(val_loader, eval_spatial_resolution=eval_spatial_resolution,
                               return_knn_details=return_knn_details, ignore_index=effective_ignore, window=window)

@@ -483,6 +483,8 @@ class HipMultiIndex:
             raise RuntimeError("set_label_denominator: the index already holds label rows")
         if not 0 <= int(P) <= 32767:
             raise ValueError("set_label_denominator: P must be in [0, 32767]")
+        if (int(P) == 0) != (self._label_P == 0):
+            self._labels = None         # fp32 values <-> int16 counts: a table kept by reset() has the other form's dtype
         self._label_P = int(P)
 
     @property
@@ -498,7 +500,7 @@ class HipMultiIndex:
         self._c = int(c)
         need = self._nlab + n
         dt = torch.int16 if self._label_P else torch.float32
-        if self._labels is None or self._labels.shape[0] < need or self._labels.shape[1] != c:
+        if self._labels is None or self._labels.shape[0] < need or self._labels.shape[1] != c or self._labels.dtype != dt:
             planned = (self._quota * len(self.indexes)) if (self.shard and self._quota) else 0
             cap = max(need, planned, 0 if self._labels is None else self._labels.shape[0] * 3 // 2)
             grown = torch.empty((cap, c), dtype=dt, device=self.home)

@@ -358,3 +358,47 @@ def test_two_rank_sharded_bank_saves_one_reference_format_file_pair(cuda_device,
     ev.f_mem_p, ev.l_mem_p = str(tmp_path / "fm.pt"), str(tmp_path / "lm.pt")
     assert ev.load_memory() and ev.index.ntotal == g["feature_memory_unb"].shape[0]
     assert abs(ev.evaluate(c["val"], c["S"], ignore_index=c["ign"]) - float(g["jac_unb"])) < 1e-4
+
+
+def _reuse_worker(rank, world, port, golden_dir, tmp, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "open-hummingbird-eval_amd"), os.path.join(root, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from helpers import IndexedReplayExtractor, golden_case_indexed
+    from hbird_mi.hbird_eval import HbirdEvaluation
+
+    class Untouchable(list):
+        def __iter__(self):
+            raise AssertionError("the training loader was iterated although the saved bank exists")
+
+    g = np.load(f"{golden_dir}/g67_memory_evaluate.npz")
+    c = golden_case_indexed(g, "unb")
+    fp, lp = os.path.join(tmp, "fm.pt"), os.path.join(tmp, "lm.pt")
+    have = os.path.isfile(fp) and os.path.isfile(lp)
+    ev = HbirdEvaluation(IndexedReplayExtractor(c["tokens_by_key"], c["S"], c["D"]), Untouchable(c["train"]) if have else c["train"],
+                         num_classes=c["C"], n_neighbours=c["k"], device="cuda:0", nn_method="hip", nn_params={"idx_shard": True},
+                         f_mem_p=fp, l_mem_p=lp, reuse_memory=True)
+    jac, det = ev.evaluate(c["val"], c["S"], return_knn_details=True, ignore_index=c["ign"])
+    ret[(world, have, rank)] = (bool(ev.bank_loaded), int(ev.batches_loaded), float(jac), int(ev.total_rows),
+                                det["knns_ca_labels"].numpy().view(np.uint32).copy())
+    td.destroy_process_group()
+
+
+def test_saved_bank_is_reused_by_two_ranks(cuda_device, golden_dir, tmp_path):
+    """SURVEY 8 f2 under a row-sharded bank: two ranks build + save ONE file pair; two NEW ranks (and then one) load their row ranges of
+    it without touching the training loader: same mIoU, same label_hat bits per rank."""
+    ret = mp.Manager().dict()
+    mp.spawn(_reuse_worker, args=(2, _free_port(), golden_dir, str(tmp_path), ret), nprocs=2, join=True)     # builds
+    mp.spawn(_reuse_worker, args=(2, _free_port(), golden_dir, str(tmp_path), ret), nprocs=2, join=True)     # loads
+    mp.spawn(_reuse_worker, args=(1, _free_port(), golden_dir, str(tmp_path), ret), nprocs=1, join=True)     # loads into one rank
+    g = np.load(f"{golden_dir}/g67_memory_evaluate.npz")
+    for r in (0, 1):
+        b, l = ret[(2, False, r)], ret[(2, True, r)]
+        assert b[0] is False and b[1] > 0 and l[0] is True and l[1] == 0
+        assert l[2] == b[2] and l[3] == b[3] == g["feature_memory_unb"].shape[0] and np.array_equal(l[4], b[4])
+    one = ret[(1, True, 0)]
+    assert one[0] is True and one[1] == 0 and abs(one[2] - float(g["jac_unb"])) < 1e-4

@@ -321,3 +321,60 @@ def test_use_fp16_through_the_evaluator_only_where_it_pays(cuda_device):
     res = {f: (v[0], min(v[1])) for f, v in res.items()}
     assert torch.equal(res[False][0], res[True][0])
     assert res[True][1] < 1.25 * res[False][1], (res[True][1], res[False][1])       # (round 2, unphased pools: mode 1 measured 1.7x slower here; now 0.5x)
+
+
+def _reuse_worker(rank, golden_dir, tmp, phase, ret):
+    """One fresh process: phase 0 builds the bank and saves it, phase 1 finds the files and must not touch the training loader."""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "open-hummingbird-eval_amd"), os.path.join(root, "tests")]
+    from helpers import ReplayExtractor, golden_case
+    from hbird_mi.hbird_eval import HbirdEvaluation
+
+    class Untouchable(list):
+        def __iter__(self):
+            raise AssertionError("the training loader was iterated although the saved bank exists")
+
+    g = np.load(f"{golden_dir}/g67_memory_evaluate.npz")
+    c = golden_case(g, "unb")
+    fp, lp = os.path.join(tmp, "f.pt"), os.path.join(tmp, "l.pt")
+    tokens = (c["tr_tok"] if phase == 0 else []) + c["va_tok"]
+    train = c["train"] if phase == 0 else Untouchable(c["train"])
+    ev = HbirdEvaluation(ReplayExtractor(tokens, c["S"], c["D"]), train, num_classes=c["C"], n_neighbours=c["k"],
+                         device="cuda", nn_method="hip", f_mem_p=fp, l_mem_p=lp, reuse_memory=True)
+    jac, det = ev.evaluate(c["val"], c["S"], return_knn_details=True, ignore_index=c["ign"])
+    ret[phase] = (bool(ev.bank_loaded), float(ev.bank_build_s), int(ev.batches_loaded), float(jac),
+                  det["knns_ca_labels"].numpy().view(np.uint32).copy(), int(ev.index.ntotal))
+
+
+def test_saved_bank_is_reused_by_a_new_process(cuda_device, golden_dir, tmp_path):
+    """a first process builds + saves (f_mem_p / l_mem_p), a second one loads: no training batch decoded, the same
+    label_hat bits and mIoU."""
+    import torch.multiprocessing as mp
+    ret = mp.Manager().dict()
+    for phase in (0, 1):
+        mp.spawn(_reuse_worker, args=(golden_dir, str(tmp_path), phase, ret), nprocs=1, join=True)
+    built, loaded = ret[0], ret[1]
+    assert built[0] is False and built[2] > 0
+    assert loaded[0] is True and loaded[2] == 0 and loaded[5] == built[5]
+    assert loaded[3] == built[3] and np.array_equal(loaded[4], built[4])
+    g = np.load(f"{golden_dir}/g67_memory_evaluate.npz")
+    assert abs(loaded[3] - float(g["jac_unb"])) < 1e-4
+
+
+def test_cli_reuses_the_saved_bank(cuda_device, tmp_path):
+    """eval.py --f-mem-p / --l-mem-p: the second invocation reports bank_loaded and the same mIoU."""
+    import importlib.util, json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("hb_cli", os.path.join(root, "eval.py"))
+    cli = importlib.util.module_from_spec(spec); spec.loader.exec_module(cli)
+    res = []
+    for i in range(2):
+        out = str(tmp_path / f"res{i}.json")
+        cli.main(["--dataset-name", "synthetic", "--data-dir", "", "--d-model", "3", "--patch-size", "8", "--input-size", "64",
+                  "--batch-size", "8", "--device", "cuda", "--nn-method", "hip", "--out", out, "--log-level", "WARNING",
+                  "--f-mem-p", str(tmp_path / "f.pt"), "--l-mem-p", str(tmp_path / "l.pt")])
+        res.append(json.load(open(out)))
+    assert res[0]["bank_loaded"] is False and res[0]["train_batches_loaded"] > 0
+    assert res[1]["bank_loaded"] is True and res[1]["train_batches_loaded"] == 0
+    assert res[1]["bank_rows"] == res[0]["bank_rows"] and res[1]["miou"] == res[0]["miou"]

@@ -1,17 +1,22 @@
 """Spill guard: every shipped kNN kernel instantiation is held to the committed register / spill / scratch baseline.
 No test fails when a header change for ONE kernel pushes ANOTHER over its scalar registers -- it only gets slower (round 2: +12 % at
-k = 90 from 16 reloads of spilled SGPRs per stage) -- so the build leaves hipcc's per-kernel resource report in lib/ and this test
+k = 90 from 16 reloads of spilled SGPRs per stage) -- so the build leaves hipcc's per-kernel resource report in lib/build/ (untracked) and this test
 compares it with tests/golden/kernel_resources.json (rewrite it with `python tools/kernel_resources.py --write-baseline` when a
 change is meant to move the numbers)."""
 import json
 import os
+import shutil
 import subprocess
 import sys
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"))),
+                    reason="needs hipcc: the resource report is a by-product of compiling the kNN units")
 def test_no_kernel_spills_more_than_the_baseline():
     subprocess.run(["make", "-C", os.path.join(ROOT, "open-hummingbird-eval_amd", "csrc"), "-j", "8"], check=True,
                    stdout=subprocess.PIPE, stderr=subprocess.STDOUT)          # a no-op when the library is up to date

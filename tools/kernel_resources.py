@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Registers / spills / scratch of every kNN kernel, from the resource reports the build leaves in open-hummingbird-eval_amd/lib/
-(csrc/Makefile compiles the kNN units with -Rpass-analysis=kernel-resource-usage).
+(untracked lib/build/: csrc/Makefile compiles the kNN units with -Rpass-analysis=kernel-resource-usage).
 
 usage: kernel_resources.py                  print one line per kernel
        kernel_resources.py --write-baseline  also rewrite tests/golden/kernel_resources.json (the spill guard's baseline:
                                              tests/test_kernel_resources_cpu.py fails when a shipped kernel spills more than this)"""
 import glob, json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "open-hummingbird-eval_amd", "lib")
+LIB = os.path.join(ROOT, "open-hummingbird-eval_amd", "lib", "build")
 FIELDS = {"VGPRs": "vgpr", "AGPRs": "agpr", "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill", "ScratchSize [bytes/lane]": "scratch",
           "Occupancy [waves/SIMD]": "waves_per_simd"}
 
