@@ -41,6 +41,7 @@ import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 PEAK_FP16_MFMA_TFLOPS = 2516.6   # 256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz (dense, no sparsity)
+LABEL_P = 196                    # pixels per patch of the synthetic soft labels (14 x 14): every label value is j / 196
 
 
 def parse():
@@ -63,8 +64,21 @@ def parse():
                     "HBIRD_BENCH_OVERLAP=1 asks for the side stream (the default is the kNN stream anyway)")
     ap.add_argument("--checksum", action="store_true", help="add label_hat_checksum (bit sum + float64 sum of the last step's "
                     "label_hat over all queries): equal for any number of ranks")
+    ap.add_argument("--no-selftest", action="store_true", help="N > 1: skip the check of the merged neighbour lists of 64 queries against the "
+                    "chain oracle (every rank searches its shard on the CPU, rank 0 merges) that runs before the timed steps")
+    ap.add_argument("--no-e2e", action="store_true", help="N = 1: skip the end-to-end leg (random-weight ViT -> HbirdEvaluation.evaluate on this bank)")
+    ap.add_argument("--e2e-batches", type=int, default=3, help="validation batches of the end-to-end leg in fp32 mode (use_fp16 mode: twice as many)")
+    ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 --pmc pass behind clock_ghz / mfma_busy")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # one untimed step under rocprofv3 --pmc
     return ap.parse_args()
+
+
+def images_note(nq):
+    """' (B x N)' when the query count is a whole number of 37 x 37- or 14 x 14-token images, else nothing."""
+    for n in (1369, 196):
+        if nq % n == 0:
+            return f" ({nq // n} x {n})"
+    return ""
 
 
 def kernel_source_hash():
@@ -117,10 +131,15 @@ def build_bank(index, rows_lo, rows_hi, D, C, device):
         g.manual_seed(5000 + r // chunk)
         c1 = torch.randint(0, C, (chunk,), generator=g, device=device)
         c2 = torch.randint(0, C, (chunk,), generator=g, device=device)
-        cnt = torch.randint(0, 197, (chunk,), generator=g, device=device).float() / 196.0
+        j = torch.randint(0, LABEL_P + 1, (chunk,), generator=g, device=device)
+        j = torch.where(c1 == c2, torch.full_like(j, LABEL_P), j)        # one class: the whole patch
+        # exactly what K2 produces: (float)count / (float)P per class (hbird_eval.py:319-320) -- a division by a 0-dim TENSOR (torch turns a
+        # Python-scalar divisor into a multiplication by the reciprocal on the GPU, another rounding), so that the index can keep the rows
+        # as uint16 counts (hb_index_set_label_denominator: half the table, what the evaluator does by default)
+        P = torch.tensor(float(LABEL_P), device=device)
         lab = torch.zeros((chunk, C), device=device)
-        lab.scatter_(1, c1[:, None], cnt[:, None])
-        lab.scatter_add_(1, c2[:, None], (1.0 - cnt)[:, None])
+        lab.scatter_(1, c2[:, None], ((LABEL_P - j).float() / P)[:, None])
+        lab.scatter_(1, c1[:, None], (j.float() / P)[:, None])
         index.add_labels(lab[lo:hi])
         del full, lab
         r = c0 + hi
@@ -269,6 +288,55 @@ def miou_parity(device):
             "fixture": "tests/golden/g67_memory_evaluate.npz (reference HbirdEvaluation outputs)", "tolerance": 1e-4}
 
 
+def pmc_pass(a, kernel, counters, fp16):
+    """One `rocprofv3 --kernel-trace --pmc <counters>` child pass of this script in --pmc-child mode (same bank, ONE untimed search; the
+    program itself follows `--`).  -> ({counter: sum over the kernel family's dispatches, "ms": their total duration, "launches": n,
+    "kernel": the name of the dispatch that ran longest}, None) or (None, why)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    import csv
+    env = dict(os.environ); env["TMPDIR"] = "/tmp"
+    args = ["--rows", str(a.rows), "--dim", str(a.dim), "--classes", str(a.classes), "--nq", str(a.nq), "--k", str(a.k),
+            "--workgroups", str(a.workgroups), "--panel", str(a.panel), "--variant", str(a.variant)] + (["--fp16"] if fp16 else [])
+    out = tempfile.mkdtemp(prefix="hbird_pmc_", dir="/tmp")
+    try:
+        cmd = [exe, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", out, "--",
+               sys.executable, os.path.abspath(__file__), "--pmc-child"] + args
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        vals, dur, names = {}, {}, {}
+        for root, _, files in os.walk(out):
+            for f in files:
+                if f.endswith("counter_collection.csv"):
+                    for row in csv.DictReader(open(os.path.join(root, f))):
+                        if kernel in row["Kernel_Name"] and row["Counter_Name"] in counters:
+                            vals[row["Counter_Name"]] = vals.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                            dur[row["Dispatch_Id"]] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
+                            names[row["Dispatch_Id"]] = row["Kernel_Name"].split("(")[0].replace("void ", "")
+        if not dur:
+            return None, f"rocprofv3 --pmc {' '.join(counters)}: no {kernel} rows (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}"
+        vals["ms"] = sum(dur.values()); vals["launches"] = len(dur); vals["kernel"] = names[max(dur, key=dur.get)]
+        return vals, None
+    except Exception as e:     # optional evidence, never a reason to lose the bench line
+        return None, f"rocprofv3 --pmc {' '.join(counters)} failed: {e!r}"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def matrix_pipe_counters(a, kernel, fp16):
+    """clock_ghz and mfma_busy of the kNN kernel family from one counter pass (MI355X_MICROARCH.md, rocprofv3 section): GRBM_GUI_ACTIVE
+    counts busy cycles per XCD (8 of them) -> clock = GRBM_GUI_ACTIVE / 8 / kernel time; SQ_VALU_MFMA_BUSY_CYCLES sums the cycles each
+    of the 1024 SIMDs had its matrix pipe busy -> mfma_busy = that / 1024 / (GRBM_GUI_ACTIVE / 8).  frac of the nominal peak =
+    mfma_busy x clock / 2.4 GHz: the decomposition of a power-limited kernel's roofline fraction."""
+    v, why = pmc_pass(a, kernel, ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], fp16)
+    if v is None:
+        return {"clock_ghz": None, "mfma_busy": None, "source": why}
+    cyc = v["GRBM_GUI_ACTIVE"] / 8.0
+    return {"clock_ghz": cyc / (v["ms"] * 1e-3) / 1e9, "mfma_busy": v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc,
+            "kernel_ms_under_counters": v["ms"], "launches": v["launches"],
+            "source": f"live: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE on {v['kernel']} (one search); frac of the nominal peak = mfma_busy x clock_ghz / 2.4"}
+
+
 def measure_traffic(a, kernel):
     """roofline.traffic measured LIVE: two `rocprofv3 --pmc` child passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one
     pass, MI355X_MICROARCH.md "rocprofv3 PMC slots") of this script in --pmc-child mode (same bank, one untimed step;
@@ -309,6 +377,132 @@ def measure_traffic(a, kernel):
             shutil.rmtree(out, ignore_errors=True)
     return 2.0 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024, \
         f"live: rocprofv3 --pmc on {vals['kernel']} ({vals['launches']} launch(es) of one search): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE = {vals['FETCH_SIZE']:.0f} KiB x2 + {vals['WRITE_SIZE']:.0f} KiB"
+
+
+class DinoV2LikeViT(torch.nn.Module):
+    """A plain pre-norm ViT with the DINOv2 interface (`forward_features(x)["x_norm_patchtokens"]`; the class name makes
+    hbird_mi.models.FeatureExtractor pick its dinov2 path, models.py:199-206) and random weights: there is no network for checkpoints, and
+    the end-to-end leg measures throughput, which does not depend on them."""
+
+    def __init__(self, img, patch, dim, depth, heads):
+        super().__init__()
+        nn = torch.nn
+        self.patch_embed = nn.Conv2d(3, dim, patch, patch)
+        n = (img // patch) ** 2
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embed = nn.Parameter(0.02 * torch.randn(1, n + 1, dim))
+        self.blocks = nn.ModuleList([nn.TransformerEncoderLayer(dim, heads, 4 * dim, dropout=0.0, activation="gelu", batch_first=True,
+                                                                norm_first=True) for _ in range(depth)])
+        self.norm = nn.LayerNorm(dim)
+
+    def forward_features(self, x):
+        t = self.patch_embed(x).flatten(2).transpose(1, 2)
+        t = torch.cat([self.cls_token.expand(t.shape[0], -1, -1), t], dim=1) + self.pos_embed
+        for b in self.blocks:
+            t = b(t)
+        t = self.norm(t)
+        return {"x_norm_clstoken": t[:, 0], "x_norm_patchtokens": t[:, 1:]}
+
+
+def e2e_leg(index, D, C, k, nq, device, n_batches):
+    """BASELINE.json's configs are whole evaluations: images -> ViT -> kNN -> label aggregation -> upsample + argmax -> confusion matrix.
+    This leg times HbirdEvaluation.evaluate (hbird_eval.py:184-265 of the reference) on the bench's own bank with a random-weight ViT of
+    the config's architecture and synthetic images / masks from pinned host memory: images/s and where a batch's time goes."""
+    from hbird_mi.hbird_eval import HbirdEvaluation
+    from hbird_mi.models import FeatureExtractor
+    arch = {384: ("ViT-S/16", 224, 16, 12, 6), 768: ("ViT-B/14", 518, 14, 12, 12), 1024: ("ViT-L/14", 518, 14, 24, 16),
+            1536: ("ViT-g/14", 518, 14, 40, 24)}.get(D)
+    if arch is None:
+        return {"skipped": f"no ViT of width {D} in the reference's model list"}
+    name, img, patch, depth, heads = arch
+    S = img // patch
+    if nq % (S * S) != 0:
+        return {"skipped": f"{nq} queries per step are not whole {S} x {S}-token images"}
+    B = nq // (S * S)
+    torch.manual_seed(0)
+    vit = DinoV2LikeViT(img, patch, D, depth, heads).to(device).eval()
+    ext = FeatureExtractor(vit, eval_spatial_resolution=S, d_model=D)            # fp16 autocast + inference_mode: the reference's API default
+    ev = HbirdEvaluation.from_index(ext, index, C, n_neighbours=k, device=str(device))
+    g = torch.Generator().manual_seed(11)
+
+    def loader(n):
+        out = []
+        for _ in range(n):
+            x = torch.randn((B, 3, img, img), generator=g).pin_memory()
+            y = (torch.randint(0, C, (B, 1, img, img), generator=g).float() / 255.0).pin_memory()      # masks as the reference's ToTensor delivers them
+            out.append((x, y))
+        return out
+    res = {"model": f"{name} (random init), {img} px, batch {B}, FeatureExtractor (fp16 autocast)", "queries_per_batch": nq}
+    for mode, fp16, n in (("fp32", False, n_batches), ("use_fp16", True, 2 * n_batches)):
+        index.set_fp16(fp16)
+        ev.profile = False
+        ev.evaluate(loader(1), S, ignore_index=255)                               # warm-up (kernels, fp16 copies of the bank, allocator)
+        val = loader(n)
+        ev.profile = True
+        torch.cuda.synchronize(device)
+        t0 = time.time()
+        jac = ev.evaluate(val, S, ignore_index=255)
+        torch.cuda.synchronize(device)
+        dt = time.time() - t0
+        st = ev.stage_times() or {}
+        stages = {key: round(st[key], 3) for key in ("h2d_ms", "vit_forward_ms", "knn_k5_ms", "k6_k7_ms") if key in st}
+        stages["loader_wait_ms"] = round(1e3 * st.get("loader_wait_s_total", 0.0) / max(1, n), 3)
+        on_stream = {key: v for key, v in stages.items() if key in ("vit_forward_ms", "knn_k5_ms", "k6_k7_ms")}
+        res[mode] = {"images_per_s": B * n / dt, "ms_per_batch": dt / n * 1e3, "batches": n, "per_batch_ms": stages,
+                     "bound_by": max(on_stream, key=on_stream.get) if on_stream else None,
+                     "h2d_and_loader": "overlapped: the next batch is fetched and copied on a side stream during the current search",
+                     "miou_of_random_weights": float(jac)}
+    index.set_fp16(False)
+    del ev, ext, vit
+    torch.cuda.empty_cache()
+    return res
+
+
+def selftest_against_oracle(index, q, k, lo, hi, world, rank, device, search_merged):
+    """Before the timed steps of an N-rank run: the merged neighbour lists of 64 queries (what the ranks' kernels + the packed all-gather + the
+    in-place merge produce) against the CPU chain oracle -- every rank searches ITS shard's rows with oracle.knn_chain_f32 (the checker, not
+    the thing measured), the per-rank lists are gathered and merged on the host by (score descending, id ascending).  Ids AND score bits must
+    agree on every rank; a mismatch ends the run with a message and a non-zero status (nothing is re-executed)."""
+    import oracle
+    td = torch.distributed
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import chain_oracle_topk_chunked
+    nsel = min(64, q.shape[0])
+    sel = torch.linspace(0, q.shape[0] - 1, nsel, device=device).long()
+    mi, md = search_merged()                                    # [nq, k] merged ids / ordering scores, identical on every rank
+    got_i, got_d = mi[sel].cpu().numpy(), md[sel].cpu().numpy()
+    oracle.set_num_threads(max(1, host_cpu_budget()["cores"] // max(1, world)))
+    n_local = hi - lo
+    if n_local > 0:
+        ci, cd = chain_oracle_topk_chunked(index, q[sel], n_local, min(k, n_local))
+        ci = ci + lo
+        if ci.shape[1] < k:
+            pad = k - ci.shape[1]
+            ci = np.concatenate([ci, np.full((nsel, pad), -1, dtype=np.int64)], axis=1)
+            cd = np.concatenate([cd, np.full((nsel, pad), -np.inf, dtype=np.float32)], axis=1)
+    else:
+        ci = np.full((nsel, k), -1, dtype=np.int64); cd = np.full((nsel, k), -np.inf, dtype=np.float32)
+    parts_i = [torch.empty((nsel, k), dtype=torch.int64, device=device) for _ in range(world)]
+    parts_d = [torch.empty((nsel, k), dtype=torch.float32, device=device) for _ in range(world)]
+    if world > 1:
+        td.all_gather(parts_i, torch.from_numpy(ci).to(device)); td.all_gather(parts_d, torch.from_numpy(cd).to(device))
+    else:
+        parts_i, parts_d = [torch.from_numpy(ci)], [torch.from_numpy(cd)]
+    ai = np.concatenate([p.cpu().numpy() for p in parts_i], axis=1); ad = np.concatenate([p.cpu().numpy() for p in parts_d], axis=1)
+    order = np.lexsort((np.where(ai < 0, np.iinfo(np.int64).max, ai), -ad.astype(np.float64)), axis=1)[:, :k]
+    ref_i, ref_d = np.take_along_axis(ai, order, axis=1), np.take_along_axis(ad, order, axis=1)
+    ok = bool(np.array_equal(got_i, ref_i) and np.array_equal(got_d.view(np.uint32), ref_d.view(np.uint32)))
+    flag = torch.tensor([0 if ok else 1], device=device)
+    if world > 1:
+        td.all_reduce(flag)
+    if int(flag.item()) != 0:
+        bad = np.argwhere(got_i != ref_i)
+        sys.stderr.write(f"bench.py selftest FAILED on rank {rank}/{world}: merged neighbour lists differ from the chain oracle "
+                         f"({len(bad)} id mismatches on this rank, first {bad[:3].tolist()})\n")
+        sys.stderr.flush()
+        raise SystemExit(4)
+    return {"queries": int(nsel), "k": int(k), "ids_and_score_bits_equal_the_chain_oracle": True,
+            "how": "every rank: oracle.knn_chain_f32 over its own shard rows (chunked reconstruction); all-gather; host merge by (score desc, id asc)"}
 
 
 def first_collective_or_die(td, device, backend, world, rank, seconds=None):
@@ -404,19 +598,22 @@ def main():
         index.set_variant(a.variant)
     if a.fp16:
         index.set_fp16(True)
+    index.set_label_denominator(LABEL_P)       # label rows j / 196 as uint16 counts: what HbirdEvaluation does by default (half the table)
     t_build = time.time()
     build_bank(index, lo, hi, D, C, device)
     agg = index
     if dist_on:
-        # label rows and bank-row norms are small (6 GB / 40 MB at cfg-3): replicate them once so that any
-        # rank can aggregate the labels of any merged neighbour list.  They hang off a second, row-less handle, whose
-        # workspace is independent of the searching index (the aggregation may run on a side stream).
-        lab_all, counts = hdist.allgather_rows(index.gather_labels(torch.arange(hi - lo, device=device)))
+        # label rows and bank-row norms are small (3 GB of counts / 40 MB at cfg-3): replicate them once so that any
+        # rank can aggregate the labels of any merged neighbour list -- as uint16 counts, travelling as bytes (gloo has no int16
+        # collectives).  They hang off a second, row-less handle, whose workspace is independent of the searching index (the
+        # aggregation may run on a side stream).
+        cnt_local = index.copy_label_counts() if hi > lo else torch.zeros((0, C), dtype=torch.int16, device=device)
+        cnt_all, counts = hdist.allgather_rows(cnt_local.contiguous().view(torch.uint8))
         nrm_all, _ = hdist.allgather_rows(index.copy_norms())
         agg = HipFlatIndex(D, 0, dev_index)
-        agg.set_label_table(torch.cat([lab_all[r, :counts[r]] for r in range(world)]),
-                            torch.cat([nrm_all[r, :counts[r]] for r in range(world)]), 0)
-        del lab_all, nrm_all
+        agg.set_label_count_table(torch.cat([cnt_all[r, :counts[r]] for r in range(world)]).contiguous().view(torch.int16),
+                                  torch.cat([nrm_all[r, :counts[r]] for r in range(world)]), LABEL_P, 0)
+        del cnt_all, nrm_all, cnt_local
     torch.cuda.synchronize(device)
     t_build = time.time() - t_build
 
@@ -473,6 +670,14 @@ def main():
             td.barrier(**({} if one_gpu else {"device_ids": [dev_index]}))
             torch.cuda.synchronize(device)
 
+    selftest = None
+    if dist_on and not a.no_selftest:
+        def search_merged():
+            index.use_current_stream()
+            index.search_scores(q, k, lo, out=(ex[0].idx, ex[0].dist))
+            ex[0].gather()
+            return merge_topk_packed(ex[0].recv, ex[0].part_bytes, world, nq, k, 0)
+        selftest = selftest_against_oracle(index, q, k, lo, hi, world, rank, device, search_merged)
     for i in range(a.warmup):
         step(i)
     sync()
@@ -567,7 +772,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16-candidates+f32-rerank" if a.fp16 else "f32",
             "data": "synthetic",
             "config": {"workload": f"exact kNN + label aggregation, {M} x {D} fp32 bank, k={k}, "
-                                   f"{nq} query patches/step (16 x 1369), C={C}",
+                                   f"{nq} query patches/step{images_note(nq)}, C={C}",
                        "bank_rows": M, "dim": D, "k": k, "queries_per_step": nq, "classes": C,
                        "parallelism": f"bank-shard{world}" if world > 1 else "single-gpu",
                        "bank_build_s": round(t_build, 2), "schedule": index.schedule_info(),
@@ -591,6 +796,8 @@ def main():
                             "label aggregation of this rank's query slice" + (", on a side stream under the next step's kNN kernel" if overlap else
                             ", exposed after the kNN kernel (it owns every CU's registers, nothing can run beside it)"),
                 "packed_list_bytes_per_rank": ex[0].part_bytes,
+                "selftest": selftest if selftest is not None else "skipped (--no-selftest)",
+                "replicated_label_table": f"uint16 counts (denominator {LABEL_P}), {M * C * 2 / 1e9:.2f} GB per rank",
                 "exchange_split_ms_per_rank": None if overlap else {
                     "all_gather": [round(r[4], 3) for r in per_rank], "merge": [round(r[5], 3) for r in per_rank],
                     "aggregate": [round(r[6], 3) for r in per_rank]},
@@ -619,7 +826,7 @@ def main():
                                        "note": "hb_index_set_cluster(ix, 1, 1, 0); same outputs; roofline.traffic is of the timed (clustered) kernel"}
         if world == 1 and not dist_on and not a.fp16:
             # extra, not the headline: the same step in use_fp16 mode (fp16 candidate pass + certified exact fp32
-            # re-rank; returns the identical bits)
+            # re-rank; returns the identical bits, see DESIGN.md, `use_fp16`)
             index.set_fp16(True)
             index.search_aggregate(q, k, beta=0.02); torch.cuda.synchronize(device)
             index.set_timing(True)
@@ -637,11 +844,22 @@ def main():
                                     "candidate_kernel_frac_of_fp16_mfma_peak": flops / (float(np.mean(k16)) * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
                                     "note": "certified-exact fast mode, same outputs as the fp32 search"}
             index.set_fp16(False)
+        if world == 1 and not dist_on and not a.no_e2e:
+            try:
+                res["e2e"] = e2e_leg(index, D, C, k, nq, device, max(1, a.e2e_batches))
+            except Exception as e:          # an extra leg never costs the bench line
+                res["e2e"] = {"failed": repr(e)}
     if world == 1 and not dist_on:
         # roofline.traffic: live counter passes (children of this process); else the committed figure of the same
         # workload IF it was measured on these very kernel sources; else null
         del index, agg
         torch.cuda.empty_cache()
+        if not a.no_counters and not a.no_traffic:
+            res["roofline"].update({key: v for key, v in matrix_pipe_counters(a, kernel, a.fp16).items()
+                                    if key in ("clock_ghz", "mfma_busy")})
+            res["roofline"]["clock_and_busy_source"] = "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (child pass, one search)"
+            if "use_fp16_mode" in res:
+                res["use_fp16_mode"].update(matrix_pipe_counters(a, "knn_f16", True))
         traffic, note = (None, "skipped (--no-traffic)") if a.no_traffic else measure_traffic(a, kernel)
         if traffic is not None and " on " in note:     # the counter pass saw the instantiation's full name
             res["roofline"]["kernel"] = note.split(" on ", 1)[1].split(":", 1)[0]

@@ -200,12 +200,33 @@ int hb_index_last_fp16_fallbacks(const hb_index_t* ix, int64_t* n);
  * wherever it applies (D padded to a multiple of 32: what the default does too); 4 = never that kernel (both operands staged through
  * LDS); 6 = small fp32 searches with k <= 32 on sorted LDS lists as until round 3 (the default runs them on phased candidate pools).
  * 1 (4-wave fp32 kernel), 2 (first design of the fp16 candidate kernel) and 5 (16x16x32 fp16 kernel) no longer exist: same bits,
- * not faster. */
+ * not faster (profiles/LABBOOK.md). */
 int hb_index_set_variant(hb_index_t* ix, int variant);
 /* Two more A/B switches (same results): phases = 0 launches a pool search (k > 32, use_fp16, small fp32 searches) once instead of in
  * phases; small_limit_stages > 0 moves the size (k8 stages per workgroup) below which a search takes the small-search kernels (0 =
  * the built-in 400,000). */
 int hb_index_set_search_options(hb_index_t* ix, int phases, int64_t small_limit_stages);
+/* A phased search (see above; the reference's one `index.search` call, search_faiss.py:89) can run as ONE launch: the workgroups stay
+ * resident over all phases, meet at a grid barrier at each phase boundary and compute the next phase's floors themselves, instead of one
+ * launch per phase with a floor kernel between two.  Same results bit for bit.  OPT-IN (mode 2): measured on MI355X it is 2-10 % slower
+ * than a launch per phase at every size tried -- what a phase boundary costs is the arrival skew of the workgroups and the floor
+ * computation, which eight waves per CU hide worse than a launch of its own does, not the launches (profiles/r05/README.md).
+ * A workgroup that waits at a barrier for more than the timeout (a peer is not resident: the GPU shared with another process) gives the
+ * launch up -- every workgroup leaves, a second launch that is always enqueued behind the first finishes the search without barriers --
+ * so the device cannot hang; spins are bounded by the 100 MHz real-time counter.
+ * mode 0 = automatic (today: a launch per phase), 1 = a launch per phase, 2 = one launch wherever the search qualifies (pools, every
+ * workgroup resident, at most 32 slots per query tile whose pools fit the LDS between two phases).  timeout_us 0 = automatic (20 ms +
+ * twice the search's estimated time).  inject (tests and diagnostics; 0 = nothing): (kind << 28) | (phase << 16) | (block + 1) makes that
+ * block fail at that phase boundary -- kind 1: it raises the abort flag, kind 2: it leaves silently and the others run into their timeout;
+ * kind 3: no failure, every workgroup stamps the real-time counter at each boundary (hb_index_one_launch_trace). */
+int hb_index_set_one_launch(hb_index_t* ix, int mode, int64_t timeout_us, int inject);
+/* What the last search did about it (one stream synchronisation): out[0] = 1 if it ran as one launch, [1] = its phases, [2] = phase
+ * boundaries passed by block 0, [3] / [4] / [5] = ticks (100 MHz) block 0 spent in the first barrier / the floor computation / the second
+ * barrier over all boundaries, [6] = workgroups that timed out, [7] = 1 if the launch was given up and the completion launch finished it. */
+int hb_index_one_launch_stats(hb_index_t* ix, int64_t out[8]);
+/* Diagnostics: with inject = 3 << 28 every workgroup of a one-launch search stamps the 100 MHz real-time counter (low 32 bits) at each phase
+ * boundary -- out[boundary][4][workgroup]: arrival at the first barrier, its pass, floors done, pass of the second barrier. */
+int hb_index_one_launch_trace(hb_index_t* ix, uint32_t* out, int64_t max_words, int* n_boundaries, int* workgroups);
 /* use_fp16 searches re-rank their candidates in exact fp32 arithmetic.  In the fragment tiles a bank row is 2 x D/8 sixteen-byte pieces
  * 512 B apart, so that pass pulls eight times the bytes it uses; a second, row-major fp32 copy of the bank lets it read whole lines (a
  * use_fp16 search at 300,000 x 768: 8.0 -> 6.6 ms, k = 90: 18.0 -> 12.4; results identical).  mode 0 = automatic: the copy is made at the first use_fp16

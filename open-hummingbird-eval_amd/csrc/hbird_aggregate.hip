@@ -16,9 +16,12 @@
 // ordinary index.  Label-sharded aggregation (hb_index_aggregate_partial): the norms of ALL rows are replicated (4 B per row), the
 // label rows stay with their owners; every rank computes the same weights and the partial sum over the neighbours it owns, the
 // all-reduce of the partial sums is label_hat ("distributed softmax + all-reduce").
-// Label rows come as fp32 values or (U16) as uint16 counts j of values j / P -- what K2 produces: (float)j / (float)P, so a table
-// of the P + 1 quotients in LDS gives the very same fp32 values at half the gather traffic and half the table in HBM (6.2 -> 3.1 GB
-// at cfg-3, per rank when the table is replicated); denominators beyond AGG_LUT entries divide in place (same rounding).
+// Label rows come as fp32 values or (U16) as uint16 counts j of values j / P -- what K2 produces: (float)j / (float)P -- at half the
+// gather traffic and half the table in HBM (6.2 -> 3.1 GB at cfg-3, per rank when the table is replicated).  The very same fp32 value
+// comes back from three instructions instead of a division: r = RN(1 / P) once, q' = RN(j r), e = fma(-q', P, j) (exact), q = fma(e, r, q')
+// -- correctly rounded for every 0 <= j <= P <= 2048 (checked exhaustively: tests/test_ops_gpu.py::test_count_quotients_are_exact); larger
+// denominators divide in place.  (Until round 5 a table of the P + 1 quotients in LDS: 64 lanes looking up random entries conflict three-
+// to four-way, and the kernel ran slower on counts than on fp32 rows although it moved half the bytes.)
 #define AGG_LUT 2048
 template <bool U16>
 __global__ __launch_bounds__(256) void aggregate_kernel(const void* __restrict__ labels_v, int P, int64_t nlabels, int C,
@@ -30,16 +33,11 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const void* __restrict__
                                                         float beta, float* __restrict__ out) {
     __shared__ float s_w[4][AGG_MAX_K];
     __shared__ int64_t s_row[4][AGG_MAX_K];
-    __shared__ float s_lut[U16 ? AGG_LUT + 1 : 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t q = (int64_t)blockIdx.x * 4 + wv;
     const float* labels = reinterpret_cast<const float*>(labels_v);
     const unsigned short* counts = reinterpret_cast<const unsigned short*>(labels_v);
-    const float Pf = (float)P;
-    if (U16 && P <= AGG_LUT) {
-        for (int j = threadIdx.x; j <= P; j += 256) s_lut[j] = (float)j / Pf;
-        __syncthreads();
-    }
+    const float Pf = (float)P, Pr = 1.0f / Pf;
     if (q >= nq) return;   // whole wave exits together (no block-level barrier below)
     float* wgt = s_w[wv];
     int64_t* rows = s_row[wv];
@@ -71,20 +69,63 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const void* __restrict__
     }
     for (int o = 32; o > 0; o >>= 1) den += __shfl_xor(den, o);
     const float inv = den > 0.0f ? 1.0f / den : 0.0f;
+    // the weights as they enter the sum (attn_j = e_j / den), and row 0 with weight 0 for a neighbour whose label row is not here: the
+    // gather below is then branch-free, so that a batch of loads is in flight before the first is used (the kernel is bound by the
+    // gather's latency: 90 dependent-looking two-byte loads per lane at C = 151, k = 30 until round 5)
+    for (int j = lane; j < k; j += 64) {
+        const bool own = rows[j] >= 0;
+        wgt[j] = own ? wgt[j] * inv : 0.0f;
+        if (!own) rows[j] = 0;
+    }
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are visible to all its lanes
+    auto label_at = [&](int64_t rj, int c) -> float {
+        if (U16) {
+            const float jf = (float)counts[rj * (int64_t)C + c];
+            if (P > AGG_LUT) return jf / Pf;
+            const float q1 = jf * Pr;
+            return fmaf(fmaf(-q1, Pf, jf), Pr, q1);
+        }
+        return labels[rj * (int64_t)C + c];
+    };
+    constexpr int UB = 8;                  // label rows in flight per lane
+    if (C <= 32) {
+        // few classes (VOC 21, Cityscapes 19, COCO-Stuff 15 ...): G = 64 / C neighbours at a time, lane = (neighbour group g, class c);
+        // group g sums the neighbours j = g, g + G, ... in ascending order, the G partial sums are added in group order
+        const int G = 64 / C, g = lane / C, c = lane - g * C;
+        const bool act = g < G;
+        float accv = 0.0f;
+        for (int j0 = 0; j0 < k; j0 += G * UB) {
+            float lv[UB], wj[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int j = j0 + u * G + g;
+                const bool in = act && j < k;
+                wj[u] = in ? wgt[j] : 0.0f;
+                lv[u] = in ? label_at(rows[j], c) : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) accv = fmaf(wj[u], lv[u], accv);
+        }
+        float total = accv;                 // lanes of group 0: + group 1 + group 2 ...
+        for (int gg = 1; gg < G; ++gg) total += __shfl(accv, gg * C + c);
+        if (g == 0) out[q * (int64_t)C + c] = total;
+        return;
+    }
     for (int c0 = 0; c0 < C; c0 += 64) {
         const int c = c0 + lane;
+        const int cc = c < C ? c : C - 1;   // lanes past the last class repeat it (no store)
         float accv = 0.0f;
-        if (c < C)
-            for (int j = 0; j < k; ++j) {
-                const int64_t rj = rows[j];
-                if (rj >= 0) {
-                    float lv;
-                    if (U16) { const int cnt = counts[rj * (int64_t)C + c]; lv = P <= AGG_LUT ? s_lut[cnt] : (float)cnt / Pf; }
-                    else lv = labels[rj * (int64_t)C + c];
-                    accv = fmaf(wgt[j] * inv, lv, accv);
-                }
+        for (int j0 = 0; j0 < k; j0 += UB) {
+            float lv[UB], wj[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int j = j0 + u;
+                wj[u] = j < k ? wgt[j] : 0.0f;
+                lv[u] = j < k ? label_at(rows[j], cc) : 0.0f;
             }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) accv = fmaf(wj[u], lv[u], accv);
+        }
         if (c < C) out[q * (int64_t)C + c] = accv;
     }
 }

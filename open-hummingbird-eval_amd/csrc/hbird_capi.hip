@@ -133,62 +133,7 @@ extern "C" int hb_index_last_fp16_fallbacks(const hb_index_t* ix, int64_t* n) {
     return 0;
 }
 
-// Host-only: build the kNN work list for a (query tiles x bank tiles) grid without touching a GPU, for inspection
-// and tests.  segs_out receives up to max_segs rows of {block, q_tile, b_tile0, n_tiles, slot, first}.
-static int schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b, bool phased,
-                         int* segs_out, int64_t max_segs, int64_t stats[8], hb_schedule& sc, bool xcd_share = false) {
-    if (!stats) return hb_fail("hb_schedule_plan: stats is NULL");
-    if (nqt <= 0 || nbt <= 0 || workgroups <= 0 || d <= 0) return hb_fail("hb_schedule_plan: bad arguments");
-    const int dp = (d + HB_KC - 1) / HB_KC * HB_KC;
-    const int G = (int)std::min<long long>(workgroups, (long long)nqt * nbt);
-    int cq = cluster_q, cb = cluster_b;
-    if (cq < 0 || cb < 0) hb_default_cluster(nqt, nbt, G, cq == -2, &cq, &cb);  // negative: the automatic shape (-1 fp16, -2 fp32 kernel)
-    if (cq < 1 || cb < 1 || (long long)nqt * nbt < workgroups || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
-    const int panel = panel_tiles > 0 ? panel_tiles : hb_default_panel(nqt, G, (size_t)HB_BT * dp * 4, cq, cb);
-    hb_build_schedule(nqt, nbt, workgroups, panel, sc, cq, cb, phased, xcd_share && cq * cb > 1);
-    stats[0] = sc.G; stats[1] = (int64_t)sc.segs.size(); stats[2] = sc.n_slots; stats[3] = sc.panel;
-    stats[4] = sc.max_slots_per_qt; stats[5] = sc.nqt; stats[6] = sc.nbt; stats[7] = sc.cq * 16 + sc.cb;
-    if (segs_out) {
-        int64_t n = 0;
-        for (int b = 0; b < sc.G; ++b)
-            for (int i = sc.wg_off[b]; i < sc.wg_off[b + 1] && n < max_segs; ++i, ++n) {
-                const hb_seg& g = sc.segs[i];
-                int* o = segs_out + n * 10;
-                o[0] = b; o[1] = g.q_tile; o[2] = g.b_tile0; o[3] = g.n_tiles; o[4] = g.slot; o[5] = g.first;
-                o[6] = g.stride; o[7] = g.tile0; o[8] = g.next_tile0; o[9] = sc.wg_member[b];
-            }
-    }
-    return 0;
-}
-
-extern "C" int hb_schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b,
-                                int* segs_out, int64_t max_segs, int64_t stats[8]) {
-    hb_schedule sc;
-    return schedule_plan(nqt, nbt, workgroups, panel_tiles, d, cluster_q, cluster_b, false, segs_out, max_segs, stats, sc);
-}
-
-// The same for a PHASED search (pools: k > 32 and the fp16 candidate pass): the work list with its segments cut at the phase
-// clocks, the clocks, and per cut and block the position (within the block's own segments) of the first segment of the next phase.
-extern "C" int hb_schedule_plan_phased(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b,
-                                       int* segs_out, int64_t max_segs, int64_t stats[8], int* clocks_out, int max_cuts, int* n_cuts,
-                                       int* bounds_out) {
-    if (!n_cuts) return hb_fail("hb_schedule_plan_phased: n_cuts is NULL");
-    hb_schedule sc;
-    if (schedule_plan(nqt, nbt, workgroups, panel_tiles, d, cluster_q, cluster_b, true, segs_out, max_segs, stats, sc)) return -1;
-    *n_cuts = (int)sc.phase_clock.size();
-    for (int p = 0; p < *n_cuts && p < max_cuts; ++p) {
-        if (clocks_out) clocks_out[p] = sc.phase_clock[p];
-        if (bounds_out)
-            for (int b = 0; b < sc.G; ++b) bounds_out[(size_t)p * sc.G + b] = sc.phase_bounds[(size_t)p * sc.G + b] - sc.wg_off[b];
-    }
-    return 0;
-}
-
-extern "C" int hb_schedule_plan_shared(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b, int phased,
-                                       int* segs_out, int64_t max_segs, int64_t stats[8]) {
-    hb_schedule sc;
-    return schedule_plan(nqt, nbt, workgroups, panel_tiles, d, cluster_q, cluster_b, phased != 0, segs_out, max_segs, stats, sc, true);
-}
+// (hb_schedule_plan / _phased / _shared: hbird_schedule.cpp)
 
 extern "C" int hb_index_set_cluster_sharing(hb_index_t* ix, int mode) {
     if (!ix) return hb_fail("hb_index_set_cluster_sharing: NULL index handle");
@@ -229,6 +174,38 @@ extern "C" int hb_index_set_search_options(hb_index_t* ix, int phases, int64_t s
     if (!ix) return hb_fail("hb_index_set_search_options: NULL index handle");
     if (small_limit_stages < 0) return hb_fail("hb_index_set_search_options: negative limit");
     ix->phases_on = phases ? 1 : 0; ix->small_limit = small_limit_stages; ix->sched = hb_schedule();
+    return 0;
+}
+extern "C" int hb_index_set_one_launch(hb_index_t* ix, int mode, int64_t timeout_us, int inject) {
+    if (!ix) return hb_fail("hb_index_set_one_launch: NULL index handle");
+    if (mode < 0 || mode > 2) return hb_fail("hb_index_set_one_launch: mode must be 0 (automatic), 1 (a launch per phase) or 2 (one launch)");
+    if (timeout_us < 0 || timeout_us > 40000000) return hb_fail("hb_index_set_one_launch: timeout_us must be in [0, 40,000,000]");
+    ix->one_launch = mode; ix->ol_timeout_us = timeout_us; ix->ol_inject = inject;
+    return 0;
+}
+extern "C" int hb_index_one_launch_stats(hb_index_t* ix, int64_t out[8]) {
+    if (!ix || !out) return hb_fail("hb_index_one_launch_stats: NULL pointer");
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    out[1] = ix->ol_last_phases;
+    if (!ix->ol_words_dev) return 0;
+    HB_HIP(hipSetDevice(ix->device));
+    unsigned h[2 * 32];     // the abort line and the statistics line (hbird_knn_dev.h: HB_GB_ABORT, HB_GB_STATS)
+    HB_HIP(hipMemcpyAsync(h, ix->ol_words_dev + 17 * 32, sizeof(h), hipMemcpyDeviceToHost, ix->stream));
+    HB_HIP(hipStreamSynchronize(ix->stream));
+    out[0] = 1; out[2] = h[32]; out[3] = h[33]; out[4] = h[34]; out[5] = h[35]; out[6] = h[36]; out[7] = h[0] != 0;
+    return 0;
+}
+extern "C" int hb_index_one_launch_trace(hb_index_t* ix, uint32_t* out, int64_t max_words, int* n_boundaries, int* workgroups) {
+    if (!ix || !out || !n_boundaries || !workgroups) return hb_fail("hb_index_one_launch_trace: NULL pointer");
+    *n_boundaries = 0; *workgroups = 0;
+    if (!ix->ol_words_dev) return 0;
+    const int G = ix->sched.G, nb = ix->ol_last_phases - 1;
+    const int64_t words = (int64_t)nb * 4 * G;
+    if (words > max_words) return hb_fail("hb_index_one_launch_trace: the buffer is too small");
+    HB_HIP(hipSetDevice(ix->device));
+    HB_HIP(hipMemcpyAsync(out, ix->ol_words_dev + (20 * 32 + (G + 31) / 32 * 32), (size_t)words * 4, hipMemcpyDeviceToHost, ix->stream));
+    HB_HIP(hipStreamSynchronize(ix->stream));
+    *n_boundaries = nb; *workgroups = G;
     return 0;
 }
 extern "C" int hb_index_set_rerank_copy(hb_index_t* ix, int mode) {

@@ -17,6 +17,7 @@
 // oracle/hbird_oracle.c:orc_knn_chain_f32.  Ordering key: (score descending, row id ascending).
 #include "hbird_internal.h"
 #include <algorithm>
+#include <cstring>
 #include <map>
 
 #include "hbird_knn_dev.h"
@@ -33,7 +34,7 @@
 // CL: support for L2-sharing clusters (strided segments, soft sync).  A separate instantiation: its extra scalar state
 // spilled SGPRs inside the stage loop of the pool (WIDE) instantiation (k = 90: +12 % kernel time).
 // (The timing-only ablation instantiations of rounds 1-3 -- no copies / no fragment reads / no barrier / no epilogue -- and the
-// in-kernel counters of the small-search work are gone from the product: their numbers are in DESIGN.md and profiles/r01 - r03.)
+// in-kernel counters of the small-search work are gone from the product: their numbers are in profiles/LABBOOK.md and profiles/r01 - r03.)
 template <bool COLD, bool WIDE, bool CL = false>
 __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
                     tile_epilogue<true, true>(acc, thr, ps, pi, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
                 } else if constexpr (COLD) {
                     // small searches: cold start of a slot's first tile (separate instantiation, see launcher)
-                    if (seg.first && bt == seg.b_tile0) thr = fmaxf(thr, cold_start_threshold(acc, k));
+                    if (seg.first && bt == seg.b_tile0 && cold_start_needed(thr)) thr = fmaxf(thr, cold_start_threshold(acc, k));
                     // the floors requested four stages ago (waves 4-7 have nothing else in flight; waves 0-3 have passed
                     // counted waits that cover them -- except in a one-stage tile, D <= 8)
                     if (g8 < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -456,266 +457,7 @@ int hb_launch_merge_parts(const float* dist_parts, const int64_t* idx_parts, int
     return 0;
 }
 
-// ---- host-side work list ------------------------------------------------------------------------------
-// Pairs (query tile q, bank tile b) are processed panel by panel (a panel = `panel` consecutive bank
-// tiles, sized to stay resident in the 256 MiB Infinity Cache together with the queries): inside a
-// panel the q-major pair list is cut into G equal contiguous ranges, one per workgroup, so at any time
-// all workgroups read the same panel (each bank byte leaves HBM about once per search) while every
-// workgroup keeps working on the same <= 2 query tiles for the whole search.  Bank tiles are visited in
-// ascending order for every slot, which the strict `score > threshold` filter relies on for ties.
-//
-// Tried and dropped (round 1, 10 M x 768): dealing each XCD's 32 workgroups a grid of 4 query tiles x 8 bank ranges
-// per round, started together by an XCD-wide rendezvous, so that fragments are shared through the XCD's L2.  The
-// sharing works (L2 hit rate 26 % -> 68 %, fabric reads -58 %, profiles/r01/README.md) but buys nothing: the fp32
-// kernel is bound by the matrix pipe (2438 vs 2413 ms) and the fp16 candidate kernel by the latency of a stage's slowest
-// line, which a 68 % hit rate does not shorten, while 3.4x more partial-list slots cost more (454 vs 413 ms).
-static int hb_gcd(int x, int y) { while (y) { int t = x % y; x = y; y = t; } return x; }
-
-int hb_default_panel(int nqt, int G, size_t tile_bytes, int cq, int cb) {
-    // smallest panel for which the work of a panel divides evenly: nqt * panel pairs over G workgroups, or, with
-    // clusters, ceil(nqt / cq) * (panel / cb) units over G / (cq cb) clusters
-    int p0;
-    if (cq * cb > 1) {
-        const int NC = std::max(1, G / (cq * cb)), NQG = (nqt + cq - 1) / cq;
-        p0 = cb * (NC / hb_gcd(NQG, NC));
-    } else p0 = G / hb_gcd(nqt, G);
-    size_t budget = (size_t)96 << 20;
-    int j = (int)std::max<size_t>(1, budget / (tile_bytes * (size_t)p0));
-    return p0 * j;
-}
-
-// L2-sharing clusters: cq x cb workgroups of ONE XCD walk the same unit list in lockstep -- a unit is (cq query tiles)
-// x (cb consecutive bank tiles), member (ia, ib) takes the pair (query tile ia, bank tile ib) -- so that at any time the
-// cq members with the same ib stream the same bank tile and the cb members with the same ia the same query tile: one L2
-// fill serves cq (bank) or cb (query) consumers, fabric traffic per pair drops from Q + B to Q / cb + B / cq.  The
-// members hold each other within a few stages through the progress words (soft sync in the kernels); placement and
-// lockstep are speed only, any schedule gives the same result.
-void hb_default_cluster(int nqt, int nbt, int G, bool fp32_kernel, int* cq, int* cb) {
-    // The first shape whose ragged last group idles at most 2.5 % of the pairs (fp16 kernel: 1 / 16 -- 49 query tiles run 6 % faster as
-    // 4 x 2 with three idle members than as 2 x 2).  fp16 candidate kernel: 8 x 1 (eight
-    // workgroups stream the same bank tiles: measured best at 10 M x 768), else 4 x 2, else 2 x 2, else none.  fp32 kernel
-    // (bound by the matrix pipe, so only the cheapest sharing pays): 2 x 4, else 2 x 2 -- at 10 M x 768 fabric reads
-    // 4.79 -> 1.93 TB for +0.5 % time; 4 x 2 and 8 x 1 cost 3 %.
-    *cq = 1; *cb = 1;
-    if ((long long)nqt * nbt < 64LL * G) return;                 // enough work to share
-    static const int shapes16[3][2] = {{8, 1}, {4, 2}, {2, 2}};
-    static const int shapes32[3][2] = {{2, 4}, {2, 2}, {2, 2}};
-    for (const auto& sh : fp32_kernel ? shapes32 : shapes16) {
-        const int q = sh[0], b = sh[1];
-        if (G % (8 * q * b) != 0 || nqt < q) continue;
-        const int padded = (nqt + q - 1) / q * q;
-        if ((padded - nqt) * (fp32_kernel ? 40 : 16) > padded) continue;
-        *cq = q; *cb = b;
-        return;
-    }
-}
-
-static void hb_finish_schedule(hb_schedule& out, std::vector<std::vector<hb_seg>>& per_wg, const std::vector<int>& logical_of_block,
-                               const std::vector<std::vector<int>>& slots_of_qt) {
-    const int G = out.G;
-    // Phased searches (hb_build_schedule): every workgroup's segment list is cut at the same CLOCK values (tiles dealt), so that all
-    // workgroups work in every phase and the members of a cluster stay on their common clock; a segment that straddles a cut is
-    // split (same slot, the second piece continues it)
-    const int n_cuts = (int)out.phase_clock.size();
-    std::vector<std::vector<int>> rel(n_cuts, std::vector<int>(G, 0));   // per cut and logical workgroup: index of the first segment at or beyond it
-    if (n_cuts) {
-        for (int w = 0; w < G; ++w) {
-            std::vector<hb_seg> v;
-            v.reserve(per_wg[w].size() + n_cuts);
-            for (hb_seg sg : per_wg[w]) {
-                for (int t : out.phase_clock)
-                    if (t > sg.tile0 && t < sg.tile0 + sg.n_tiles) {
-                        hb_seg head = sg;
-                        head.n_tiles = t - sg.tile0;
-                        v.push_back(head);
-                        sg.b_tile0 += sg.stride * head.n_tiles; sg.tile0 = t; sg.n_tiles -= head.n_tiles; sg.first = 0;
-                    }
-                v.push_back(sg);
-            }
-            per_wg[w].swap(v);
-            for (int p = 0; p < n_cuts; ++p) {
-                int i = 0;
-                while (i < (int)per_wg[w].size() && per_wg[w][i].tile0 < out.phase_clock[p]) ++i;
-                rel[p][w] = i;
-            }
-        }
-    }
-    std::map<int, std::pair<int, int>> ord_of;   // slot -> (ordinal among its query tile's slots, their number)
-    for (const auto& sl : slots_of_qt)
-        for (size_t i = 0; i < sl.size(); ++i) ord_of[sl[i]] = {(int)i, (int)sl.size()};
-    for (auto& v : per_wg)
-        for (size_t i = 0; i < v.size(); ++i) {
-            v[i].next_tile0 = i + 1 < v.size() ? v[i + 1].tile0 : 0x7FFFFFFF;
-            v[i].ord = ord_of[v[i].slot].first; v[i].nsl = ord_of[v[i].slot].second;
-        }
-    out.wg_off.assign(G + 1, 0);
-    out.phase_bounds.assign((size_t)n_cuts * G, 0);
-    for (int b = 0; b < G; ++b) {
-        const int w = logical_of_block[b];
-        out.wg_off[b + 1] = out.wg_off[b] + (int)per_wg[w].size();
-        out.segs.insert(out.segs.end(), per_wg[w].begin(), per_wg[w].end());
-        for (int p = 0; p < n_cuts; ++p) out.phase_bounds[(size_t)p * G + b] = out.wg_off[b] + rel[p][w];
-    }
-    out.qt_off.assign(out.nqt + 1, 0);
-    for (int q = 0; q < out.nqt; ++q) {
-        out.qt_off[q + 1] = out.qt_off[q] + (int)slots_of_qt[q].size();
-        out.qt_slots.insert(out.qt_slots.end(), slots_of_qt[q].begin(), slots_of_qt[q].end());
-        out.max_slots_per_qt = std::max(out.max_slots_per_qt, (int)slots_of_qt[q].size());
-    }
-}
-
-static void hb_build_clustered(int nqt, int nbt, int G, int panel, int cq, int cb, hb_schedule& out, bool xcd_share) {
-    const int CS = cq * cb, NC = G / CS, NQG = (nqt + cq - 1) / cq;
-    out.cq = cq; out.cb = cb; out.n_clusters = NC; out.xcd_share = xcd_share;
-    std::vector<std::vector<hb_seg>> per_wg(G);   // logical workgroup = cluster * CS + member
-    std::map<std::pair<int, int>, int> slot_of;   // (logical wg, q_tile) -> slot
-    std::vector<std::vector<int>> slots_of_qt(nqt);
-    std::vector<int> clock(NC, 0);                // cluster clock: tiles each member has been dealt (idle ones included)
-    // units [qg][j0, j0 + cnt) of the panel at bank tile b0 (pp tiles) -> the members of cluster c
-    auto deal = [&](int c, int b0, int pp, int qg, int j0, int cnt) {
-        for (int m = 0; m < CS; ++m) {
-            const int ia = m / cb, ib = m % cb, q = qg * cq + ia, w = c * CS + m;
-            int n = cnt;
-            if ((j0 + cnt - 1) * cb + ib >= pp) --n;      // the partial last group has no tile for this member
-            if (q >= nqt || n <= 0) continue;             // idle for these units (its clock still advances)
-            hb_seg sg;
-            sg.q_tile = q; sg.b_tile0 = b0 + j0 * cb + ib; sg.n_tiles = n; sg.stride = cb; sg.tile0 = clock[c]; sg.next_tile0 = 0;
-            auto key = std::make_pair(w, q);
-            auto it = slot_of.find(key);
-            if (it == slot_of.end()) {
-                sg.slot = out.n_slots++; sg.first = 1;
-                slot_of[key] = sg.slot;
-                slots_of_qt[q].push_back(sg.slot);
-            } else { sg.slot = it->second; sg.first = 0; }
-            per_wg[w].push_back(sg);
-        }
-        clock[c] += cnt;
-    };
-    const int per_xcd_c = NC / 8;
-    int rot = 0;
-    for (int b0 = 0; b0 < nbt; b0 += panel) {
-        const int pp = std::min(panel, nbt - b0);
-        const int UB = (pp + cb - 1) / cb;        // bank groups of the panel (the last one may be partial)
-        const long long U = (long long)NQG * UB;
-        if (xcd_share) {
-            // XCD-level sharing of the QUERY tiles: the q-major unit list is cut into eight ranges, one per XCD, and every run of
-            // one query group inside a range is split over ALL clusters of that XCD (contiguous bank sub-ranges), so that at any
-            // time the XCD's workgroups re-read the same cq query tiles -- which then stay in its L2 (cq x 384 KiB of fp16 at
-            // D = 768 beside the bank streams) instead of being re-streamed through the fabric for every pair; the clusters among
-            // themselves need no sync for that.  The remainders of a run rotate over the clusters (balance within a tile or two).
-            for (int x = 0; x < 8; ++x) {
-                long long e = (U * x) / 8;
-                const long long e1 = (U * (x + 1)) / 8;
-                while (e < e1) {
-                    const int qg = (int)(e / UB), j0 = (int)(e % UB);
-                    const int L = (int)std::min<long long>(UB - j0, e1 - e);
-                    for (int i = 0; i < per_xcd_c; ++i) {
-                        const int a0 = (int)((long long)L * i / per_xcd_c), a1 = (int)((long long)L * (i + 1) / per_xcd_c);
-                        if (a1 > a0) deal(x * per_xcd_c + (i + rot) % per_xcd_c, b0, pp, qg, j0 + a0, a1 - a0);
-                    }
-                    ++rot;
-                    e += L;
-                }
-            }
-            continue;
-        }
-        for (int c = 0; c < NC; ++c) {
-            long long e0 = (U * c) / NC, e1 = (U * (c + 1)) / NC;
-            while (e0 < e1) {
-                const int qg = (int)(e0 / UB), j0 = (int)(e0 % UB);
-                const int cnt = (int)std::min<long long>(UB - j0, e1 - e0);
-                deal(c, b0, pp, qg, j0, cnt);
-                e0 += cnt;
-            }
-        }
-    }
-    // placement (speed only): blocks b, b + 8, ... share an XCD; every XCD gets NC / 8 consecutive clusters, whole
-    std::vector<int> logical_of_block(G);
-    out.wg_member.assign(G, -1);
-    const int per_xcd = NC / 8;
-    for (int c = 0; c < NC; ++c)
-        for (int m = 0; m < CS; ++m) {
-            const int block = c / per_xcd + 8 * ((c % per_xcd) * CS + m);
-            logical_of_block[block] = c * CS + m;
-            out.wg_member[block] = c * HB_CLUSTER_LINE + m;
-        }
-    hb_finish_schedule(out, per_wg, logical_of_block, slots_of_qt);
-}
-
-void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out, int cq, int cb, bool phased, bool xcd_share) {
-    out = hb_schedule();
-    out.nqt = nqt; out.nbt = nbt; out.panel = panel; out.phased = phased;
-    const long long total_pairs = (long long)nqt * nbt;
-    if (total_pairs < G) G = (int)std::max<long long>(1, total_pairs);
-    out.G = G;
-    if (phased) {
-        // Cut clocks (tiles dealt per workgroup): 1, 3, 6, 10, 16, 25, ... -- phases that grow by half, twofold beyond 128 tiles;
-        // the last phase keeps at least half of the work.  With the floor fixed during a phase, a phase that multiplies the rows seen
-        // by g appends about k (g - 1) candidates per query, k (g - 1) / ln g per e-fold: g = 2 is 1.44 x the continuous
-        // bound k ln(N / n0), g = 1.5 1.23 x.  Measured (kernel ms, 2,074,072 x 384 fp16): first cut at 1 / 2 / 4 / 8 tiles
-        // 23.6 / 24.0 / 24.0 / 24.4, growth 1.5 / 2 / 3 flat within 0.3; at 50,176 x 384 the first cut is what matters (fp32 k = 90:
-        // 7.85 with cuts from 2 tiles, 6.2 from 1).
-        // Short searches (at most 64 tiles per workgroup) grow threefold: every launch costs about 40 us beyond its tiles (cfg-1, fp32: 132 /
-        // 224 / 321 / 410 / 579 / 1983 us for 1 / 2 / 3 / 4 / 6 / 21.5 tiles per workgroup), four launches instead of six there: 3.78 -> 3.72 ms.
-        const long long per_wg_tiles = total_pairs / G;
-        long long t = 0, step = 1;
-        while (out.phase_clock.size() < HB_PHASE_CUTS) {
-            t += step;
-            if (t * 2 > per_wg_tiles) break;
-            out.phase_clock.push_back((int)t);
-            step = std::max<long long>(step + 1, per_wg_tiles <= 64 ? step * 3 : step < 128 ? step * 3 / 2 : step * 2);
-        }
-    }
-    if (cq < 1 || cb < 1 || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
-    if (cq * cb > 1) { hb_build_clustered(nqt, nbt, G, panel, cq, cb, out, xcd_share); return; }
-    std::vector<std::vector<hb_seg>> per_wg(G);
-    std::map<std::pair<int, int>, int> slot_of;   // (wg, q_tile) -> slot
-    std::vector<std::vector<int>> slots_of_qt(nqt);
-    std::vector<int> clock(G, 0);
-    for (int b0 = 0; b0 < nbt; b0 += panel) {
-        const int pp = std::min(panel, nbt - b0);
-        const long long W = (long long)nqt * pp;
-        for (int w = 0; w < G; ++w) {
-            long long e0 = (W * w) / G, e1 = (W * (w + 1)) / G;
-            while (e0 < e1) {
-                const int q = (int)(e0 / pp), b = (int)(e0 % pp);
-                const int cnt = (int)std::min<long long>(pp - b, e1 - e0);
-                auto key = std::make_pair(w, q);
-                auto it = slot_of.find(key);
-                hb_seg sg;
-                sg.q_tile = q; sg.b_tile0 = b0 + b; sg.n_tiles = cnt; sg.stride = 1; sg.tile0 = clock[w]; sg.next_tile0 = 0;
-                clock[w] += cnt;
-                if (it == slot_of.end()) {
-                    sg.slot = out.n_slots++; sg.first = 1;
-                    slot_of[key] = sg.slot;
-                    slots_of_qt[q].push_back(sg.slot);
-                } else { sg.slot = it->second; sg.first = 0; }
-                // coalesce with the previous segment when it continues the same slot contiguously
-                if (!per_wg[w].empty()) {
-                    hb_seg& pv = per_wg[w].back();
-                    if (pv.slot == sg.slot && pv.b_tile0 + pv.n_tiles == sg.b_tile0) { pv.n_tiles += cnt; e0 += cnt; continue; }
-                }
-                per_wg[w].push_back(sg);
-                e0 += cnt;
-            }
-        }
-    }
-    // XCD-aware placement (speed only, never correctness): hardware deals workgroups round-robin over the 8 XCDs
-    // (block b runs on XCD b % 8, checked with tools/ubench/xcc_map.hip; blocks b and b+8 share an L2), so logical
-    // ranges v = 0..G-1 -- neighbours share a query tile -- are laid out so that each XCD gets a contiguous run of
-    // them: block b runs logical range (b % 8) * (G / 8) + b / 8.
-    std::vector<int> logical_of_block(G);
-    for (int b = 0; b < G; ++b) {
-        if (G % 8 == 0) logical_of_block[b] = (b % 8) * (G / 8) + b / 8;
-        else {
-            const int q = G / 8, r = G % 8, x = b % 8;   // bijective variant for G not a multiple of 8
-            logical_of_block[b] = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
-        }
-    }
-    out.wg_member.assign(G, -1);
-    hb_finish_schedule(out, per_wg, logical_of_block, slots_of_qt);
-}
-
+// (the host-side work list -- hb_build_schedule and friends -- lives in hbird_schedule.cpp: plain C++, also built host-only under sanitizers)
 
 // Phased searches (pools: k > HB_KL and the fp16 candidate pass).  A pool's threshold is the k-th best of ONE slot's share of the rows
 // and only rises when the pool is compacted: with S slots per query tile every slot re-discovers what the others already know, and
@@ -747,62 +489,11 @@ __global__ __launch_bounds__(256) void pool_floor_kernel(const float* __restrict
                                                         unsigned* __restrict__ gthr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // (one query per wave: a launch of its own has all the parallelism it wants -- the two-queries-per-wave form that the kNN kernels run
+    // at the phase boundaries of a one-launch search, hbird_knn_dev.h: pool_floor_pair, measured 25 us per boundary SLOWER here)
     const int64_t q = (int64_t)blockIdx.x * 4 + w;
     if (q >= nq) return;
-    float* cs = reinterpret_cast<float*>(smem) + (size_t)w * per_wave;
-    const int qt = (int)(q / HB_QT), ql = (int)(q % HB_QT);
-    const int s0 = qt_off[qt], ns = qt_off[qt + 1] - s0;
-    float tstar = -INFINITY;
-    for (int j = lane; j < ns; j += 64) {
-        const size_t oq = (size_t)qt_slots[s0 + j] * HB_QT + ql;
-        if (cnts[oq] >= kk) tstar = fmaxf(tstar, pthr[oq]);
-    }
-    for (int o = 32; o > 0; o >>= 1) tstar = fmaxf(tstar, __shfl_xor(tstar, o));
-    int n = 0;
-    float hi = -INFINITY, mn = INFINITY;
-    for (int j = 0; j < ns; ++j) {
-        const size_t oq = (size_t)qt_slots[s0 + j] * HB_QT + ql;
-        const int valid = min(klw, cnts[oq]);
-        float vv[HB_POOL_MAX / 64];   // (all of the slot's scores in flight at once: knn_merge_kernel)
-#pragma unroll
-        for (int u = 0; u < HB_POOL_MAX / 64; ++u) {
-            const int e = u * 64 + lane;
-            vv[u] = e < valid ? state_s[oq * klw + e] : -INFINITY;
-        }
-#pragma unroll
-        for (int u = 0; u < HB_POOL_MAX / 64; ++u) {
-            if (u * 64 >= valid) break;
-            const int e = u * 64 + lane;
-            const float v = vv[u];
-            const bool keep = e < valid && (v >= tstar || tstar == -INFINITY);
-            const unsigned long long m = __ballot(keep);
-            if (keep) { cs[n + __popcll(m & ((1ull << lane) - 1ull))] = v; hi = fmaxf(hi, v); mn = fminf(mn, v); }
-            n += __popcll(m);
-        }
-    }
-    if (n < kk) return;   // fewer than kk rows seen so far: no floor yet
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are visible to its lanes
-    __builtin_amdgcn_wave_barrier();
-    for (int o = 32; o > 0; o >>= 1) { hi = fmaxf(hi, __shfl_xor(hi, o)); mn = fminf(mn, __shfl_xor(mn, o)); }
-    hi = fminf(hi, 3.4028234664e38f);
-    float lo = mn - fmaxf(fabsf(mn) * 1e-6f, 1.2e-38f);   // all n exceed it (cold_start_threshold, hbird_knn_dev.h)
-    // the first 256 gathered scores in registers (usually all of them): a round is then compares and ballots only
-    const float r0 = lane < n ? cs[lane] : -INFINITY, r1 = 64 + lane < n ? cs[64 + lane] : -INFINITY;
-    const float r2 = 128 + lane < n ? cs[128 + lane] : -INFINITY, r3 = 192 + lane < n ? cs[192 + lane] : -INFINITY;
-    const bool stretched = !(hi - mn <= 1e30f);   // an astronomically large score: halve the interval of the monotone keys (cold_start_threshold)
-    for (int it = 0; it < 14; ++it) {
-        float mid = 0.5f * lo + 0.5f * hi;
-        if (stretched) {
-            const unsigned klo = pool_key(lo), khi = pool_key(hi);
-            unsigned km = klo + ((khi - klo) >> 1);
-            if (km == 0x7FFFFFFFu) km = 0x7FFFFFFEu;
-            mid = __builtin_bit_cast(float, (km & 0x80000000u) ? (km ^ 0x80000000u) : ~km);
-        }
-        int c = __popcll(__ballot(r0 > mid)) + __popcll(__ballot(r1 > mid)) + __popcll(__ballot(r2 > mid)) + __popcll(__ballot(r3 > mid));
-        for (int base = 256; base < n; base += 64) c += __popcll(__ballot(base + lane < n && cs[base + lane] > mid));
-        if (c >= kk) lo = mid; else hi = mid;
-    }
-    if (lane == 0 && lo > -INFINITY) atomicMax(gthr + q, pool_key(lo));   // kk rows exceed lo
+    pool_floor_query(state_s, cnts, pthr, qt_off, qt_slots, q, kk, klw, reinterpret_cast<float*>(smem) + (size_t)w * per_wave, gthr, lane);
 }
 
 // q_tiles / q_aux must already be prepared by the caller (hb_index_search).
@@ -908,7 +599,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // L2-sharing clusters (hb_index_set_cluster; automatic shapes below): q x b workgroups of one XCD walk the same bank /
     // query tiles within `lag` stages of each other, so one L2 fill serves several.  Neither kernel is bound by the fabric
     // (the fp32 one by the matrix pipe, the fp16 candidate kernel by its LDS-DMA copies and the power the chip grants it:
-    // DESIGN.md, profiles/r02), so what they buy is traffic, and time only for the fp16 kernel (-8 %).  The 4-wave variant
+    // profiles/LABBOOK.md, profiles/r02), so what they buy is traffic, and time only for the fp16 kernel (-8 %).  The 4-wave variant
     // does not know strided segments.
     int cq = 1, cb = 1;
     if (ix->force_cq > 0 && ix->force_cb > 0) { cq = ix->force_cq; cb = ix->force_cb; }
@@ -965,9 +656,11 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     const size_t state_aux = wide ? (size_t)sc.n_slots * HB_QT * 4 : 0;   // pools: fill counts + thresholds
     const size_t floor_bytes = (size_t)nqt * HB_QT * 4 * 17;              // shared threshold floors, one per query, + 16 quota-floor keys per query
     const size_t prog_bytes = ((size_t)std::max(1, sc.n_clusters) * HB_CLUSTER_MAX + 1) * HB_CLUSTER_LINE * 4;   // progress words, a line each, + statistics
-    if (ensure_bytes(&ix->state, &ix->state_bytes, 2 * state_half + 2 * state_aux + floor_bytes + prog_bytes)) return -1;
+    const size_t gb_bytes = ((size_t)HB_GB_WORDS(sc.G) + (size_t)HB_PHASE_CUTS * 4 * sc.G) * 4;   // grid-barrier words of a one-launch search (zeroed per search) + time stamps (diagnostics)
+    if (ensure_bytes(&ix->state, &ix->state_bytes, 2 * state_half + 2 * state_aux + floor_bytes + prog_bytes + gb_bytes)) return -1;
 
     knn_args a;
+    memset(&a.ol, 0, sizeof(a.ol));
     a.bank_tiles = ix->tiles; a.binit = ix->binit; a.q_tiles = ix->q_tiles;
     a.segs = reinterpret_cast<const hb_seg*>(ix->sched_dev);
     a.wg_off = reinterpret_cast<const int*>(ix->sched_dev + o_wg);
@@ -1020,6 +713,37 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         HB_HIP(hipGetLastError());
         return 0;
     };
+    // ONE launch for all phases (hbird_knn_dev.h, "One launch per phased search"; hb_index_set_one_launch(ix, 2, ...)): the kernels with
+    // register-resident query fragments and the fp16 candidate kernel, every workgroup resident (one per CU), a query tile's pools within
+    // the LDS that is free between two phases.  The completion launch behind it costs about 2 us when nothing went wrong.
+    // OPT-IN, not the default: what a launch per phase costs beyond its tiles is the arrival skew of the workgroups at the phase's end
+    // (10-60 us: they wait for the slowest either way, at a grid barrier as at a kernel's tail) and the floor computation (25-30 us as a
+    // launch of its own with 28 waves per CU, 36-48 us inside a kernel that has eight), not the launches (about 2 us each).  Same box,
+    // whole searches, a launch per phase / one launch: 50,176 x 384 fp32 3.81 / 3.99 ms, use_fp16 1.36 / 1.50; 300,000 x 768 use_fp16 6.57 /
+    // 6.88; 2,074,072 x 384 use_fp16 20.1 / 20.7 (profiles/r05/one_launch_*.txt).
+    hb_one_launch ol;
+    memset(&ol, 0, sizeof(ol));
+    ix->ol_words_dev = nullptr; ix->ol_last_phases = n_phases;
+    {
+        const size_t per_wave = (size_t)sc.max_slots_per_qt * klw;
+        const bool kernel_ok = f16 || (bd_shape && (ix->variant == 0 || ix->variant == 3 || ix->variant == 6));
+        const size_t lds_free = f16 ? (size_t)hb_knn_f16_floor_lds_bytes() : (size_t)hb_knn_bd_floor_lds_bytes();
+        if (wide && n_phases > 1 && ix->one_launch == 2 && kernel_ok && sc.G <= ix->num_cu && sc.max_slots_per_qt <= 32 &&
+            2 * per_wave * 4 * HB_WAVES <= lds_free && nq < (1ll << 31)) {
+            ol.gb = reinterpret_cast<unsigned*>(ix->state + 2 * state_half + 2 * state_aux + floor_bytes + prog_bytes);
+            ol.phase_bounds = pb;
+            ol.qt_off = reinterpret_cast<const int*>(ix->sched_dev + o_qo);
+            ol.qt_slots = reinterpret_cast<const int*>(ix->sched_dev + o_qs);
+            ol.n_phases = n_phases; ol.G = sc.G; ol.nq = (int)nq; ol.per_wave = (int)per_wave;
+            // a barrier waits for the slowest workgroup of a phase: never longer than the whole search at a third of the fp32 rate
+            const double est_ms = 2.0 * (double)nq * (double)ix->ntotal * (double)ix->d / 47e12 * 1e3;
+            const double to_us = ix->ol_timeout_us > 0 ? (double)ix->ol_timeout_us : 20000.0 + 2000.0 * est_ms;
+            ol.timeout = (unsigned)std::min(4.0e9, to_us * 100.0);          // ticks of the 100 MHz real-time counter
+            ol.inject = ix->ol_inject;
+            HB_HIP(hipMemsetAsync(ol.gb, 0, gb_bytes, s));
+            ix->ol_words_dev = ol.gb;
+        }
+    }
     if (f16) {
         // fp16 copy of the query fragment tiles (the bank's is up to date: top of this function)
         const int64_t nqp = (int64_t)nqt * HB_QT;
@@ -1029,6 +753,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         int64_t* cand_idx = reinterpret_cast<int64_t*>(ix->cand);
         float* cand_dist = reinterpret_cast<float*>(ix->cand + (size_t)nq * kc * 8);
         knn16_args h;
+        memset(&h.ol, 0, sizeof(h.ol));
         h.bank16 = reinterpret_cast<const _Float16*>(ix->tiles16); h.binit = ix->binit; h.q16 = reinterpret_cast<const _Float16*>(ix->q16); h.segs = a.segs; h.wg_off = a.wg_off; h.wg_end = a.wg_end;
         h.state_s = a.state_s; h.state_i = a.state_i; h.g16 = ix->dp16 / 16; h.k = kc; h.klw = klw;
         h.state_cnt = a.state_cnt; h.state_thr = a.state_thr; h.gthr = a.gthr;
@@ -1038,6 +763,12 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
             HB_HIP(hipMemsetAsync(a.state_cnt, 0, state_aux, s));
             HB_HIP(hipMemsetD32Async((hipDeviceptr_t)a.state_thr, 0xFF800000u, state_aux / 4, s));
         }
+        h.ol = ol;
+        if (ol.gb) {      // all phases in one launch, then the completion launch (a no-op unless a barrier was given up)
+            if (hb_knn_f16_launch(h, sc.G, s)) return -1;
+            h.ol.resume = 1;
+            if (hb_knn_f16_launch(h, sc.G, s)) return -1;
+        } else
         for (int ph = 0; ph < n_phases; ++ph) {
             h.wg_off = phase_begin(ph); h.wg_end = phase_end(ph);
             if (hb_knn_f16_launch(h, sc.G, s)) return -1;
@@ -1126,7 +857,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // fp32 MFMA peak), same bits.  Default for the big LDS-list searches whose stage count per tile is a multiple of four
     // (D = 384, 768, 1024, ...); variant 3 forces it wherever it applies (tests), variant 4 keeps the LDS-staged kernel.
     if (bd_shape && (ix->variant == 0 || ix->variant == 3 || ix->variant == 6)) {
-        fn = hb_knn_bd_kernel(wide, a.cl > 1, small);
+        fn = hb_knn_bd_kernel(wide, a.cl > 1, small, ol.gb != nullptr);
         lds_bytes = hb_knn_bd_lds_bytes(small && !wide);
     }
     if (hb_ensure_dyn_lds((const void*)fn, lds_bytes)) return -1;   // per (kernel, device)
@@ -1135,6 +866,14 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         HB_HIP(hipMemsetAsync(a.state_cnt, 0, state_aux, s));
         HB_HIP(hipMemsetD32Async((hipDeviceptr_t)a.state_thr, 0xFF800000u, state_aux / 4, s));
     }
+    a.ol = ol;
+    if (ol.gb) {      // all phases in one launch, then the completion launch (a no-op unless a barrier was given up)
+        fn<<<dim3((unsigned)sc.G), dim3(threads), lds_bytes, s>>>(a);
+        HB_HIP(hipGetLastError());
+        a.ol.resume = 1;
+        fn<<<dim3((unsigned)sc.G), dim3(threads), lds_bytes, s>>>(a);
+        HB_HIP(hipGetLastError());
+    } else
     for (int ph = 0; ph < n_phases; ++ph) {
         a.wg_off = phase_begin(ph); a.wg_end = phase_end(ph);
         fn<<<dim3((unsigned)sc.G), dim3(threads), lds_bytes, s>>>(a);

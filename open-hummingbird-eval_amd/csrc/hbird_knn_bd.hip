@@ -34,7 +34,7 @@
                  : "+v"(B) : "s"(w) : "memory", "scc");
 // (Rounds 2 / 3 carried timing-only ablation builds of this loop -- no bank copies / no query-fragment loads / no epilogue / no
 // fragment reads -- and placement experiments -- every wave copying its own row tile, static wave priorities, the requests in the Y
-// half, floors requested at a tile's start: their numbers are in DESIGN.md section 4 and profiles/r02, the switches are gone.)
+// half, floors requested at a tile's start: their numbers are in profiles/LABBOOK.md section 4 and profiles/r02, the switches are gone.)
 #define BD_BLOAD(B) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(B) : "v"(lane_off), "s"(qfp) : "memory");
 // one 1 KiB LDS-DMA piece in the saddr form: wave-uniform 64-bit base + 32-bit lane offset -> LDS (wave-uniform address in M0 + 16 * lane);
 // the builtin takes a per-lane flat address (a 64-bit VALU add per piece).  M0 is clobbered on purpose (hbird_knn_f16.hip: F2_DMA)
@@ -45,7 +45,10 @@
 // WIDE: k > HB_KL, candidate pools in global memory; CL: member of an L2-sharing cluster (strided segments on a common
 // clock, soft sync from wave 0); COLD: small search (radix-select cold start, scan epilogue, per-tile floors) -- all as in
 // hbird_knn.hip
-template <bool WIDE, bool CL, bool COLD = false>
+// OL: the instantiation that can run all phases of a pool search in one launch (hbird_knn_dev.h, "One launch per phased search") -- its own
+// instantiation, so that the others keep their register allocation (a call on the boundary path costs the stage loop four reloads of spilled
+// scalars: +0.4 % at k = 90, 5 M x 768)
+template <bool WIDE, bool CL, bool COLD = false, bool OL = false>
 __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -65,7 +68,11 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
     cl_sync cs;
     if constexpr (CL) cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + BD_CLWORDS);
 
-    const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_end[blockIdx.x];   // this launch's share of the block's segments (phases: hb_launch_knn)
+    [[maybe_unused]] int ol_ph = 0;   // OL: the phase being run
+    if constexpr (OL) { if (!ol_enter<knn_args>(ol_ph)) return; }
+  for (;;) {
+    int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_end[blockIdx.x];   // this launch's share of the block's segments (phases: hb_launch_knn)
+    if constexpr (OL) ol_range<knn_args>(ol_ph, HB_KARG(knn_args, wg_off), HB_KARG(knn_args, wg_end), seg_begin, seg_end);
     // "everything before my first segment is done" (a member without any work: everything)
     if constexpr (CL) { if (w == 0) cl_publish(cs, seg_begin < seg_end ? a.segs[seg_begin].tile0 * g8 : 0x7FFFFFFF, lane); }
     for (int si = seg_begin; si < seg_end; ++si) {
@@ -212,11 +219,11 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
                     if constexpr (COLD) {
                         // small searches: a slot sees few rows, so its first tiles and its appends are a visible share -- cold start,
                         // then the fp16 candidate kernel's epilogue (register queue, one drain per tile; hbird_knn_dev.h)
-                        if (sp_->first && bt == sp_->b_tile0) thr = fmaxf(thr, cold_start_threshold(acc, k));
+                        if (sp_->first && bt == sp_->b_tile0 && cold_start_needed(thr)) thr = fmaxf(thr, cold_start_threshold(acc, k));
                         pool_epilogue_scan<HB_POOL_MAX / 64>(acc, thr, ps, pi, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt, bulk);
                     } else tile_epilogue<true, true>(acc, thr, ps, pi, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
                 } else if constexpr (COLD) {
-                    if (seg.first && bt == seg.b_tile0) thr = fmaxf(thr, cold_start_threshold(acc, k));
+                    if (seg.first && bt == seg.b_tile0 && cold_start_needed(thr)) thr = fmaxf(thr, cold_start_threshold(acc, k));
                     // the floors requested at the tile's start (waves 4-7: behind their query fragments; waves 0-3 have passed
                     // counted waits that cover them)
                     asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 .Lbfl_%=\n\ts_waitcnt vmcnt(0)\n.Lbfl_%=:" :: "s"(w) : "memory", "scc");
@@ -245,12 +252,20 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // the ring and the lists are reused by the next segment
     }
+    if constexpr (OL) { if (ol_boundary<knn_args>(ol_ph, smem, w, lane)) continue; }
+    break;
+  }
     if constexpr (CL) cl_finish(cs, a.cl_stats, w == 0, lane);
 }
 
-hb_knn_fn hb_knn_bd_kernel(bool wide, bool clustered, bool small) {
+hb_knn_fn hb_knn_bd_kernel(bool wide, bool clustered, bool small, bool one_launch) {
+    if (one_launch && wide) {
+        if (small && !clustered) return knn_fused_bd_kernel<true, false, true, true>;
+        return clustered ? knn_fused_bd_kernel<true, true, false, true> : knn_fused_bd_kernel<true, false, false, true>;
+    }
     if (small && !clustered) return wide ? knn_fused_bd_kernel<true, false, true> : knn_fused_bd_kernel<false, false, true>;
     if (clustered) return wide ? knn_fused_bd_kernel<true, true> : knn_fused_bd_kernel<false, true>;
     return wide ? knn_fused_bd_kernel<true, false> : knn_fused_bd_kernel<false, false>;
 }
 int hb_knn_bd_lds_bytes(bool small_lists) { return small_lists ? BD_LDS_TOTAL_COLD : BD_LDS_TOTAL; }
+int hb_knn_bd_floor_lds_bytes() { return BD_CLWORDS; }   // what the floor computation of a one-launch search may use between two phases

@@ -42,13 +42,18 @@ __device__ __forceinline__ int k6_band_begin(float scale, int j, int S, int n) {
 // A wave holds 64 neighbouring pixels of one row: segmentation maps are piecewise constant, so the wave first groups equal (gt, pred)
 // pairs (leader election by ballot: usually one or two groups) and issues ONE 64-bit global atomic per group -- K7's per-pixel LDS
 // atomics serialise exactly there (64 lanes on one bin).
-#define K6_HASH_BITS 8
-#define K6_HASH (1 << K6_HASH_BITS)                  // entries of the fused kernel's (pair, count) table: 2 KiB of the staging area
+// Where the counts go (`hbits`): few classes (G x P bins within 16 KiB: C <= 64) -> a plain [G x P] histogram in LDS (hbits = 0), so that
+// noise-like maps -- every lane its own pair -- cost one LDS atomic per pixel; until round 5 they overflowed a 256-entry hash table and
+// sent 3.2 M same-bin global atomics through the L2 (0.26 ms at the cfg-2 batch against 0.09 for the two separate kernels).  More
+// classes -> a (pair, count) hash table of 2^hbits entries in the staging area (open addressing, four probes); a wave that still holds
+// more than 16 ungrouped pixels after its three leader rounds is looking at noise, where a table buys nothing (as many distinct pairs as
+// pixels): those lanes add to the matrix directly instead of probing a full table eight times each.
+#define K6_HIST_BYTES (16 * 1024)
 template <int K6_R>
 __global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* __restrict__ lh, int S, int C, int h, int w,
                                                               float sy, float sx, int chunks, int cmax,
                                                               int64_t* __restrict__ out, const int64_t* __restrict__ gt, int G, int P,
-                                                              int64_t ignore, int has_ignore, unsigned long long* __restrict__ conf) {
+                                                              int64_t ignore, int has_ignore, unsigned long long* __restrict__ conf, int hbits) {
     extern __shared__ __attribute__((aligned(16))) float k6_sm[];
     const int j = blockIdx.y / chunks, rc = blockIdx.y % chunks;
     const int64_t b = blockIdx.z;
@@ -120,22 +125,24 @@ __global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* __res
             if (r0 + r < r1) out[(b * h + (r0 + r)) * (int64_t)w + x] = arg[r];
     }
     if (conf) {
-        // counts go through a small per-workgroup table in LDS ((pair, count) entries, open addressing) and reach the matrix as ONE
-        // global atomic per distinct pair of the workgroup's <= 16 x 256 pixels: same-address global atomics from every wave would
-        // serialise at the L2 (uniform regions send most pixels to one bin), and a full [G, P] histogram (91 KB at C = 151) does not
-        // fit beside the staged source rows.  A pair that finds no slot in 8 probes (noise-like maps) adds to the matrix directly.
+        // counts go through LDS -- a plain histogram or a (pair, count) table, see above -- and reach the matrix as ONE global atomic per
+        // distinct pair of the workgroup's <= 16 x 256 pixels: same-address global atomics from every wave would serialise at the L2
+        // (uniform regions send most pixels to one bin)
         __syncthreads();                                    // the staging area is free now
+        const int bins = G * P, hsize = 1 << hbits;
         int* hkey = reinterpret_cast<int*>(k6_sm);
-        unsigned* hcnt = reinterpret_cast<unsigned*>(k6_sm) + K6_HASH;
-        for (int e = threadIdx.x; e < K6_HASH; e += blockDim.x) { hkey[e] = -1; hcnt[e] = 0u; }
+        unsigned* hcnt = hbits ? reinterpret_cast<unsigned*>(k6_sm) + hsize : reinterpret_cast<unsigned*>(k6_sm);
+        if (hbits) { for (int e = threadIdx.x; e < hsize; e += blockDim.x) { hkey[e] = -1; hcnt[e] = 0u; } }
+        else for (int e = threadIdx.x; e < bins; e += blockDim.x) hcnt[e] = 0u;
         __syncthreads();
         const int lane = threadIdx.x & 63;
         auto count = [&](int key, unsigned n) {
-            unsigned slot = ((unsigned)key * 2654435761u) >> (32 - K6_HASH_BITS);
-            for (int probe = 0; probe < 8; ++probe) {
+            if (!hbits) { atomicAdd(&hcnt[key], n); return; }
+            unsigned slot = ((unsigned)key * 2654435761u) >> (32 - hbits);
+            for (int probe = 0; probe < 4; ++probe) {
                 const int old = atomicCAS(&hkey[slot], -1, key);
                 if (old == -1 || old == key) { atomicAdd(&hcnt[slot], n); return; }
-                slot = (slot + 1) & (K6_HASH - 1);
+                slot = (slot + 1) & (hsize - 1);
             }
             atomicAdd(&conf[key], (unsigned long long)n);
         };
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* __res
             valid = valid && !(has_ignore && g == ignore) && g >= 0 && g < G && arg[r] < P;
             const int key = valid ? (int)g * P + arg[r] : -1;
             // a wave's 64 neighbouring pixels of one row mostly share one or two pairs: up to three groups are counted by their
-            // leaders, whatever is left (noise) lane by lane
+            // leaders, whatever is left lane by lane
             unsigned long long todo = __ballot(valid);
 #pragma unroll 1
             for (int round = 0; round < 3 && todo; ++round) {
@@ -157,11 +164,18 @@ __global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* __res
                 if (lane == leader) count(k0, (unsigned)__popcll(same));
                 todo &= ~same;
             }
-            if ((todo >> lane) & 1ull) count(key, 1u);
+            if ((todo >> lane) & 1ull) {
+                if (hbits && __popcll(todo) > 16) atomicAdd(&conf[key], 1ull);     // noise: no reuse to collect
+                else count(key, 1u);
+            }
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < K6_HASH; e += blockDim.x)
-            if (hkey[e] >= 0 && hcnt[e]) atomicAdd(&conf[hkey[e]], (unsigned long long)hcnt[e]);
+        if (hbits) {
+            for (int e = threadIdx.x; e < hsize; e += blockDim.x)
+                if (hkey[e] >= 0 && hcnt[e]) atomicAdd(&conf[hkey[e]], (unsigned long long)hcnt[e]);
+        } else
+            for (int e = threadIdx.x; e < bins; e += blockDim.x)
+                if (hcnt[e]) atomicAdd(&conf[e], (unsigned long long)hcnt[e]);
     }
 }
 
@@ -211,9 +225,22 @@ int hb_launch_upsample_argmax_confusion(const float* label_hat, int64_t B, int S
     // widest column window of a block, and the classes per LDS pass that keep it within 64 KiB
     const int ncols = std::min(S, (int)std::ceil((double)bw * S / w) + 2);
     const int cmax = std::max(1, std::min(C, (64 * 1024) / (2 * ncols * 4)));
-    const size_t lds = std::max<size_t>((size_t)2 * ncols * cmax * 4, conf ? (size_t)K6_HASH * 8 : 0);
+    // the confusion counts' home in the (then free) staging area: a plain histogram where G x P bins fit 16 KiB, else a hash table of
+    // 256 or 512 (pair, count) entries
+    const size_t stage_bytes = (size_t)2 * ncols * cmax * 4;
+    int hbits = 0;
+    size_t table_bytes = 0;
+    if (conf) {
+        if ((size_t)num_gt * num_pred * 4 <= K6_HIST_BYTES) table_bytes = (size_t)num_gt * num_pred * 4;
+        else {
+            hbits = 8;
+            while (hbits < 9 && ((size_t)8 << (hbits + 1)) <= stage_bytes) ++hbits;     // (2048 entries: their per-block init + flush cost more than they catch, 0.175 -> 0.200 ms at cfg-3)
+            table_bytes = (size_t)8 << hbits;
+        }
+    }
+    const size_t lds = std::max<size_t>(stage_bytes, table_bytes);
     const dim3 grid((unsigned)blocks_x, (unsigned)(S * chunks), (unsigned)B);
-#define K6_LAUNCH(RR) upsample_argmax_kernel<RR><<<grid, dim3(bw), lds, s>>>(label_hat, S, C, h, w, sy, sx, chunks, cmax, out, gt, num_gt, num_pred, ignore, has_ignore, conf)
+#define K6_LAUNCH(RR) upsample_argmax_kernel<RR><<<grid, dim3(bw), lds, s>>>(label_hat, S, C, h, w, sy, sx, chunks, cmax, out, gt, num_gt, num_pred, ignore, has_ignore, conf, hbits)
     switch (R) {
         case 8: K6_LAUNCH(8); break;
         case 10: K6_LAUNCH(10); break;

@@ -83,6 +83,9 @@ SIGNATURES = {
     "hb_index_cluster_stats": (c_int, [c_void_p, POINTER(c_int64)]),
     "hb_index_set_variant": (c_int, [c_void_p, c_int]),
     "hb_index_set_search_options": (c_int, [c_void_p, c_int, c_int64]),
+    "hb_index_set_one_launch": (c_int, [c_void_p, c_int, c_int64, c_int]),
+    "hb_index_one_launch_stats": (c_int, [c_void_p, POINTER(c_int64)]),
+    "hb_index_one_launch_trace": (c_int, [c_void_p, c_void_p, c_int64, POINTER(c_int), POINTER(c_int)]),
     "hb_index_set_rerank_copy": (c_int, [c_void_p, c_int]),
     "hb_index_rerank_copy_bytes": (c_int, [c_void_p, POINTER(c_int64)]),
     "hb_index_schedule_info": (c_int, [c_void_p, POINTER(c_int64)]),
@@ -106,7 +109,12 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "
                 f"g.build()' or make -C {CSRC_DIR}). There is no CPU fallback.")
         L = ctypes.CDLL(LIB_PATH)
+        # HBIRD_PLAN_ONLY=1 (tests/test_sanitizers_cpu.py): LIB_PATH names the host-only sanitizer build of the work-list planner,
+        # which exports the hb_schedule_plan* entry points and hb_last_error only
+        plan_only = os.environ.get("HBIRD_PLAN_ONLY") == "1"
         for name, (res, args) in SIGNATURES.items():
+            if plan_only and not (name.startswith("hb_schedule_plan") or name == "hb_last_error"):
+                continue
             fn = getattr(L, name)  # AttributeError here = header and library disagree
             fn.restype = res
             fn.argtypes = args

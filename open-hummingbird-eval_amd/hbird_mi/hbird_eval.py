@@ -179,6 +179,32 @@ class HbirdEvaluation:
             torch.cuda.synchronize(self.gpu_device)
         self.bank_build_s = _time.perf_counter() - t0
 
+    @classmethod
+    def from_index(cls, feature_extractor: torch.nn.Module, index, num_classes: int, n_neighbours: int = 30,
+                   device: torch.device | str = "cuda") -> "HbirdEvaluation":
+        """An evaluator over a bank that is already resident in a `HipFlatIndex` (rows + label rows added by the caller): `evaluate` runs
+        as usual, nothing is built.  Not in the reference (its bank only ever comes from `_create_memory`); used by `bench.py --e2e` to time
+        the evaluation loop against the synthetic 10 M-row bank, and handy for banks produced elsewhere."""
+        self = cls.__new__(cls)
+        self.nn_params, self.device, self.nn_method = {}, device, "hip"
+        dev = torch.device(device)
+        self.gpu = dev.index if dev.type == "cuda" and dev.index is not None else torch.cuda.current_device()
+        self.gpu_device = torch.device("cuda", self.gpu)
+        self.feature_extractor = feature_extractor.to(device).eval()
+        self.augmentation_epoch, self.memory_size, self.n_neighbours, self.num_classes = 1, None, n_neighbours, num_classes
+        self.f_mem_p = self.l_mem_p = None
+        self.num_sampled_features = None
+        self.rank, self.world = 0, 1
+        self.metric = index.metric
+        self.local_gpus = [self.gpu]
+        self.sharded = self.label_shard = False
+        self.compress_labels = True
+        self.index = index
+        self.index.set_num_classes(num_classes)
+        self.id_base, self.total_rows, self._label_table = 0, index.ntotal, None
+        self.bank_loaded, self.bank_build_s, self.batches_loaded = True, 0.0, 0
+        return self
+
     def _align_cpu_rng(self) -> None:
         """Sharded bank build: every rank replays the reference's single CPU random stream (the sampling noise of
         hbird_eval.py:500 is drawn for EVERY batch, owned or not), so all ranks must start from rank 0's state."""
@@ -507,18 +533,25 @@ class HbirdEvaluation:
                 # replica mode (idx_shard=False) under torch.distributed: validation batches are data-parallel, and a rank loads only its own
                 batches = (enumerate(val_loader) if self.world == 1
                            else hdist.rank_batches(val_loader, lambda i: i % self.world == self.rank))
-                for bi, (x, y) in tqdm(batches, desc="Evaluation loop"):
+                # the NEXT batch is fetched from the loader and copied to the GPU (side stream) while this one is searched; with
+                # `self.profile = True` every batch's stages are timed by events (stage_times() afterwards; bench.py --e2e)
+                prof = self._stage_profile = [] if getattr(self, "profile", False) else None
+                for bi, (x, y) in tqdm(self._prefetched(batches, window is None), desc="Evaluation loop"):
                     _, _, h, w = x.shape
+                    ev = self._mark(prof)                                           # batch on the GPU
                     y = (y.to(self.gpu_device) * 255).long()                       # 219 (255 is NOT remapped here)
                     if window is not None:
                         metric.update(y, self._windowed_cluster_map(x, S, window))
                         continue
                     feats = self._tokens(x)                                       # 217 (stays on the GPU)
+                    self._mark(prof, ev)                                            # ViT forward
                     label_hat, idx, _ = self._label_hat(feats, return_knn_details)  # 224-227
+                    self._mark(prof, ev)                                            # K4 + K5
                     if return_knn_details:
                         kf, kl = self._gather_details(idx, feats.shape[0], feats.shape[1])
                         knns.append(kf.cpu()); knns_labels.append(kl.cpu()); knns_ca_labels.append(label_hat.cpu())
                     metric.update_from_label_hat(y, label_hat, S)                   # 235-243 + 252: upsample + argmax + confusion counts, one kernel
+                    self._mark(prof, ev)                                            # K6 + K7
         jac, tp, fp, fn, _, _ = metric.compute(is_global_zero=True, sync_distributed=self.world > 1,
                                                return_reordered=False)            # 253
         if return_knn_details:
@@ -528,6 +561,82 @@ class HbirdEvaluation:
             return jac, details
         logger.info("Evaluation complete.")
         return jac
+
+    # -- batch prefetch + stage timing of the evaluation loop ---------------------------------------------------------------------
+    def _prefetched(self, batches, to_gpu: bool):
+        """(bi, (x, y)) of `batches`, one batch ahead: while the caller works on batch i, batch i + 1 is pulled from the loader (its
+        workers decode in the background anyway) and -- `to_gpu` -- copied to the GPU on a side stream from pinned memory, so that neither
+        the loader nor PCIe sits between two searches.  The host time spent waiting for the loader is kept in `loader_wait_s`."""
+        import time as _time
+        self.loader_wait_s = 0.0
+        self.h2d_ms = []
+        copy = torch.cuda.Stream(self.gpu_device) if to_gpu else None
+        main = torch.cuda.current_stream(self.gpu_device)
+
+        def stage(item):
+            bi, (x, y) = item
+            if copy is None or not isinstance(x, torch.Tensor) or x.is_cuda:
+                return bi, x, y, None, None
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(copy):
+                e0.record(copy)
+                xd = (x if x.is_pinned() else x.pin_memory()).to(self.gpu_device, non_blocking=True)
+                yd = (y if y.is_pinned() else y.pin_memory()).to(self.gpu_device, non_blocking=True) if isinstance(y, torch.Tensor) and not y.is_cuda else y
+                e1.record(copy)
+            return bi, xd, yd, e0, e1
+
+        it = iter(batches)
+
+        def pull():
+            t0 = _time.perf_counter()
+            try:
+                item = next(it)
+            except StopIteration:
+                item = None
+            self.loader_wait_s += _time.perf_counter() - t0
+            return None if item is None else stage(item)
+
+        nxt = pull()
+        while nxt is not None:
+            bi, x, y, e0, e1 = nxt
+            if e1 is not None:
+                main.wait_event(e1)
+                x.record_stream(main)
+                if isinstance(y, torch.Tensor) and y.is_cuda:
+                    y.record_stream(main)
+                self.h2d_ms.append((e0, e1))
+            nxt = pull()                    # enqueue the next batch's copy before this one's work is enqueued
+            yield bi, (x, y)
+
+    def _mark(self, prof, ev=None):
+        """Stage boundary of the profiled evaluation loop: one event on the current stream."""
+        if prof is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream(self.gpu_device))
+        if ev is None:
+            ev = [e]
+            prof.append(ev)
+        else:
+            ev.append(e)
+        return ev
+
+    def stage_times(self) -> Optional[Dict[str, float]]:
+        """After evaluate() with `self.profile = True`: mean ms per batch of the stages (GPU time between events on the evaluation stream),
+        of the prefetched H2D copies (side stream), and the host seconds spent waiting for the loader."""
+        prof = getattr(self, "_stage_profile", None)
+        if not prof:
+            return None
+        torch.cuda.synchronize(self.gpu_device)
+        rows = [[ev[i].elapsed_time(ev[i + 1]) for i in range(3)] for ev in prof if len(ev) == 4]
+        if not rows:
+            return None
+        n = len(rows)
+        out = {"batches": n, "vit_forward_ms": sum(r[0] for r in rows) / n, "knn_k5_ms": sum(r[1] for r in rows) / n,
+               "k6_k7_ms": sum(r[2] for r in rows) / n, "loader_wait_s_total": self.loader_wait_s}
+        if self.h2d_ms:
+            out["h2d_ms"] = sum(a.elapsed_time(b) for a, b in self.h2d_ms) / len(self.h2d_ms)
+        return out
 
     def _windowed_cluster_map(self, x: torch.Tensor, S: int, window: Tuple[int, int]) -> torch.Tensor:
         """Frames x [B,3,H,W] -> class map [B,1,H,W]: hot path per window, stitched on the device."""

@@ -278,6 +278,27 @@ class HipFlatIndex:
         """A/B switches (same results): pool searches in one launch instead of phases; the size below which a search is "small"."""
         _lib.check(_lib.lib().hb_index_set_search_options(self._h, int(bool(phases)), int(small_limit_stages)))
 
+    def set_one_launch(self, mode: int = 0, timeout_us: int = 0, inject: int = 0):
+        """Phased searches as ONE launch with grid barriers: mode 2 (opt-in: measured 2-10 % slower than a launch per phase, which modes
+        0 / 1 select); same results.  `inject` (tests): (kind << 28) | (phase << 16) | (block + 1) makes one block fail at one phase
+        boundary; 3 << 28 records per-workgroup time stamps (hb_index_set_one_launch)."""
+        _lib.check(_lib.lib().hb_index_set_one_launch(self._h, int(mode), int(timeout_us), int(inject)))
+
+    def one_launch_stats(self) -> dict:
+        out = (ctypes.c_int64 * 8)()
+        _lib.check(_lib.lib().hb_index_one_launch_stats(self._h, out))
+        keys = ["one_launch", "phases", "boundaries", "barrier1_ticks", "floor_ticks", "barrier2_ticks", "timeouts", "given_up"]
+        return dict(zip(keys, [int(v) for v in out]))
+
+    def one_launch_trace(self):
+        """After a search with set_one_launch(inject=3 << 28): int64 array [boundaries, 4, workgroups] of 100 MHz ticks (relative to the
+        earliest stamp): arrival at barrier 1, its pass, floors done, pass of barrier 2."""
+        buf = np.zeros(24 * 4 * 1024, dtype=np.uint32)
+        nb, g = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(_lib.lib().hb_index_one_launch_trace(self._h, _ptr(buf), buf.size, ctypes.byref(nb), ctypes.byref(g)))
+        t = buf[: nb.value * 4 * g.value].reshape(nb.value, 4, g.value).astype(np.int64)
+        return (t - t.min()) & 0xFFFFFFFF if t.size else t
+
     def set_rerank_copy(self, mode: int = 0):
         """use_fp16 searches: a second, row-major fp32 copy of the bank for the exact re-rank (speed only; 0 automatic -- made when the
         device keeps a third of its memory free --, 1 always, 2 never)."""
@@ -352,6 +373,17 @@ class HipMultiIndex:
         self.home = torch.device("cuda", self.device)
         self.indexes = [HipFlatIndex(d, metric, g) for g in self.devices]
         self.agg = HipFlatIndex(d, metric, self.device)        # row-less handle: aggregation against the home tables
+        # peer access between the home device and every other listed GPU (xGMI on one node): without it a cross-device copy is staged
+        # through pinned host memory explicitly -- one warning, same results
+        self._staged = set()
+        for g in sorted(set(self.devices)):
+            if g != self.device and torch.cuda.is_available() and not (torch.cuda.can_device_access_peer(self.device, g)
+                                                                         and torch.cuda.can_device_access_peer(g, self.device)):
+                self._staged.add(g)
+        if self._staged:
+            import warnings
+            warnings.warn(f"HipMultiIndex: no peer access between cuda:{self.device} and {sorted(self._staged)}: rows, queries and neighbour "
+                          "lists are staged through host memory (slower copies, same results)", RuntimeWarning, stacklevel=2)
         self._warned_no_plan = False
         self._label_P = 0               # > 0: label rows are kept as int16 counts j of values j / P (set_label_denominator)
         self._quota = None              # shard mode: planned rows per shard (reserve); None = everything into the first
@@ -438,12 +470,20 @@ class HipMultiIndex:
     def _on(self, i):
         return torch.cuda.device(torch.device("cuda", self.devices[i]))
 
+    def _move(self, t: torch.Tensor, dev: torch.device) -> torch.Tensor:
+        """t on `dev`: a peer copy (xGMI) where the two GPUs can reach each other, else staged through the host."""
+        if not t.is_cuda or t.device == dev:
+            return t.to(dev)
+        if t.device.index in self._staged or dev.index in self._staged:
+            return t.cpu().to(dev)             # (.cpu() synchronises the source stream; the upload is ordered on the destination's)
+        return t.to(dev)
+
     def _put(self, i, x, normalize):
         """Rows x (CUDA tensor on any device, CPU tensor or numpy) appended to index i on ITS device and stream."""
         ix = self.indexes[i]
         with self._on(i):
             if isinstance(x, torch.Tensor) and x.is_cuda and x.device.index != self.devices[i]:
-                x = x.to(torch.device("cuda", self.devices[i]))       # peer copy (xGMI), ordered by torch's streams
+                x = self._move(x, torch.device("cuda", self.devices[i]))   # peer copy (xGMI), ordered by torch's streams
             ix.use_current_stream()
             ix.add(x, normalize=normalize)
 
@@ -532,7 +572,7 @@ class HipMultiIndex:
                             ix.use_current_stream()
                             nr = ix.copy_norms()
                             torch.cuda.current_stream(nr.device).synchronize()
-                        parts.append(nr.to(self.home))
+                        parts.append(self._move(nr, self.home))
                     self._norms = torch.cat(parts) if parts else torch.zeros(0, device=self.home)
                 else:
                     with self._on(0):
@@ -577,16 +617,16 @@ class HipMultiIndex:
             index, dev = self.indexes[i], torch.device("cuda", self.devices[i])
             with torch.cuda.device(dev):
                 if self.shard:
-                    qi = q if dev == q.device else q.to(dev)
+                    qi = q if dev == q.device else self._move(q, dev)
                 else:
                     a, b = (nq * i) // n, (nq * (i + 1)) // n       # replicas: a slice of the queries each
-                    qi = q[a:b] if dev == q.device else q[a:b].to(dev)
+                    qi = q[a:b] if dev == q.device else self._move(q[a:b], dev)
                 index.use_current_stream()
                 # shards always return ordering scores: the merge must see what the single index orders by
                 idx, d = (index.search_scores if (self.shard or scores) else index.search)(qi.contiguous(), k, id_base + bases[i])
                 fb = index.last_fp16_fallbacks()
                 torch.cuda.current_stream(dev).synchronize()
-                idx, d = idx.to(self.home), d.to(self.home)         # peer copy of the [nq, k] lists (xGMI)
+                idx, d = self._move(idx, self.home), self._move(d, self.home)   # peer copy of the [nq, k] lists (xGMI)
                 # the copy was enqueued on THIS thread's current streams (torch runs a peer copy on the source device's stream and
                 # makes the destination's wait for it), the caller merges on its own: the lists must have landed before the
                 # worker hands them over
@@ -659,11 +699,11 @@ class HipMultiIndex:
                     continue
                 with self._on(i):
                     dev = torch.device("cuda", self.devices[i])
-                    mine = torch.where(own, ids_h, torch.full_like(ids_h, -1)).to(dev)
+                    mine = self._move(torch.where(own, ids_h, torch.full_like(ids_h, -1)), dev)
                     ix.use_current_stream()
                     part = ix.reconstruct(mine, lo)                 # rows of other shards (id -1) come back as zeros
                     torch.cuda.current_stream(dev).synchronize()
-                    part = part.to(self.home)
+                    part = self._move(part, self.home)
                     torch.cuda.current_stream(dev).synchronize()
                 out += part
         return out.cpu().numpy() if host else out

@@ -186,3 +186,50 @@ def test_cfg2_full_size_bank_oracle_on_a_query_sample(cuda_device):
     ix.set_fp16(True)
     idx16, dist16 = ix.search(q, k)
     assert torch.equal(idx16, idx) and torch.equal(dist16, dist)
+
+
+# ---- the widest published operating point: DINOv2 ViT-G/14, D = 1536 (reference README.md:327-334) ----------------------------------
+@pytest.mark.parametrize("metric,fp16,k", [("dot_product", False, 30), ("l2", False, 30), ("dot_product", True, 30), ("l2", True, 30),
+                                           ("dot_product", False, 90), ("dot_product", True, 90)])
+def test_vit_g14_width_1536_vs_oracle(cuda_device, metric, fp16, k):
+    M, D, nq = 30_000, 1536, 600
+    bank = gi.unit_bank(M, D, seed=61)
+    bank[25_000] = bank[9]                                   # an exact tie
+    q = gi.vit_like_queries(nq, D, seed=62)
+    nn = NearestNeighborSearchHIP(torch.from_numpy(bank), n_neighbors=k, distance_measure=metric, use_fp16=fp16, gpu_ids=[0])
+    idx, dist = nn.find_nearest_neighbors(torch.from_numpy(q))
+    _check_exact(idx, dist, q, bank, k, metric)
+    nn.index.set_fp16(1 if fp16 else 0)                      # the candidate pass itself (the plugin's mode 2 may decline a bank this small)
+    nn.index.set_tuning(11, 5)                               # several slots per query tile
+    idx, dist = nn.index.search(torch.from_numpy(q).cuda(), k)
+    _check_exact(idx, dist, q, bank, k, metric)
+    if fp16:
+        assert nn.index.last_fp16_fallbacks() < nq // 20
+
+
+def test_vit_g14_width_1536_two_million_rows(cuda_device):
+    """D = 1536 at a bank size the reference publishes for it (1024 x 10^3 x ... rows, README.md:327-334): planted neighbours, order, distinct
+    ids, determinism, 2-shard merge, use_fp16 == fp32 bits, the chain oracle on 32 queries against all rows, float64 on 16."""
+    _full_size_properties(2_000_000, 1536, 8 * 1369, [30], torch.device("cuda:0"), seed=66)
+
+
+# ---- k beyond the candidate pass (k' = 2k <= 256): use_fp16 is served by the fp32 kernel, as documented ------------------------------
+@pytest.mark.parametrize("k", [129, 200, 256])
+def test_use_fp16_beyond_k_128_is_the_fp32_search(cuda_device, k):
+    """include/hbird_hip.h: k <= HB_MAX_K = 256 (faiss-gpu: 2048); the fp16 candidate pass keeps k' = 2k <= 256 candidates, so a use_fp16 search
+    with k > 128 runs on the exact fp32 kernel: no fallback queries are counted, ids and distance bits are the chain oracle's."""
+    M, D, nq = 50_000, 256, 400
+    bank = gi.unit_bank(M, D, seed=71); q = gi.vit_like_queries(nq, D, seed=72)
+    ix = HipFlatIndex(D, 0, 0); ix.add(torch.from_numpy(bank).cuda())
+    i32, d32 = ix.search(torch.from_numpy(q).cuda(), k)
+    _check_exact(i32, d32, q, bank, k, "dot_product")
+    for mode in (1, 2):
+        ix.set_fp16(mode)
+        i16, d16 = ix.search(torch.from_numpy(q).cuda(), k)
+        assert ix.last_fp16_fallbacks() == 0
+        assert torch.equal(i16, i32) and torch.equal(d16.view(torch.int32), d32.view(torch.int32))
+    nn = NearestNeighborSearchHIP(torch.from_numpy(bank), n_neighbors=k, use_fp16=True, gpu_ids=[0])
+    i2, d2 = nn.find_nearest_neighbors(torch.from_numpy(q))
+    _check_exact(i2, d2, q, bank, k, "dot_product")
+    with pytest.raises(ValueError):
+        nn.find_nearest_neighbors(torch.from_numpy(q), k=257)

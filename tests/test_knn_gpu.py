@@ -634,20 +634,62 @@ def test_phased_and_unphased_pool_searches_return_the_same_bits(cuda_device):
     bit for bit, in all four."""
     bank = gi.unit_bank(70001, 64, seed=5); q = torch.from_numpy(gi.vit_like_queries(1301, 64, seed=6)).cuda()
     results = []
-    for setup in ("default", "unphased", "lists", "never_small"):
+    for setup in ("default", "one_launch", "unphased", "lists", "never_small"):
         out = []
         for k, fp16 in ((30, False), (90, False), (30, True)):
             ix = HipFlatIndex(64, 0, 0); ix.add(torch.from_numpy(bank).cuda()); ix.set_fp16(fp16)
-            if setup == "unphased":
+            if setup == "one_launch":
+                ix.set_one_launch(2)            # all phases in ONE launch with grid barriers, where the search qualifies (opt-in)
+            elif setup == "unphased":
                 ix.set_search_options(phases=False)
             elif setup == "lists":
                 ix.set_variant(6)
             elif setup == "never_small":
                 ix.set_search_options(small_limit_stages=1)
             out.append(ix.search(q, k))
+            st = ix.one_launch_stats()
+            # (six query tiles over 256 workgroups: 43 pools per query do not fit the LDS between two phases, so even mode 2 keeps a
+            # launch per phase here; test_one_launch_search_... below has shapes that qualify)
+            assert st["given_up"] == 0 and (setup == "one_launch" or st["one_launch"] == 0), st
         results.append(out)
     for other in results[1:]:
         for (i0, d0), (i1, d1) in zip(results[0], other):
             assert torch.equal(i0, i1) and torch.equal(d0.view(torch.int32), d1.view(torch.int32))
     with pytest.raises(RuntimeError):
         HipFlatIndex(8, 0, 0).set_search_options(small_limit_stages=-1)
+
+
+@pytest.mark.parametrize("fp16", [False, True])
+def test_one_launch_search_against_the_oracle_and_its_escape_paths(cuda_device, fp16):
+    """A phased search as ONE launch (grid barrier + in-kernel floors at every phase boundary): ids and distance bits of the chain oracle.
+    Then the ways out, all with the same bits: a block that raises the abort flag at a boundary (everyone leaves, the completion launch
+    finishes every block's list from its recorded phase), a block that leaves silently (the others run into their timeout -- a bounded
+    spin, 2 ms here -- and give up), both at the first and at a late boundary; and repeated searches (the barrier words are re-zeroed)."""
+    M, D, nq = 120_000, 128, 12_800
+    bank = gi.unit_bank(M, D, seed=15); qn = gi.vit_like_queries(nq, D, seed=16)
+    q = torch.from_numpy(qn).cuda()
+    for k in (30, 90):
+        ix = HipFlatIndex(D, 0, 0); ix.add(torch.from_numpy(bank).cuda()); ix.set_fp16(fp16)
+        ridx, rdist = oracle.knn_chain_f32(qn[:400], bank, k)
+        ip, dp = ix.search(q, k)                                            # the default: a launch per phase
+        assert ix.one_launch_stats()["one_launch"] == 0
+        ix.set_one_launch(2)
+        i0, d0 = ix.search(q, k)
+        assert torch.equal(i0, ip) and torch.equal(d0.view(torch.int32), dp.view(torch.int32))
+        st = ix.one_launch_stats()
+        assert st["one_launch"] == 1 and st["given_up"] == 0 and st["boundaries"] == st["phases"] - 1 >= 2, st
+        assert ix.last_fp16_fallbacks() == 0
+        assert np.array_equal(i0[:400].cpu().numpy(), ridx) and np.array_equal(d0[:400].cpu().numpy().view(np.uint32), rdist.view(np.uint32))
+        last = st["phases"] - 2
+        for kind, phase, block in ((1, 0, 7), (1, last, 200), (2, 0, 255), (2, last, 3), (1, 1, 0)):
+            ix.set_one_launch(2, timeout_us=2000, inject=(kind << 28) | (phase << 16) | (block + 1))
+            i1, d1 = ix.search(q, k)
+            st = ix.one_launch_stats()
+            assert st["one_launch"] == 1 and st["given_up"] == 1, (kind, phase, block, st)
+            assert (st["timeouts"] > 0) == (kind == 2), (kind, st)
+            assert torch.equal(i0, i1) and torch.equal(d0.view(torch.int32), d1.view(torch.int32)), (kind, phase, block)
+        ix.set_one_launch(2)
+        for _ in range(3):
+            i1, d1 = ix.search(q, k)
+            assert ix.one_launch_stats()["given_up"] == 0
+            assert torch.equal(i0, i1) and torch.equal(d0.view(torch.int32), d1.view(torch.int32))

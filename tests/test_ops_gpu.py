@@ -152,6 +152,58 @@ def test_label_table_as_counts_returns_the_fp32_bits(cuda_device, golden_dir, P,
         assert np.array_equal(e.gather_labels(np.arange(rows.shape[0])).view(np.uint32), rows.view(np.uint32))
 
 
+def test_count_quotients_are_exact(cuda_device):
+    """K5 turns a stored count j back into (float)j / (float)P with r = RN(1 / P), q' = RN(j r), q = fma(fma(-q', P, j), r, q') -- three
+    instructions instead of a division.  Exhaustive over j for a spread of denominators (every P up to 64, the patch sizes in use, primes,
+    powers of two, the last one the shortcut covers and the first beyond it): with ONE neighbour the softmax weight is exactly 1, so
+    label_hat is the label value itself, bit for bit."""
+    Ps = sorted(set(list(range(1, 65)) + [196, 256, 49, 64, 81, 100, 121, 144, 169, 225, 1024, 2039, 2047, 2048, 2049, 4096] + list(range(97, 2048, 131))))
+    for P in Ps:
+        j = np.arange(P + 1, dtype=np.float32)
+        vals = (j / np.float32(P)).astype(np.float32)              # numpy divides in fp32: the values K2 stores
+        C = 4
+        lab = np.zeros((P + 1, C), dtype=np.float32); lab[:, 1] = vals; lab[:, 3] = vals[::-1]
+        ix = HipFlatIndex(8, 0, 0)
+        ix.set_label_denominator(P)
+        bank = np.zeros((P + 1, 8), dtype=np.float32); bank[:, 0] = 1.0
+        ix.add(torch.from_numpy(bank).cuda()); ix.add_labels(torch.from_numpy(lab).cuda()); ix.set_num_classes(C)
+        q = torch.from_numpy(bank).cuda()
+        idx = torch.arange(P + 1, device="cuda", dtype=torch.int64)[:, None].contiguous()
+        dist = torch.ones((P + 1, 1), device="cuda")
+        got = ix.aggregate(q, idx, dist).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), lab.view(np.uint32)), P
+
+
+@pytest.mark.parametrize("multi", [False, True])
+def test_label_storage_form_can_change_after_reset(cuda_device, multi):
+    """reset() keeps allocations; a following set_label_denominator may switch between fp32 rows and uint16 counts -- in both
+    directions the table of the other form must not be written through (a null / smaller buffer in the library, an int16 tensor
+    silently truncating fp32 rows in HipMultiIndex).  With fewer rows than the old capacity, so that nothing regrows by itself."""
+    from hbird_mi.nn.search_hip import HipMultiIndex
+    D, C, P = 32, 21, 196
+    bank = gi.unit_bank(3000, D, seed=3)
+    lab = gi.labels_from_masks(3000, C, P, seed=4)
+    q = torch.from_numpy(gi.vit_like_queries(200, D, seed=5)).cuda()
+    ref = HipFlatIndex(D, 0, 0); ref.add(torch.from_numpy(bank[:2000]).cuda()); ref.add_labels(torch.from_numpy(lab[:2000]).cuda()); ref.set_num_classes(C)
+    want = ref.search_aggregate(q, 30)
+    mk = (lambda: HipMultiIndex(D, 0, [0, 0], shard=True)) if multi else (lambda: HipFlatIndex(D, 0, 0))
+    for first, second in ((0, P), (P, 0)):
+        ix = mk()
+        ix.set_label_denominator(first)
+        ix.reserve(3000)
+        ix.add(torch.from_numpy(bank).cuda()); ix.add_labels(torch.from_numpy(lab).cuda()); ix.set_num_classes(C)
+        ix.use_current_stream()
+        assert torch.equal(ix.search_aggregate(q, 30).view(torch.int32), ix.search_aggregate(q, 30).view(torch.int32))
+        ix.reset()
+        ix.set_label_denominator(second)
+        assert ix.label_denominator == second
+        ix.add(torch.from_numpy(bank[:2000]).cuda()); ix.add_labels(torch.from_numpy(lab[:2000]).cuda())
+        got = ix.search_aggregate(q, 30)
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (multi, first, second)
+        got_rows = ix.gather_labels(torch.arange(2000, device="cuda"))
+        assert np.array_equal(got_rows.cpu().numpy().view(np.uint32), lab[:2000].view(np.uint32))
+
+
 def test_k4_k5_fused_vs_oracle(cuda_device):
     M, D, C, nq, k = 30000, 384, 21, 500, 30
     bank = gi.unit_bank(M, D, seed=1)

@@ -254,7 +254,7 @@ def test_knn_f64_oracle_against_torch_float64_topk():
     d2 = ((q64[:, None, :] - b64[None, :, :]) ** 2).sum(-1)
     s, i = d2.topk(k, dim=1, largest=False)
     assert np.array_equal(idx, i.numpy()) and np.abs(dist - s.numpy()).max() < 1e-9
-    # the fp32 chain oracle returns the same SET except at near-ties of fp32 rounding (97.9 % ordered at cfg-2 scale)
+    # the fp32 chain oracle returns the same SET except at near-ties of fp32 rounding (profiles/LABBOOK.md: 97.9 % ordered at cfg-2 scale)
     idx32, _ = oracle.knn_chain_f32(q, bank, k, "l2")
     assert np.mean([len(set(a) & set(b)) for a, b in zip(idx32, idx)]) > k - 0.5
 

@@ -356,3 +356,13 @@ def test_multi_index_row_planning_without_a_gpu(monkeypatch):
     assert u.shard_rows == [9, 0]
     m.set_fp16(2)
     assert all(ix.fp16 == 2 for ix in m.indexes)
+    # GPUs without peer access to the home device: one warning, cross-device tensors go through the host
+    monkeypatch.setattr(search_hip.torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(search_hip.torch.cuda, "can_device_access_peer", lambda a, b: {a, b} != {0, 2})
+    with pytest.warns(RuntimeWarning, match="no peer access"):
+        s = search_hip.HipMultiIndex(4, 0, [0, 1, 2], shard=True)
+    assert s._staged == {2}
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert search_hip.HipMultiIndex(4, 0, [0, 1], shard=True)._staged == set()

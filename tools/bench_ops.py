@@ -80,6 +80,6 @@ for name, op, ms, nbytes in res:
           f"{nbytes / ms / 1e6 / 8000:6.3f} of 8 TB/s")
     rows.append({"shape": name, "kernel": op, "ms": round(ms, 4), "algorithmic_MB": round(nbytes / 1e6, 2),
                  "GBps": round(nbytes / ms / 1e6, 1), "frac_of_hbm_8TBps": round(nbytes / ms / 1e6 / 8000, 4)})
-if len(sys.argv) > 1:      # tools/bench_ops.py <out.json>: the table behind DESIGN.md section 4 (kept under profiles/<round>/)
+if len(sys.argv) > 1:      # tools/bench_ops.py <out.json>: the secondary-kernel table of profiles/<round>/README.md (kept under profiles/<round>/)
     json.dump({"device": torch.cuda.get_device_name(0), "timing": "torch.cuda.Event over 5 calls after one warm-up",
                "rows": rows}, open(sys.argv[1], "w"), indent=1)
