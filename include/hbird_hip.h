@@ -230,7 +230,8 @@ int hb_index_one_launch_trace(hb_index_t* ix, uint32_t* out, int64_t max_words, 
 /* use_fp16 searches re-rank their candidates in exact fp32 arithmetic.  In the fragment tiles a bank row is 2 x D/8 sixteen-byte pieces
  * 512 B apart, so that pass pulls eight times the bytes it uses; a second, row-major fp32 copy of the bank lets it read whole lines (a
  * use_fp16 search at 300,000 x 768: 8.0 -> 6.6 ms, k = 90: 18.0 -> 12.4; results identical).  mode 0 = automatic: the copy is made at the first use_fp16
- * search if the device then still has a third of its memory free; 1 = always (an error if the allocation fails); 2 = never (an
+ * search when fp32 tiles + fp16 tiles + this copy (2.5 x the bank) stay within 55 % of the device's memory -- a rule on the bank's size, not on
+ * what happens to be free (10 M x 768: 77 of 288 GB, copied; 20 M x 1024: 207 GB, not copied); 1 = always (an error if the allocation fails); 2 = never (an
  * existing copy is released).  hb_index_rerank_copy_bytes: what the copy occupies now (0 = none). */
 int hb_index_set_rerank_copy(hb_index_t* ix, int mode);
 int hb_index_rerank_copy_bytes(const hb_index_t* ix, int64_t* bytes);

@@ -90,22 +90,34 @@ __global__ __launch_bounds__(256) void patch_freq_kernel(const float* __restrict
     for (int c = threadIdx.x; c < C; c += 256)
         if (fl[c]) atomicAdd(&freq[(int64_t)b * C + c], fl[c]);
 }
+#define K3_PATCHES 64      // patches per block of the score pass (16 per wave): ONE atomic per block on the image's counter -- the counters of
+                           // a batch share a cache line, and 21,904 same-line atomics (one per patch) took 250 us at the cfg-3 batch
 __global__ __launch_bounds__(256) void patch_scores_kernel(const float* __restrict__ label, int SS, int C, const int* __restrict__ freq,
                                                            float* __restrict__ scores, int* __restrict__ nonempty,
                                                            int* __restrict__ nz_count) {
-    const int lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
-    if (p >= SS) return;                                   // whole wave
-    const float* lp = label + ((int64_t)b * SS + p) * C;
+    __shared__ int s_nz[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.y;
     const int* fb = freq + (int64_t)b * C;
-    int sum = 0, any = 0;
-    for (int c = lane; c < C; c += 64)
-        if (lp[c] > 0.0f) { sum += fb[c]; any = 1; }
-    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); any |= __shfl_xor(any, o); }
-    if (lane == 0) {
-        scores[(int64_t)b * SS + p] = any ? (float)sum : 1e6f;
-        nonempty[(int64_t)b * SS + p] = any;
-        if (any) atomicAdd(&nz_count[b], 1);
+    int mine = 0;
+    for (int i = 0; i < K3_PATCHES / 4; ++i) {
+        const int p = blockIdx.x * K3_PATCHES + i * 4 + wv;
+        if (p >= SS) break;                                // wave-uniform
+        const float* lp = label + ((int64_t)b * SS + p) * C;
+        int sum = 0, any = 0;
+        for (int c = lane; c < C; c += 64)
+            if (lp[c] > 0.0f) { sum += fb[c]; any = 1; }
+        for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); any |= __shfl_xor(any, o); }
+        if (lane == 0) {
+            scores[(int64_t)b * SS + p] = any ? (float)sum : 1e6f;
+            nonempty[(int64_t)b * SS + p] = any;
+        }
+        mine += any;
+    }
+    if (lane == 0) s_nz[wv] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int n = s_nz[0] + s_nz[1] + s_nz[2] + s_nz[3];
+        if (n) atomicAdd(&nz_count[b], n);
     }
 }
 
@@ -180,7 +192,7 @@ extern "C" int hb_patch_scores(const float* label, int64_t B, int SS, int C, flo
     const int64_t n = (int64_t)SS * C;
     patch_freq_kernel<<<dim3((unsigned)((n + K3_CHUNK - 1) / K3_CHUNK), (unsigned)B), dim3(256), (size_t)C * 4, s>>>(label, SS, C, freq);
     HB_HIP(hipGetLastError());
-    patch_scores_kernel<<<dim3((unsigned)((SS + 3) / 4), (unsigned)B), dim3(256), 0, s>>>(label, SS, C, freq, scores, nonempty, nz_count);
+    patch_scores_kernel<<<dim3((unsigned)((SS + K3_PATCHES - 1) / K3_PATCHES), (unsigned)B), dim3(256), 0, s>>>(label, SS, C, freq, scores, nonempty, nz_count);
     HB_HIP(hipGetLastError());
     return 0;
 }

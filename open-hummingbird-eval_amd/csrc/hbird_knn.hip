@@ -532,8 +532,8 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
             HB_HIP(hipStreamSynchronize(s0));
         }
         if (ix->f16_overflow) { f16 = false; ix->last_fp16_fallbacks = nq; }
-        // ... and the row-major fp32 copy for the re-rank (hbird_knn_f16.hip).  Automatic: only while the device keeps a third of its
-        // memory free beyond it (a 10 M x 768 bank: 30.7 GB of tiles + 15.4 GB of fp16 tiles + 30.7 GB of rows, of 288)
+        // ... and the row-major fp32 copy for the re-rank (hbird_knn_f16.hip).  Automatic: by the bank's size (below; a 10 M x 768 bank:
+        // 30.7 GB of tiles + 15.4 GB of fp16 tiles + 30.7 GB of rows, of 288)
         if (f16 && ix->rerank_copy != 2) {
             const int rs = (ix->g8 * 8 + 31) / 32 * 32;
             if (ix->rows32 && (ix->rows32_cap_rows != ix->cap_rows || ix->rows32_rs != rs)) {
@@ -545,7 +545,12 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
                 size_t free_b = 0, total_b = 0;
                 HB_HIP(hipMemGetInfo(&free_b, &total_b));
                 ix->rows32_declined_cap = ix->cap_rows;     // (cleared below when the copy is made)
-                if (ix->rerank_copy == 1 || (free_b > need && free_b - need > total_b / 3)) {
+                // automatic: by the BANK's size against the device's memory, not by what happens to be free at the first search (round 4's rule:
+                // the same index then behaved differently beside other allocations) -- the three copies (fp32 tiles, fp16 tiles, fp32 rows =
+                // 2.5 x the bank) may take up to 55 % of the device: 10 M x 768 (77 of 288 GB) gets the copy, 20 M x 1024 (207 GB) does not; an
+                // allocation that fails all the same just means no copy
+                const size_t bank_b = (size_t)ix->cap_rows * ix->dp * 4;
+                if (ix->rerank_copy == 1 || (bank_b + bank_b / 2 + need <= total_b / 100 * 55 && free_b > need)) {
                     if (hipMalloc((void**)&ix->rows32, need) == hipSuccess) { ix->rows32_cap_rows = ix->cap_rows; ix->rows32_rs = rs; ix->rows32_rows = 0; ix->rows32_declined_cap = -1; }
                     else { (void)hipGetLastError(); ix->rows32 = nullptr; if (ix->rerank_copy == 1) return hb_fail("hb_index_search: no memory for the re-rank copy of the bank"); }
                 }

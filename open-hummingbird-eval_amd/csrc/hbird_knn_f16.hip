@@ -373,7 +373,7 @@ int hb_launch_rerank(const float* tiles, const float* binit, int g8, int d, cons
 // ---- the re-rank on a row-major copy of the bank ---------------------------------------------------------------------
 // In the fragment tiles a row is 2 x D/8 sixteen-byte pieces 512 B apart: the re-rank above pulls a 128-byte line for every piece it
 // uses (FETCH_SIZE of the kernel at 300,000 x 768, 12,544 queries: 11.6 GB for 1.35 GB of rows, 1.72 of the search's 8.05 ms; k = 90:
-// a third of the search).  Where memory allows (hb_launch_knn) the bank is kept a second time as plain rows [row][rs] and the
+// a third of the search).  Where the bank is small enough (hb_launch_knn: 2.5 x the bank within 55 % of the device) the bank is kept a second time as plain rows [row][rs] and the
 // re-rank reads whole lines: eight lanes fetch one candidate row's 128 B (32 k) with one instruction, eight rows per instruction;
 // the pieces go through a padded LDS image from which lane t takes row t's 32 values for its serial chain (same chain, same order, same
 // bits as rerank_kernel).  The next 32 k of every row are in flight while a chunk is consumed; the query's chunk travels as one more

@@ -665,10 +665,13 @@ def test_one_launch_search_against_the_oracle_and_its_escape_paths(cuda_device, 
     Then the ways out, all with the same bits: a block that raises the abort flag at a boundary (everyone leaves, the completion launch
     finishes every block's list from its recorded phase), a block that leaves silently (the others run into their timeout -- a bounded
     spin, 2 ms here -- and give up), both at the first and at a late boundary; and repeated searches (the barrier words are re-zeroed)."""
-    M, D, nq = 120_000, 128, 12_800
-    bank = gi.unit_bank(M, D, seed=15); qn = gi.vit_like_queries(nq, D, seed=16)
-    q = torch.from_numpy(qn).cuda()
-    for k in (30, 90):
+    M, D = 120_000, 128
+    bank = gi.unit_bank(M, D, seed=15)
+    # (more queries for k = 90: a search qualifies when the pools of a query tile's slots -- about 256 workgroups / query tiles + 2 of
+    # them, capacity 192 at k = 30, 256 / 384 at k = 90 -- fit the LDS that is free between two phases, two queries per wave)
+    for k, nq in ((30, 12_800), (90, 22_016)):
+        qn = gi.vit_like_queries(nq, D, seed=16)
+        q = torch.from_numpy(qn).cuda()
         ix = HipFlatIndex(D, 0, 0); ix.add(torch.from_numpy(bank).cuda()); ix.set_fp16(fp16)
         ridx, rdist = oracle.knn_chain_f32(qn[:400], bank, k)
         ip, dp = ix.search(q, k)                                            # the default: a launch per phase

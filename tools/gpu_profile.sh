@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_${1:-r3}
 mkdir -p $OUT
 cd /tmp
-B="python3 $ROOT/bench.py --no-cpu-baseline --no-traffic"
+B="python3 $ROOT/bench.py --no-cpu-baseline --no-traffic --no-e2e"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_trace -- $B --steps 3 --warmup 1 > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 find /tmp/p_trace -name "*kernel_stats.csv" -exec cp {} $OUT/knn_10Mx768_kernel_stats.csv \;
 find /tmp/p_trace -name "*kernel_trace.csv" -exec sh -c 'head -1 "$1" > "$2"; grep -E "knn_|aggregate_kernel|query_aux|rerank|rows_to_tiles_kernel<false, false>|tiles_to_f16" "$1" | tail -60 >> "$2"' _ {} $OUT/knn_10Mx768_kernel_trace_hot.csv \;
