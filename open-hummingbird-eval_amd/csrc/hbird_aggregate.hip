@@ -24,7 +24,7 @@
 // to four-way, and the kernel ran slower on counts than on fp32 rows although it moved half the bytes.)
 #define AGG_LUT 2048
 template <bool U16>
-__global__ __launch_bounds__(256) void aggregate_kernel(const void* __restrict__ labels_v, int P, int64_t nlabels, int C,
+__global__ __launch_bounds__(256) void aggregate_kernel(const void* __restrict__ labels_v, int ls, int wide, int P, int64_t nlabels, int C,
                                                         const float* __restrict__ bnorm, int64_t norm_base, int64_t nnorm,
                                                         const float* __restrict__ qnorm,
                                                         const int64_t* __restrict__ idx,
@@ -80,12 +80,12 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const void* __restrict__
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are visible to all its lanes
     auto label_at = [&](int64_t rj, int c) -> float {
         if (U16) {
-            const float jf = (float)counts[rj * (int64_t)C + c];
+            const float jf = (float)counts[rj * (int64_t)ls + c];
             if (P > AGG_LUT) return jf / Pf;
             const float q1 = jf * Pr;
             return fmaf(fmaf(-q1, Pf, jf), Pr, q1);
         }
-        return labels[rj * (int64_t)C + c];
+        return labels[rj * (int64_t)ls + c];
     };
     constexpr int UB = 8;                  // label rows in flight per lane
     if (C <= 32) {
@@ -109,6 +109,42 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const void* __restrict__
         float total = accv;                 // lanes of group 0: + group 1 + group 2 ...
         for (int gg = 1; gg < G; ++gg) total += __shfl(accv, gg * C + c);
         if (g == 0) out[q * (int64_t)C + c] = total;
+        return;
+    }
+    if (U16 && wide) {
+        // count rows of 16-byte granules (the index's own table, padded; hb_launch_aggregate checks stride, alignment, P and C): lane l gathers the eight counts 8 l .. 8 l + 7 of a row with ONE 16-byte load
+        // -- ceil(C / 8) lanes cover a row (19 of 64 at C = 151), k loads per lane instead of 3 k two-byte ones: the kernel is bound by the
+        // number of gather instructions in flight, not by lanes or bytes.  Every class still sums its neighbours in ascending order with
+        // the same fmaf chain, so the bits equal the narrow path's (and the fp32 table's).
+        const int nl = (C + 7) >> 3;
+        float a8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a8[i] = 0.0f;
+        if (lane < nl) {
+            for (int j0 = 0; j0 < k; j0 += UB) {
+                uint4 raw[UB];
+                float wj[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int j = j0 + u;
+                    wj[u] = j < k ? wgt[j] : 0.0f;
+                    raw[u] = *reinterpret_cast<const uint4*>(counts + (j < k ? rows[j] : 0) * (int64_t)ls + 8 * lane);
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const unsigned wds[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float jf = (float)((wds[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu);
+                        const float q1 = jf * Pr;
+                        a8[i] = fmaf(wj[u], fmaf(fmaf(-q1, Pf, jf), Pr, q1), a8[i]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (8 * lane + i < C) out[q * (int64_t)C + 8 * lane + i] = a8[i];
+        }
         return;
     }
     for (int c0 = 0; c0 < C; c0 += 64) {
@@ -139,57 +175,65 @@ int hb_launch_aggregate(const hb_index* ix, const float* qnorm, const int64_t* i
     const float* bnorm = ix->bnorm; int64_t nlab = ix->nlabels;
     int P = ix->label_P;
     const dim3 grid((unsigned)((nq + 3) / 4)), block(256);
+    // K5's wide gather (aggregate_kernel): rows of whole 16-byte granules at a 16-byte aligned base, the three-instruction quotient's range, at
+    // most 64 lanes per row, and more classes than the (neighbour group, class) form takes
+    auto wide_ok = [&](const void* tab, int stride, int PP) {
+        return (stride & 7) == 0 && (reinterpret_cast<uintptr_t>(tab) & 15) == 0 && PP > 0 && PP <= AGG_LUT && ix->c > 32 && ix->c <= 512 ? 1 : 0;
+    };
     if (norms_all) {   // label-sharded: this index's own label rows, everybody's norms
         if (!labels || ix->nlabels < ix->ntotal) return hb_fail("hb_index_aggregate_partial: label rows missing (hb_index_add_labels)");
-        if (own16) aggregate_kernel<true><<<grid, block, 0, s>>>(labels, P, ix->ntotal, ix->c, norms_all, 0, n_all, qnorm, idx, dist, nq, k, id_base, ix->metric, ix->q_aux, beta, out);
-        else aggregate_kernel<false><<<grid, block, 0, s>>>(labels, 0, ix->ntotal, ix->c, norms_all, 0, n_all, qnorm, idx, dist, nq, k, id_base, ix->metric, ix->q_aux, beta, out);
+        if (own16) aggregate_kernel<true><<<grid, block, 0, s>>>(labels, ix->lab_stride(), wide_ok(labels, ix->lab_stride(), P), P, ix->ntotal, ix->c, norms_all, 0, n_all, qnorm, idx, dist, nq, k, id_base, ix->metric, ix->q_aux, beta, out);
+        else aggregate_kernel<false><<<grid, block, 0, s>>>(labels, ix->c, 0, 0, ix->ntotal, ix->c, norms_all, 0, n_all, qnorm, idx, dist, nq, k, id_base, ix->metric, ix->q_aux, beta, out);
         HB_HIP(hipGetLastError());
         return 0;
     }
     bool u16 = own16;
+    int ls = ix->lab_stride();
     if (ix->ext_labels || ix->ext_labels16) {
+        ls = ix->c;                                  // borrowed tables are dense [n, C]
         u16 = ix->ext_labels16 != nullptr;
         labels = u16 ? (const void*)ix->ext_labels16 : (const void*)ix->ext_labels; P = ix->ext_P;
         bnorm = ix->ext_bnorm; nlab = ix->ext_n; id_base = ix->ext_base;
     } else if (!labels || ix->nlabels < ix->ntotal) return hb_fail("hb_index_search_aggregate: label rows missing (hb_index_add_labels)");
-    if (u16) aggregate_kernel<true><<<grid, block, 0, s>>>(labels, P, nlab, ix->c, bnorm, id_base, nlab, qnorm, idx, dist, nq, k, id_base, ix->metric, ix->q_aux, beta, out);
-    else aggregate_kernel<false><<<grid, block, 0, s>>>(labels, 0, nlab, ix->c, bnorm, id_base, nlab, qnorm, idx, dist, nq, k, id_base, ix->metric, ix->q_aux, beta, out);
+    if (u16) aggregate_kernel<true><<<grid, block, 0, s>>>(labels, ls, wide_ok(labels, ls, P), P, nlab, ix->c, bnorm, id_base, nlab, qnorm, idx, dist, nq, k, id_base, ix->metric, ix->q_aux, beta, out);
+    else aggregate_kernel<false><<<grid, block, 0, s>>>(labels, ls, 0, 0, nlab, ix->c, bnorm, id_base, nlab, qnorm, idx, dist, nq, k, id_base, ix->metric, ix->q_aux, beta, out);
     HB_HIP(hipGetLastError());
     return 0;
 }
 
 // fp32 label values -> uint16 counts: j = round(v P); the stored j is exact iff (float)j / (float)P == v (every value K2 produces);
-// anything else raises the sticky flag (read once after the table grew: hb_labels_checked)
-__global__ __launch_bounds__(256) void labels_to_counts_kernel(const float* __restrict__ src, int64_t n, int P, unsigned short* __restrict__ dst,
-                                                               int* __restrict__ flag) {
+// anything else raises the sticky flag (read once after the table grew: hb_labels_checked).  Dense [rows, c] in, rows of dst_stride out.
+__global__ __launch_bounds__(256) void labels_to_counts_kernel(const float* __restrict__ src, int64_t n, int c, int dst_stride, int P,
+                                                               unsigned short* __restrict__ dst, int* __restrict__ flag) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float v = src[i], Pf = (float)P;
     const float r = rintf(v * Pf);
     const bool ok = r >= 0.0f && r <= Pf && r / Pf == v;
-    dst[i] = ok ? (unsigned short)r : 0;
+    dst[(i / c) * dst_stride + (i % c)] = ok ? (unsigned short)r : 0;
     if (!ok) *flag = 1;
 }
 
-int hb_launch_labels_to_counts(const float* src, int64_t n, int P, uint16_t* dst, int* flag, hipStream_t s) {
+int hb_launch_labels_to_counts(const float* src, int64_t rows, int c, int dst_stride, int P, uint16_t* dst, int* flag, hipStream_t s) {
+    const int64_t n = rows * c;
     if (n == 0) return 0;
-    labels_to_counts_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(src, n, P, dst, flag);
+    labels_to_counts_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(src, n, c, dst_stride, P, dst, flag);
     HB_HIP(hipGetLastError());
     return 0;
 }
 
 // out[i, :] = counts[ids[i], :] / P as fp32 (label_memory.index_select on a table stored as counts); ids outside the table give zeros
-__global__ __launch_bounds__(256) void gather_label_counts_kernel(const unsigned short* __restrict__ src, int64_t src_rows, int c, int P,
+__global__ __launch_bounds__(256) void gather_label_counts_kernel(const unsigned short* __restrict__ src, int64_t src_rows, int c, int src_stride, int P,
                                                                   const int64_t* __restrict__ ids, int64_t n, float* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n * c) return;
     const int64_t i = t / c, r = ids[i];
-    out[t] = (r >= 0 && r < src_rows) ? (float)src[r * c + (t % c)] / (float)P : 0.0f;
+    out[t] = (r >= 0 && r < src_rows) ? (float)src[r * src_stride + (t % c)] / (float)P : 0.0f;
 }
 
-int hb_launch_gather_label_counts(const uint16_t* src, int64_t src_rows, int c, int P, const int64_t* ids, int64_t n, float* out, hipStream_t s) {
+int hb_launch_gather_label_counts(const uint16_t* src, int64_t src_rows, int c, int src_stride, int P, const int64_t* ids, int64_t n, float* out, hipStream_t s) {
     if (n == 0) return 0;
-    gather_label_counts_kernel<<<dim3((unsigned)((n * c + 255) / 256)), dim3(256), 0, s>>>(src, src_rows, c, P, ids, n, out);
+    gather_label_counts_kernel<<<dim3((unsigned)((n * c + 255) / 256)), dim3(256), 0, s>>>(src, src_rows, c, src_stride, P, ids, n, out);
     HB_HIP(hipGetLastError());
     return 0;
 }

@@ -365,14 +365,22 @@ extern "C" int hb_index_add_labels(hb_index_t* ix, const float* labels, int64_t 
     if (n == 0) return 0;
     HB_HIP(hipSetDevice(ix->device));
     if (ix->c != 0 && ix->c != c && ix->nlabels > 0) return hb_fail("hb_index_add_labels: class count changed");
+    if (ix->c != c && ix->lab_cap > 0) {
+        // an emptied index (hb_index_reset keeps allocations) takes rows of another width: `lab_cap` counts rows of the OLD width
+        HB_HIP(hipStreamSynchronize(ix->stream));
+        if (ix->labels) HB_HIP(hipFree(ix->labels));
+        if (ix->labels16) HB_HIP(hipFree(ix->labels16));
+        ix->labels = nullptr; ix->labels16 = nullptr; ix->lab_cap = 0;
+    }
     ix->c = c;
     const size_t esz = ix->label_P ? 2 : 4;      // uint16 counts or fp32 values
+    const size_t ls = (size_t)ix->lab_stride();  // elements per stored row (counts: padded to 16 bytes)
     if (ix->nlabels + n > ix->lab_cap) {
         int64_t cap = std::max<int64_t>(ix->nlabels + n, std::max<int64_t>(ix->cap_rows, ix->lab_cap + ix->lab_cap / 2));
         char* nl = nullptr;
         char* old = ix->label_P ? (char*)ix->labels16 : (char*)ix->labels;
-        HB_HIP(hipMalloc((void**)&nl, (size_t)cap * c * esz));
-        if (ix->nlabels > 0) HB_HIP(hipMemcpyAsync(nl, old, (size_t)ix->nlabels * c * esz, hipMemcpyDeviceToDevice, ix->stream));
+        HB_HIP(hipMalloc((void**)&nl, (size_t)cap * ls * esz));
+        if (ix->nlabels > 0) HB_HIP(hipMemcpyAsync(nl, old, (size_t)ix->nlabels * ls * esz, hipMemcpyDeviceToDevice, ix->stream));
         HB_HIP(hipStreamSynchronize(ix->stream));
         if (old) HB_HIP(hipFree(old));
         if (ix->label_P) ix->labels16 = (uint16_t*)nl; else ix->labels = (float*)nl;
@@ -387,7 +395,7 @@ extern "C" int hb_index_add_labels(hb_index_t* ix, const float* labels, int64_t 
             if (stage_in(ix, labels, (size_t)n * c * 4, 0)) return -1;
             src = (const float*)ix->tmp;
         }
-        if (hb_launch_labels_to_counts(src, n * (int64_t)c, ix->label_P, ix->labels16 + ix->nlabels * (int64_t)c, ix->lab_flag, ix->stream)) return -1;
+        if (hb_launch_labels_to_counts(src, n, c, (int)ls, ix->label_P, ix->labels16 + ix->nlabels * (int64_t)ls, ix->lab_flag, ix->stream)) return -1;
         if (!on_device) HB_HIP(hipStreamSynchronize(ix->stream));
         ix->nlabels += n;
         return 0;
@@ -523,7 +531,7 @@ static int gather_impl(hb_index* ix, const int64_t* ids, int64_t n, int64_t id_b
     if (labels) {
         // shift global ids to local rows inside the kernel via src offset: ids are global, rows local
         if (id_base != 0) return hb_fail("hb_index_gather_labels: id_base != 0 is not supported yet");
-        if (ix->label_P ? hb_launch_gather_label_counts(ix->labels16, ix->nlabels, width, ix->label_P, d_ids, n, d_out, ix->stream)
+        if (ix->label_P ? hb_launch_gather_label_counts(ix->labels16, ix->nlabels, width, ix->lab_stride(), ix->label_P, d_ids, n, d_out, ix->stream)
                         : hb_launch_gather_rows(ix->labels, ix->nlabels, width, d_ids, n, d_out, ix->stream)) return -1;
     } else {
         if (hb_launch_tiles_to_rows(ix->tiles, ix->g8, ix->d, d_ids, n, id_base, d_out, ix->stream)) return -1;
@@ -572,7 +580,9 @@ extern "C" int hb_index_copy_label_counts(hb_index_t* ix, uint16_t* out, int on_
     if (ix->nlabels == 0) return 0;
     HB_HIP(hipSetDevice(ix->device));
     if (hb_labels_checked(ix)) return -1;
-    HB_HIP(hipMemcpyAsync(out, ix->labels16, (size_t)ix->nlabels * ix->c * 2, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ix->stream));
+    // (the stored rows are padded to 16 bytes; the caller gets dense [nlabels, C] rows)
+    HB_HIP(hipMemcpy2DAsync(out, (size_t)ix->c * 2, ix->labels16, (size_t)ix->lab_stride() * 2, (size_t)ix->c * 2, (size_t)ix->nlabels,
+                            on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ix->stream));
     if (!on_device) HB_HIP(hipStreamSynchronize(ix->stream));
     return 0;
 }

@@ -38,12 +38,13 @@ struct hb_index {
     float* binit = nullptr;                // per-row accumulator init [cap_rows]
     float* bnorm = nullptr;                // per-row L2 norm (fp32)  [cap_rows]
     float* labels = nullptr;               // [lab_cap][c] fp32 (label_P == 0) ...
-    uint16_t* labels16 = nullptr;          // ... or [lab_cap][c] uint16 counts j of values j / label_P (hb_index_set_label_denominator)
+    uint16_t* labels16 = nullptr;          // ... or [lab_cap][lab_stride()] uint16 counts j of values j / label_P (hb_index_set_label_denominator): rows padded to 8 counts = 16 B
     int label_P = 0;
     int* lab_flag = nullptr;               // sticky device flag: a label value was not a multiple of 1 / label_P
     int64_t lab_checked = 0;               // label rows whose conversion has been checked (one read-back after the table grew)
     int c = 0;
     int64_t nlabels = 0, lab_cap = 0;
+    int lab_stride() const { return label_P ? (c + 7) & ~7 : c; }   // elements per stored label row (counts: 16-byte rows for K5's wide gather)
     int num_cu = 256;
     // optional borrowed tables covering a GLOBAL id range (multi-GPU: all-gathered labels / norms)
     const float* ext_labels = nullptr; const float* ext_bnorm = nullptr; int64_t ext_n = 0, ext_base = 0;
@@ -127,8 +128,8 @@ int hb_launch_scatter_rows(const int64_t* rows, int64_t n, int k, const int64_t*
 struct knn16_args;
 int hb_knn_f16_launch(const knn16_args& args, int grid, hipStream_t s);
 // label storage: fp32 values, or uint16 counts of values j / P (exactly the fp32 value: K2 computes (float)j / (float)P)
-int hb_launch_labels_to_counts(const float* src, int64_t n, int P, uint16_t* dst, int* flag, hipStream_t s);
-int hb_launch_gather_label_counts(const uint16_t* src, int64_t src_rows, int c, int P, const int64_t* ids, int64_t n, float* out, hipStream_t s);
+int hb_launch_labels_to_counts(const float* src, int64_t rows, int c, int dst_stride, int P, uint16_t* dst, int* flag, hipStream_t s);
+int hb_launch_gather_label_counts(const uint16_t* src, int64_t src_rows, int c, int src_stride, int P, const int64_t* ids, int64_t n, float* out, hipStream_t s);
 int hb_labels_checked(hb_index* ix);   // 0, or fails when a stored label was not a multiple of 1 / label_P
 int hb_launch_aggregate(const hb_index* ix, const float* qnorm, const int64_t* idx, const float* dist, int64_t nq,
                         int k, int64_t id_base, float beta, float* out, hipStream_t s, const float* norms_all = nullptr, int64_t n_all = 0);

@@ -161,7 +161,7 @@ def test_count_quotients_are_exact(cuda_device):
     for P in Ps:
         j = np.arange(P + 1, dtype=np.float32)
         vals = (j / np.float32(P)).astype(np.float32)              # numpy divides in fp32: the values K2 stores
-        C = 4
+        C = 4 if P % 2 else 40                                     # few classes: the (neighbour group, class) form; many: the 16-byte gather
         lab = np.zeros((P + 1, C), dtype=np.float32); lab[:, 1] = vals; lab[:, 3] = vals[::-1]
         ix = HipFlatIndex(8, 0, 0)
         ix.set_label_denominator(P)
@@ -202,6 +202,30 @@ def test_label_storage_form_can_change_after_reset(cuda_device, multi):
         assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (multi, first, second)
         got_rows = ix.gather_labels(torch.arange(2000, device="cuda"))
         assert np.array_equal(got_rows.cpu().numpy().view(np.uint32), lab[:2000].view(np.uint32))
+
+
+@pytest.mark.parametrize("P", [0, 196])
+def test_class_count_can_change_after_reset(cuda_device, P):
+    """reset() keeps allocations and `lab_cap` counts ROWS: label rows of another width (more classes) after a reset must not be written
+    into the buffer sized for the old width.  Also the padded count rows (16-byte granules) against a dense fp32 table, C = 151 -> 152."""
+    D = 32
+    bank = gi.unit_bank(4000, D, seed=3)
+    q = torch.from_numpy(gi.vit_like_queries(300, D, seed=5)).cuda()
+    ix = HipFlatIndex(D, 0, 0)
+    ix.set_label_denominator(P)
+    ix.reserve(4000)
+    ix.add(torch.from_numpy(bank).cuda()); ix.add_labels(torch.from_numpy(gi.labels_from_masks(4000, 21, 196, seed=4)).cuda()); ix.set_num_classes(21)
+    ix.search_aggregate(q, 30)
+    ix.reset()
+    lab = gi.labels_from_masks(4000, 151, 196, seed=6)
+    ix.add(torch.from_numpy(bank).cuda()); ix.add_labels(torch.from_numpy(lab).cuda()); ix.set_num_classes(151)
+    ref = HipFlatIndex(D, 0, 0); ref.add(torch.from_numpy(bank).cuda()); ref.add_labels(torch.from_numpy(lab).cuda()); ref.set_num_classes(151)
+    assert torch.equal(ix.search_aggregate(q, 30).view(torch.int32), ref.search_aggregate(q, 30).view(torch.int32))
+    assert np.array_equal(ix.gather_labels(np.arange(4000)).view(np.uint32), lab.view(np.uint32))
+    if P:
+        cnt = ix.copy_label_counts()
+        assert tuple(cnt.shape) == (4000, 151)
+        assert np.array_equal(cnt.cpu().numpy().view(np.uint16).astype(np.float32) / np.float32(P), lab)
 
 
 def test_k4_k5_fused_vs_oracle(cuda_device):

@@ -55,9 +55,20 @@ for name, (B, S, ps, D, C, k) in {"cfg2": (64, 14, 16, 384, 21, 30), "cfg3": (16
     ms = timeit(lambda: bank.aggregate(q, idx, dist)); res.append((name, "K5 aggregate (+query norms), fp32 labels", ms, (4 * k * C + 12 * k + 4 * C + 4 * D) * B * N))
     lh = bank.aggregate(q, idx, dist).view(B, N, C)
     agg = HipFlatIndex(D, 0, 0); agg.use_current_stream(); agg.set_label_count_table(cbank.copy_label_counts(), bank.copy_norms(), ps * ps, 0)
-    ms = timeit(lambda: agg.aggregate(q, idx, dist)); res.append((name, "K5 aggregate (+query norms), uint16 label counts", ms, (2 * k * C + 12 * k + 4 * C + 4 * D) * B * N))
+    ms = timeit(lambda: agg.aggregate(q, idx, dist)); res.append((name, "K5 aggregate (+query norms), uint16 counts, borrowed dense table", ms, (2 * k * C + 12 * k + 4 * C + 4 * D) * B * N))
     assert torch.equal(agg.aggregate(q, idx, dist).view(torch.int32), lh.reshape(-1, C).view(torch.int32))
-    del agg, cbank
+    del agg
+    # the index's OWN count table (rows padded to 16 bytes: the wide gather) -- what a single-GPU evaluation runs
+    own = HipFlatIndex(D, 0, 0); own.reserve(M); own.use_current_stream(); own.set_label_denominator(ps * ps)
+    g2 = torch.Generator(device=dev).manual_seed(0)
+    torch.randn((B * N, D), generator=g2, device=dev); torch.randint(0, C, (B, 1, H, H), generator=g2, device=dev)      # replay the stream up to the bank rows
+    for r0 in range(0, M, 250_000):
+        own.add(torch.randn((250_000, D), generator=g2, device=dev), normalize=True)
+        own.add_labels(torch.randint(0, ps * ps + 1, (250_000, C), generator=g2, device=dev).float() / torch.tensor(float(ps * ps), device=dev))
+    own.set_num_classes(C)
+    ms = timeit(lambda: own.aggregate(q, idx, dist)); res.append((name, "K5 aggregate (+query norms), uint16 counts, own padded table", ms, (2 * k * C + 12 * k + 4 * C + 4 * D) * B * N))
+    assert torch.equal(own.aggregate(q, idx, dist).view(torch.int32), lh.reshape(-1, C).view(torch.int32))
+    del own, cbank
     # K6
     ms = timeit(lambda: ops.upsample_argmax(lh, S, H, H)); res.append((name, "K6 upsample_argmax", ms, 4 * C * N * B + 8 * H * H * B))
     pred = ops.upsample_argmax(lh, S, H, H)
