@@ -218,7 +218,8 @@ int hb_index_set_search_options(hb_index_t* ix, int phases, int64_t small_limit_
  * workgroup resident, at most 32 slots per query tile whose pools fit the LDS between two phases).  timeout_us 0 = automatic (20 ms +
  * twice the search's estimated time).  inject (tests and diagnostics; 0 = nothing): (kind << 28) | (phase << 16) | (block + 1) makes that
  * block fail at that phase boundary -- kind 1: it raises the abort flag, kind 2: it leaves silently and the others run into their timeout;
- * kind 3: no failure, every workgroup stamps the real-time counter at each boundary (hb_index_one_launch_trace). */
+ * kind 3: no failure, every workgroup stamps the real-time counter at each boundary (hb_index_one_launch_trace); kind 4: the block passes
+ * both barriers of that boundary and raises the flag afterwards (the others are already in the next phase). */
 int hb_index_set_one_launch(hb_index_t* ix, int mode, int64_t timeout_us, int inject);
 /* What the last search did about it (one stream synchronisation): out[0] = 1 if it ran as one launch, [1] = its phases, [2] = phase
  * boundaries passed by block 0, [3] / [4] / [5] = ticks (100 MHz) block 0 spent in the first barrier / the floor computation / the second

@@ -1038,7 +1038,9 @@ static inline __device__ __attribute__((noinline)) int ol_boundary_call(int ph, 
     if (done >= ol.n_phases) return 0;
     int* flag = reinterpret_cast<int*>(lds);             // [0]: the barrier's verdict for the other waves
     const int inj = ol.inject;
-    const bool hit = inj != 0 && ((inj >> 16) & 0xFFF) == ph && ((inj & 0xFFFF) - 1) == (int)blockIdx.x;
+    const bool hit_here = inj != 0 && ((inj >> 16) & 0xFFF) == ph && ((inj & 0xFFFF) - 1) == (int)blockIdx.x;
+    const bool hit = hit_here && ((inj >> 28) == 1 || (inj >> 28) == 2);    // fails AT the first barrier
+    const bool hit_late = hit_here && (inj >> 28) == 4;                      // passes both barriers, THEN raises the flag and leaves
     unsigned long long t0 = 0, t1 = 0, t2 = 0;
     unsigned* trace = (inj >> 28) == 3 ? ol.gb + HB_GB_WORDS(ol.G) + (size_t)(done - 1) * 4 * ol.G + blockIdx.x : nullptr;
     if (trace && w == 0 && lane == 0) gb_store(trace, (unsigned)__builtin_amdgcn_s_memrealtime());
@@ -1067,6 +1069,7 @@ static inline __device__ __attribute__((noinline)) int ol_boundary_call(int ph, 
             if (blockIdx.x == 0) t2 = __builtin_amdgcn_s_memrealtime();
             if (trace && lane == 0) gb_store(trace + 2 * ol.G, (unsigned)__builtin_amdgcn_s_memrealtime());
             ok = gb_arrive_wait(ol.gb, (unsigned)(2 * done), ol.G, ol.timeout, false, lane);
+            if (hit_late) { if (lane == 0) gb_store(ol.gb + HB_GB_ABORT, 1u); ok = 0; }     // (the others have passed: they run on, some to their end)
             if (lane == 0) flag[0] = ok;
             if (trace && lane == 0) gb_store(trace + 3 * ol.G, (unsigned)__builtin_amdgcn_s_memrealtime());
             if (blockIdx.x == 0 && lane == 0) {
@@ -1092,6 +1095,13 @@ __device__ __forceinline__ bool ol_boundary(int& ph, char* lds, int w, int lane)
     ol.gb = HB_KARG(ARGS, ol.gb);
     if (ol.gb == nullptr) return false;
     ol.resume = HB_KARG(ARGS, ol.resume); ol.n_phases = HB_KARG(ARGS, ol.n_phases); ol.phase_bounds = nullptr;
+    if (!ol.resume && ph + 1 >= ol.n_phases) {
+        // the end of this block's list: "all phases done" goes on record, so that a completion launch -- which runs when ANY block gave a
+        // barrier up, possibly after this one had passed its last barrier -- does not start this block's list again (its rows would enter
+        // the pools twice)
+        if (w == 0 && lane == 0) gb_store(ol.gb + HB_GB_PROGRESS + blockIdx.x, (unsigned)ol.n_phases);
+        return false;
+    }
     ol.qt_off = HB_KARG(ARGS, ol.qt_off); ol.qt_slots = HB_KARG(ARGS, ol.qt_slots); ol.G = HB_KARG(ARGS, ol.G); ol.nq = HB_KARG(ARGS, ol.nq);
     ol.per_wave = HB_KARG(ARGS, ol.per_wave); ol.timeout = HB_KARG(ARGS, ol.timeout); ol.inject = HB_KARG(ARGS, ol.inject); ol.pad_ = 0;
     ol_pools pl;

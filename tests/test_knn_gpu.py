@@ -684,7 +684,9 @@ def test_one_launch_search_against_the_oracle_and_its_escape_paths(cuda_device, 
         assert ix.last_fp16_fallbacks() == 0
         assert np.array_equal(i0[:400].cpu().numpy(), ridx) and np.array_equal(d0[:400].cpu().numpy().view(np.uint32), rdist.view(np.uint32))
         last = st["phases"] - 2
-        for kind, phase, block in ((1, 0, 7), (1, last, 200), (2, 0, 255), (2, last, 3), (1, 1, 0)):
+        # kind 4: the block passes both barriers of the boundary and only THEN raises the flag -- the others are already running the next
+        # phase, at the last boundary to their end: they must be on record as done, or the completion launch would run their lists again
+        for kind, phase, block in ((1, 0, 7), (1, last, 200), (2, 0, 255), (2, last, 3), (1, 1, 0), (4, last, 100), (4, 0, 31)):
             ix.set_one_launch(2, timeout_us=2000, inject=(kind << 28) | (phase << 16) | (block + 1))
             i1, d1 = ix.search(q, k)
             st = ix.one_launch_stats()
