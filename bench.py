@@ -677,7 +677,12 @@ def main():
             index.search_scores(q, k, lo, out=(ex[0].idx, ex[0].dist))
             ex[0].gather()
             return merge_topk_packed(ex[0].recv, ex[0].part_bytes, world, nq, k, 0)
-        selftest = selftest_against_oracle(index, q, k, lo, hi, world, rank, device, search_merged)
+        try:
+            selftest = selftest_against_oracle(index, q, k, lo, hi, world, rank, device, search_merged)
+        except SystemExit:
+            raise                       # a real mismatch: status 4, message on stderr
+        except Exception as e:          # the checker itself could not run here (no compiler for the oracle, ...): say so, do not lose the line
+            selftest = {"unavailable": repr(e)}
     for i in range(a.warmup):
         step(i)
     sync()

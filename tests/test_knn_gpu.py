@@ -698,3 +698,29 @@ def test_one_launch_search_against_the_oracle_and_its_escape_paths(cuda_device, 
             i1, d1 = ix.search(q, k)
             assert ix.one_launch_stats()["given_up"] == 0
             assert torch.equal(i0, i1) and torch.equal(d0.view(torch.int32), d1.view(torch.int32))
+
+
+def test_one_launch_search_beside_another_kernel(cuda_device):
+    """The case the escape hatch exists for: another kernel holds CUs while a one-launch search runs, so some of its workgroups are not
+    resident when the others reach a grid barrier.  A side stream keeps the device busy with large matrix products; the searches either
+    complete as one launch or give a barrier up after the (here 2 ms) timeout and finish in the completion launch -- the same bits either
+    way, and the device never hangs (every spin is bounded)."""
+    M, D, nq, k = 120_000, 128, 12_800, 30
+    bank = gi.unit_bank(M, D, seed=25); q = torch.from_numpy(gi.vit_like_queries(nq, D, seed=26)).cuda()
+    ix = HipFlatIndex(D, 0, 0); ix.add(torch.from_numpy(bank).cuda())
+    ref_i, ref_d = ix.search(q, k)
+    ix.set_one_launch(2, timeout_us=2000)
+    side = torch.cuda.Stream()
+    a = torch.randn((8192, 8192), device="cuda"); b = torch.randn((8192, 8192), device="cuda")
+    gave_up = 0
+    for rnd in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                c = a @ b
+        i1, d1 = ix.search(q, k)
+        st = ix.one_launch_stats()
+        assert st["one_launch"] == 1
+        gave_up += st["given_up"]
+        assert torch.equal(i1, ref_i) and torch.equal(d1.view(torch.int32), ref_d.view(torch.int32)), rnd
+    torch.cuda.synchronize()
+    print("one-launch searches beside a matmul stream: gave up", gave_up, "of 6")
