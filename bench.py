@@ -463,25 +463,36 @@ def selftest_against_oracle(index, q, k, lo, hi, world, rank, device, search_mer
     in-place merge produce) against the CPU chain oracle -- every rank searches ITS shard's rows with oracle.knn_chain_f32 (the checker, not
     the thing measured), the per-rank lists are gathered and merged on the host by (score descending, id ascending).  Ids AND score bits must
     agree on every rank; a mismatch ends the run with a message and a non-zero status (nothing is re-executed)."""
-    import oracle
     td = torch.distributed
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from helpers import chain_oracle_topk_chunked
     nsel = min(64, q.shape[0])
     sel = torch.linspace(0, q.shape[0] - 1, nsel, device=device).long()
     mi, md = search_merged()                                    # [nq, k] merged ids / ordering scores, identical on every rank
     got_i, got_d = mi[sel].cpu().numpy(), md[sel].cpu().numpy()
-    oracle.set_num_threads(max(1, host_cpu_budget()["cores"] // max(1, world)))
-    n_local = hi - lo
-    if n_local > 0:
-        ci, cd = chain_oracle_topk_chunked(index, q[sel], n_local, min(k, n_local))
-        ci = ci + lo
-        if ci.shape[1] < k:
-            pad = k - ci.shape[1]
-            ci = np.concatenate([ci, np.full((nsel, pad), -1, dtype=np.int64)], axis=1)
-            cd = np.concatenate([cd, np.full((nsel, pad), -np.inf, dtype=np.float32)], axis=1)
-    else:
-        ci = np.full((nsel, k), -1, dtype=np.int64); cd = np.full((nsel, k), -np.inf, dtype=np.float32)
+    # the local, fallible part first (the oracle needs its C library; a rank without it must not leave the others waiting in a collective):
+    # every rank reports whether its checker ran, and all of them go on or none
+    err, ci, cd = None, None, None
+    try:
+        import oracle
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import chain_oracle_topk_chunked
+        oracle.set_num_threads(max(1, host_cpu_budget()["cores"] // max(1, world)))
+        n_local = hi - lo
+        if n_local > 0:
+            ci, cd = chain_oracle_topk_chunked(index, q[sel], n_local, min(k, n_local))
+            ci = ci + lo
+            if ci.shape[1] < k:
+                pad = k - ci.shape[1]
+                ci = np.concatenate([ci, np.full((nsel, pad), -1, dtype=np.int64)], axis=1)
+                cd = np.concatenate([cd, np.full((nsel, pad), -np.inf, dtype=np.float32)], axis=1)
+        else:
+            ci = np.full((nsel, k), -1, dtype=np.int64); cd = np.full((nsel, k), -np.inf, dtype=np.float32)
+    except Exception as e:
+        err = repr(e)
+    failed = torch.tensor([0 if err is None else 1], device=device)
+    if world > 1:
+        td.all_reduce(failed)
+    if int(failed.item()) != 0:
+        return {"unavailable": err or "the checker could not run on another rank"}
     parts_i = [torch.empty((nsel, k), dtype=torch.int64, device=device) for _ in range(world)]
     parts_d = [torch.empty((nsel, k), dtype=torch.float32, device=device) for _ in range(world)]
     if world > 1:
@@ -677,12 +688,7 @@ def main():
             index.search_scores(q, k, lo, out=(ex[0].idx, ex[0].dist))
             ex[0].gather()
             return merge_topk_packed(ex[0].recv, ex[0].part_bytes, world, nq, k, 0)
-        try:
-            selftest = selftest_against_oracle(index, q, k, lo, hi, world, rank, device, search_merged)
-        except SystemExit:
-            raise                       # a real mismatch: status 4, message on stderr
-        except Exception as e:          # the checker itself could not run here (no compiler for the oracle, ...): say so, do not lose the line
-            selftest = {"unavailable": repr(e)}
+        selftest = selftest_against_oracle(index, q, k, lo, hi, world, rank, device, search_merged)   # exits with status 4 on a mismatch
     for i in range(a.warmup):
         step(i)
     sync()
