@@ -448,7 +448,11 @@ def e2e_leg(index, D, C, k, nq, device, n_batches):
         stages = {key: round(st[key], 3) for key in ("h2d_ms", "vit_forward_ms", "knn_k5_ms", "k6_k7_ms") if key in st}
         stages["loader_wait_ms"] = round(1e3 * st.get("loader_wait_s_total", 0.0) / max(1, n), 3)
         on_stream = {key: v for key, v in stages.items() if key in ("vit_forward_ms", "knn_k5_ms", "k6_k7_ms")}
+        gpu_ms = sum(on_stream.values())
         res[mode] = {"images_per_s": B * n / dt, "ms_per_batch": dt / n * 1e3, "batches": n, "per_batch_ms": stages,
+                     # the wall clock of a few batches also carries the one-off tail of evaluate() (confusion matrix to the host, Hungarian
+                     # matching); over a real validation set the rate tends to the batches' own GPU time
+                     "images_per_s_steady_state": B / (gpu_ms * 1e-3) if gpu_ms > 0 else None,
                      "bound_by": max(on_stream, key=on_stream.get) if on_stream else None,
                      "h2d_and_loader": "overlapped: the next batch is fetched and copied on a side stream during the current search",
                      "miou_of_random_weights": float(jac)}
