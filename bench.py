@@ -695,6 +695,7 @@ def main():
         selftest = selftest_against_oracle(index, q, k, lo, hi, world, rank, device, search_merged)   # exits with status 4 on a mismatch
     for i in range(a.warmup):
         step(i)
+        torch.cuda.synchronize(device)      # (a finished warm-up search lets the next one calibrate its per-XCD work shares: hb_index_set_xcd_weights)
     sync()
     index.set_timing(True)
     t0 = time.time()
@@ -791,7 +792,10 @@ def main():
                        "bank_rows": M, "dim": D, "k": k, "queries_per_step": nq, "classes": C,
                        "parallelism": f"bank-shard{world}" if world > 1 else "single-gpu",
                        "bank_build_s": round(t_build, 2), "schedule": index.schedule_info(),
-                       "use_fp16": bool(a.fp16), "fp16_fallback_queries": index.last_fp16_fallbacks() if a.fp16 else None},
+                       "use_fp16": bool(a.fp16), "fp16_fallback_queries": index.last_fp16_fallbacks() if a.fp16 else None,
+                       # work share per XCD group of the fp32 work list, calibrated from the workgroups' own durations during the warm-up
+                       # steps (hb_index_set_xcd_weights: the XCDs of one chip differ by 1-2 % in speed), and the calibration rounds
+                       "xcd_shares": [round(v, 4) for v in index.xcd_weights()[0]], "xcd_calibration_rounds": index.xcd_weights()[1]},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach / peak, "traffic": None,
                          "traffic_unit": "bytes/launch (L2-miss side, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE; Infinity-Cache hits included)",

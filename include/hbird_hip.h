@@ -228,6 +228,22 @@ int hb_index_one_launch_stats(hb_index_t* ix, int64_t out[8]);
 /* Diagnostics: with inject = 3 << 28 every workgroup of a one-launch search stamps the 100 MHz real-time counter (low 32 bits) at each phase
  * boundary -- out[boundary][4][workgroup]: arrival at the first barrier, its pass, floors done, pass of the second barrier. */
 int hb_index_one_launch_trace(hb_index_t* ix, uint32_t* out, int64_t max_words, int* n_boundaries, int* workgroups);
+/* Work shares per XCD.  The eight XCDs of one MI355X do not run the fp32 kNN kernel at one speed (with equal work the workgroups of the odd
+ * XCDs finish 1-2 % after those of the even ones, and a launch lasts as long as its slowest workgroup: profiles/r05/xcd_speed_stamps_
+ * headline.txt), so the work list gives group x -- the blocks equal to x mod 8, which the hardware deals to one XCD -- the share
+ * w[x] / sum(w) of every panel's pairs instead of one eighth.  Speed only: any shares give the same results.
+ * mode 0 (default) = calibrated: big fp32 searches stamp their workgroups' start and end, and the next such search turns each group's median
+ * duration into its share (one round: 2275 -> 2258 ms at 10 M x 768; never waits for the stamps; the fp16 candidate kernel keeps equal
+ * shares); 1 = equal shares; 2 = the eight shares given.  hb_index_xcd_weights: the shares in use and the calibration rounds so far.
+ * hb_schedule_plan_weighted: the host-only planner with such shares (tests). */
+int hb_index_set_xcd_weights(hb_index_t* ix, int mode, const double* w8);
+int hb_index_xcd_weights(const hb_index_t* ix, double* w8, int* rounds);
+int hb_schedule_plan_weighted(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b, int shared,
+                              const double* xcd_w8, int* segs_out, int64_t max_segs, int64_t stats[8]);
+/* Diagnostics: with hb_index_set_timing on, every workgroup of the last kNN launch (the last phase's, for a phased search) stamps the 100 MHz
+ * real-time counter when it starts and when it ends, and notes the XCD it ran on: out[block][4] = {start, end, XCC id, 0} (low 32 bits).
+ * Shows per-XCD speed differences: the launch lasts as long as its slowest workgroup. */
+int hb_index_wg_stamps(hb_index_t* ix, uint32_t* out, int max_blocks, int* workgroups);
 /* use_fp16 searches re-rank their candidates in exact fp32 arithmetic.  In the fragment tiles a bank row is 2 x D/8 sixteen-byte pieces
  * 512 B apart, so that pass pulls eight times the bytes it uses; a second, row-major fp32 copy of the bank lets it read whole lines (a
  * use_fp16 search at 300,000 x 768: 8.0 -> 6.6 ms, k = 90: 18.0 -> 12.4; results identical).  mode 0 = automatic: the copy is made at the first use_fp16

@@ -86,6 +86,8 @@ extern "C" int hb_index_free(hb_index_t* ix) {
     void* ptrs[] = {ix->tiles, ix->binit, ix->bnorm, ix->labels, ix->q_tiles, ix->q_aux, ix->state, ix->sched_dev, ix->tmp,
                     ix->tiles16, ix->q16, ix->cand, ix->bmax, ix->fb, ix->mtmp, ix->f16_flag, ix->labels16, ix->lab_flag, ix->rows32};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (ix->stamp_host) (void)hipHostFree(ix->stamp_host);
+    if (ix->stamp_ev) (void)hipEventDestroy(ix->stamp_ev);
     if (ix->ev0) (void)hipEventDestroy(ix->ev0);
     if (ix->ev1) (void)hipEventDestroy(ix->ev1);
     delete ix;
@@ -206,6 +208,36 @@ extern "C" int hb_index_one_launch_trace(hb_index_t* ix, uint32_t* out, int64_t 
     HB_HIP(hipMemcpyAsync(out, ix->ol_words_dev + (20 * 32 + (G + 31) / 32 * 32), (size_t)words * 4, hipMemcpyDeviceToHost, ix->stream));
     HB_HIP(hipStreamSynchronize(ix->stream));
     *n_boundaries = nb; *workgroups = G;
+    return 0;
+}
+extern "C" int hb_index_set_xcd_weights(hb_index_t* ix, int mode, const double* w8) {
+    if (!ix) return hb_fail("hb_index_set_xcd_weights: NULL index handle");
+    if (mode < 0 || mode > 2) return hb_fail("hb_index_set_xcd_weights: mode must be 0 (calibrated), 1 (equal shares) or 2 (the given shares)");
+    if (mode == 2 && !w8) return hb_fail("hb_index_set_xcd_weights: mode 2 needs eight shares");
+    for (int x = 0; x < 8; ++x) {
+        const double w = mode == 2 ? w8[x] : 1.0;
+        if (!(w > 0.25 && w < 4.0)) return hb_fail("hb_index_set_xcd_weights: every share must lie in (0.25, 4)");
+        ix->xcd_w[x] = w;
+    }
+    ix->xcd_balance = mode; ix->stamp_pending = 0; ix->calib_rounds = mode == 0 ? 0 : 1;
+    ix->sched = hb_schedule();
+    return 0;
+}
+extern "C" int hb_index_xcd_weights(const hb_index_t* ix, double* w8, int* rounds) {
+    if (!ix || !w8) return hb_fail("hb_index_xcd_weights: NULL pointer");
+    for (int x = 0; x < 8; ++x) w8[x] = ix->xcd_w[x];
+    if (rounds) *rounds = ix->calib_rounds;
+    return 0;
+}
+extern "C" int hb_index_wg_stamps(hb_index_t* ix, uint32_t* out, int max_blocks, int* workgroups) {
+    if (!ix || !out || !workgroups) return hb_fail("hb_index_wg_stamps: NULL pointer");
+    *workgroups = 0;
+    if (!ix->wg_stamp_dev) return 0;
+    if (ix->wg_stamp_blocks > max_blocks) return hb_fail("hb_index_wg_stamps: the buffer is too small");
+    HB_HIP(hipSetDevice(ix->device));
+    HB_HIP(hipMemcpyAsync(out, ix->wg_stamp_dev, (size_t)ix->wg_stamp_blocks * 16, hipMemcpyDeviceToHost, ix->stream));
+    HB_HIP(hipStreamSynchronize(ix->stream));
+    *workgroups = ix->wg_stamp_blocks;
     return 0;
 }
 extern "C" int hb_index_set_rerank_copy(hb_index_t* ix, int mode) {

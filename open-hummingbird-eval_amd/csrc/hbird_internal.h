@@ -60,6 +60,13 @@ struct hb_index {
     int force_cq = 0, force_cb = 0;                      // cluster shape override (0 = automatic)
     int sync_lag = -1;                                   // soft-sync lag in stages (-1 = automatic, 0 = no sync)
     int xcd_share = 0;                                   // clustered work lists: 0 = automatic, 1 = off, 2 = on (hb_index_set_cluster_sharing)
+    double xcd_w[8] = {1, 1, 1, 1, 1, 1, 1, 1};          // work share per XCD group (blocks equal mod 8): hb_index_set_xcd_weights / calibrated
+    int xcd_balance = 0;                                 // 0 = automatic (big fp32 searches calibrate the shares from their own workgroups' durations), 1 = equal shares, 2 = as set
+    unsigned* stamp_host = nullptr;                      // pinned copy of the last calibrating launch's per-block stamps ...
+    hipEvent_t stamp_ev = nullptr;                       // ... complete when this event is
+    int stamp_pending = 0;                               // blocks of that launch (0: nothing to read)
+    double stamp_w[8] = {1, 1, 1, 1, 1, 1, 1, 1};        // the shares that launch ran with
+    int calib_rounds = 0;
     const int* cl_stats_dev = nullptr;                   // {checks, spins, timeouts} of the last clustered launch (in `state`)
     // fp16 candidate mode (use_fp16): fp16 copies of the bank / query fragment tiles, candidate buffers
     int fp16 = 0, dp16 = 0;
@@ -84,6 +91,7 @@ struct hb_index {
     int ol_inject = 0;                                   // tests: make one block fail at one boundary (hb_one_launch::inject)
     const unsigned* ol_words_dev = nullptr;              // barrier words of the last one-launch search (in `state`), nullptr: it was not one
     int ol_last_phases = 0;
+    const unsigned* wg_stamp_dev = nullptr; int wg_stamp_blocks = 0;   // per-block stamps of the last timed kNN launch (hb_index_wg_stamps)
     long long small_limit = 0;                           // stages per workgroup below which a search counts as small (0 = default)
     double last_knn_ms = 0.0;                            // HIP-event time of the last knn kernel launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -17,6 +17,8 @@
 // oracle/hbird_oracle.c:orc_knn_chain_f32.  Ordering key: (score descending, row id ascending).
 #include "hbird_internal.h"
 #include <algorithm>
+#include <array>
+#include <mutex>
 #include <cstring>
 #include <map>
 
@@ -496,6 +498,58 @@ __global__ __launch_bounds__(256) void pool_floor_kernel(const float* __restrict
     pool_floor_query(state_s, cnts, pthr, qt_off, qt_slots, q, kk, klw, reinterpret_cast<float*>(smem) + (size_t)w * per_wave, gthr, lane);
 }
 
+// Per-XCD work shares, calibrated.  The eight XCDs of an MI355X do not run the fp32 kernel at one speed: with equal work the workgroups of
+// the odd XCDs finish 1-2 % after those of the even ones (profiles/r05/xcd_speed_stamps_headline.txt), and a launch lasts as long as its
+// slowest workgroup.  Big fp32 searches therefore stamp every workgroup's start and end (two stores per block), the stamps travel to pinned
+// host memory behind the launch, and the NEXT such search -- if that copy has completed; it never waits for it -- turns each XCD group's
+// median duration into its share of the work list: share_x <- share_x x (median of all / median of group x).  One round brings the groups
+// within 0.1-0.3 % of each other (10 M x 768: 2275 -> 2258 ms, 2.5 M x 768: 573.7 -> 568.4; profiles/r05/xcd_weights_iterated.txt); later
+// rounds only act on a change beyond 0.3 %.  Speed only: any shares give the same results.  The fp16 candidate kernel keeps equal shares: it
+// is power-limited, its groups' durations follow the work list's ragged ends more than the XCDs' speeds, and shares derived from them made
+// it slower (281 -> 288-297 ms).  Shares are remembered per device for indexes created later.
+static std::mutex g_xcd_mu;
+static std::map<int, std::array<double, 8>> g_xcd_known;     // device -> last calibrated shares
+static void hb_xcd_calibrate(hb_index* ix) {
+    if (ix->calib_rounds == 0 && !ix->stamp_pending) {        // a new index starts from what this device is known to need
+        std::lock_guard<std::mutex> lock(g_xcd_mu);
+        auto it = g_xcd_known.find(ix->device);
+        if (it != g_xcd_known.end()) {
+            bool differs = false;
+            for (int x = 0; x < 8; ++x) { differs = differs || ix->xcd_w[x] != it->second[x]; ix->xcd_w[x] = it->second[x]; }
+            if (differs) ix->sched = hb_schedule();
+            ix->calib_rounds = 1;
+        }
+    }
+    if (!ix->stamp_pending || !ix->stamp_ev || hipEventQuery(ix->stamp_ev) != hipSuccess) { (void)hipGetLastError(); return; }
+    const int G = ix->stamp_pending;
+    ix->stamp_pending = 0;
+    std::vector<unsigned> dur[8];
+    for (int b = 0; b < G; ++b) dur[b & 7].push_back(ix->stamp_host[4 * b + 1] - ix->stamp_host[4 * b]);     // (mod 2^32: a launch is far shorter than 43 s)
+    double med[8], all = 0.0;
+    for (int x = 0; x < 8; ++x) {
+        if (dur[x].empty()) return;
+        std::nth_element(dur[x].begin(), dur[x].begin() + dur[x].size() / 2, dur[x].end());
+        med[x] = (double)dur[x][dur[x].size() / 2];
+        if (!(med[x] > 0.0)) return;
+        all += med[x] / 8.0;
+    }
+    double w[8], mean = 0.0, change = 0.0;
+    for (int x = 0; x < 8; ++x) { w[x] = ix->stamp_w[x] * (all / med[x]); mean += w[x] / 8.0; }
+    for (int x = 0; x < 8; ++x) {
+        w[x] = std::min(1.25, std::max(0.8, w[x] / mean));
+        change = std::max(change, std::fabs(w[x] / ix->xcd_w[x] - 1.0));
+    }
+    if (change > (ix->calib_rounds < 2 ? 0.0015 : 0.003)) {
+        for (int x = 0; x < 8; ++x) ix->xcd_w[x] = w[x];
+        ix->sched = hb_schedule();                            // rebuilt with the new shares by the caller
+        std::lock_guard<std::mutex> lock(g_xcd_mu);
+        std::array<double, 8> keep;
+        for (int x = 0; x < 8; ++x) keep[x] = w[x];
+        g_xcd_known[ix->device] = keep;
+    }
+    ++ix->calib_rounds;
+}
+
 // q_tiles / q_aux must already be prepared by the caller (hb_index_search).
 int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t id_base, int64_t* out_idx, float* out_dist) {
     if (k < 1 || k > 256) return hb_fail("hb_index_search: k must be in [1, 256]");
@@ -628,6 +682,11 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     if ((long long)nqt * nbt < G || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
     const int panel = ix->force_panel > 0 ? ix->force_panel
                                           : hb_default_panel(nqt, std::min<long long>(G, (long long)nqt * nbt), tile_bytes, cq, cb);
+    // per-XCD work shares (hb_xcd_calibrate above): big fp32 searches only -- from about 100 ms of kernel per workgroup
+    const bool balance = !f16 && ix->xcd_balance != 1 && G % 8 == 0 && (long long)nqt * nbt / std::max(1, G) * ix->g8 >= 150000;
+    if (balance && ix->xcd_balance == 0) hb_xcd_calibrate(ix);
+    static const double equal_shares[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+    const double* shares = balance ? ix->xcd_w : equal_shares;
     hb_schedule& sc = ix->sched;
     // phased searches (pools only: "Phased searches" above hb_launch_knn); hb_index_set_search_options(ix, 0, ...) turns them off (A/B, tests)
     const bool phased = wide && ix->phases_on;
@@ -637,8 +696,9 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // sixteen bank streams anyway: 1.95 -> 1.62 TB) -> off there (profiles/r04/xs_*.txt)
     const bool xs = cq * cb > 1 && (ix->xcd_share == 2 || (ix->xcd_share == 0 && f16));
     const bool rebuilt = !(sc.nqt == nqt && sc.nbt == nbt && sc.panel == panel && sc.cq == cq && sc.cb == cb && sc.phased == phased &&
-                           sc.xcd_share == xs && (sc.G == G || (long long)nqt * nbt < G));
-    if (rebuilt) hb_build_schedule(nqt, nbt, G, panel, sc, cq, cb, phased, xs);
+                           sc.xcd_share == xs && (sc.G == G || (long long)nqt * nbt < G) &&
+                           (sc.xcd_w.empty() ? std::equal(shares, shares + 8, equal_shares) : std::equal(shares, shares + 8, sc.xcd_w.begin())));
+    if (rebuilt) hb_build_schedule(nqt, nbt, G, panel, sc, cq, cb, phased, xs, shares);
     // device copy of the work list: [segs][wg_off][qt_off][qt_slots][wg_member]
     const size_t b_segs = sc.segs.size() * sizeof(hb_seg), b_wg = sc.wg_off.size() * 4, b_qo = sc.qt_off.size() * 4,
                  b_qs = sc.qt_slots.size() * 4, b_wm = sc.wg_member.size() * 4;
@@ -661,11 +721,14 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     const size_t state_aux = wide ? (size_t)sc.n_slots * HB_QT * 4 : 0;   // pools: fill counts + thresholds
     const size_t floor_bytes = (size_t)nqt * HB_QT * 4 * 17;              // shared threshold floors, one per query, + 16 quota-floor keys per query
     const size_t prog_bytes = ((size_t)std::max(1, sc.n_clusters) * HB_CLUSTER_MAX + 1) * HB_CLUSTER_LINE * 4;   // progress words, a line each, + statistics
+    const size_t stamp_bytes = (size_t)sc.G * 16;                       // per-block {start, end, XCC id} stamps of the last kNN launch (diagnostics, with hb_index_set_timing)
     const size_t gb_bytes = ((size_t)HB_GB_WORDS(sc.G) + (size_t)HB_PHASE_CUTS * 4 * sc.G) * 4;   // grid-barrier words of a one-launch search (zeroed per search) + time stamps (diagnostics)
-    if (ensure_bytes(&ix->state, &ix->state_bytes, 2 * state_half + 2 * state_aux + floor_bytes + prog_bytes + gb_bytes)) return -1;
+    if (ensure_bytes(&ix->state, &ix->state_bytes, 2 * state_half + 2 * state_aux + floor_bytes + prog_bytes + gb_bytes + stamp_bytes)) return -1;
 
     knn_args a;
     memset(&a.ol, 0, sizeof(a.ol));
+    a.wg_stamp = (ix->time_kernels || (balance && ix->xcd_balance == 0)) ? reinterpret_cast<unsigned*>(ix->state + 2 * state_half + 2 * state_aux + floor_bytes + prog_bytes + gb_bytes) : nullptr;
+    ix->wg_stamp_dev = a.wg_stamp; ix->wg_stamp_blocks = sc.G;
     a.bank_tiles = ix->tiles; a.binit = ix->binit; a.q_tiles = ix->q_tiles;
     a.segs = reinterpret_cast<const hb_seg*>(ix->sched_dev);
     a.wg_off = reinterpret_cast<const int*>(ix->sched_dev + o_wg);
@@ -759,6 +822,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         float* cand_dist = reinterpret_cast<float*>(ix->cand + (size_t)nq * kc * 8);
         knn16_args h;
         memset(&h.ol, 0, sizeof(h.ol));
+        h.wg_stamp = a.wg_stamp;
         h.bank16 = reinterpret_cast<const _Float16*>(ix->tiles16); h.binit = ix->binit; h.q16 = reinterpret_cast<const _Float16*>(ix->q16); h.segs = a.segs; h.wg_off = a.wg_off; h.wg_end = a.wg_end;
         h.state_s = a.state_s; h.state_i = a.state_i; h.g16 = ix->dp16 / 16; h.k = kc; h.klw = klw;
         h.state_cnt = a.state_cnt; h.state_thr = a.state_thr; h.gthr = a.gthr;
@@ -889,6 +953,16 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         }
     }
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
+    if (balance && ix->xcd_balance == 0 && a.wg_stamp && sc.G <= 1024) {
+        // this launch's per-block stamps -> pinned host memory, read by the next big search if the copy has completed by then
+        if (!ix->stamp_host) { HB_HIP(hipHostMalloc((void**)&ix->stamp_host, 1024 * 16, hipHostMallocDefault)); HB_HIP(hipEventCreateWithFlags(&ix->stamp_ev, hipEventDisableTiming)); }
+        if (!ix->stamp_pending) {
+            HB_HIP(hipMemcpyAsync(ix->stamp_host, a.wg_stamp, (size_t)sc.G * 16, hipMemcpyDeviceToHost, s));
+            HB_HIP(hipEventRecord(ix->stamp_ev, s));
+            ix->stamp_pending = sc.G;
+            for (int x = 0; x < 8; ++x) ix->stamp_w[x] = shares[x];
+        }
+    }
     const float* qn2 = ix->q_aux;   // [nq] chain ||q||^2 (valid for L2)
     if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, pool_cnt ? a.state_thr : nullptr, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
                      reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, k, klw, id_base, out_metric,

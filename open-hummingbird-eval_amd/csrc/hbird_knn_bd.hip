@@ -68,6 +68,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
     cl_sync cs;
     if constexpr (CL) cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + BD_CLWORDS);
 
+    wg_stamp<knn_args>(0);
     [[maybe_unused]] int ol_ph = 0;   // OL: the phase being run
     if constexpr (OL) { if (!ol_enter<knn_args>(ol_ph)) return; }
   for (;;) {
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
     break;
   }
     if constexpr (CL) cl_finish(cs, a.cl_stats, w == 0, lane);
+    wg_stamp<knn_args>(1);
 }
 
 hb_knn_fn hb_knn_bd_kernel(bool wide, bool clustered, bool small, bool one_launch) {

@@ -47,6 +47,7 @@ struct knn_args {
     int* cl_stats;          // {checks, spins, timeouts} of the launch
     unsigned* qfl;          // [query][16]: quota floors of small searches (monotone keys; columns 0-6 / 8-14 per slot of the query tile, 7 the plain floor)
     hb_one_launch ol;       // phased searches in ONE launch (grid barrier + in-kernel floors): "One launch per phased search" below
+    unsigned* wg_stamp;     // diagnostics (hb_index_set_timing): [block][4] = {start, end} low words of s_memrealtime, XCC id, 0; nullptr: off
 };
 
 // A kernel argument read again from the kernarg segment at the point of use (through a laundered pointer, so that the
@@ -82,7 +83,22 @@ struct knn16_args {
     int lag;
     int* cl_stats;
     hb_one_launch ol;
+    unsigned* wg_stamp;
 };
+
+// Diagnostics: when and where a workgroup ran (per-XCD speed differences show up as the last blocks of every launch belonging to one XCD)
+template <class ARGS>
+__device__ __forceinline__ void wg_stamp(int which) {
+    unsigned* st = HB_KARG(ARGS, wg_stamp);
+    if (st == nullptr || threadIdx.x != 0) return;
+    st += 4 * blockIdx.x;
+    if (which == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        st[2] = xcc & 0xFu;
+    }
+    st[which] = (unsigned)__builtin_amdgcn_s_memrealtime();
+}
 
 // ---- soft sync of an L2-sharing cluster (hb_build_clustered) ---------------------------------------------------------
 // The members of a cluster run the same stage sequence; one L2 fill serves several of them only while they stay within

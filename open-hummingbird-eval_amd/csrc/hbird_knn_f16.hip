@@ -112,6 +112,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
     const unsigned lds_w = lds_0 + (unsigned)w * 2048u;   // this wave's two pieces of a ring slot
     cl_sync cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + F2_CLWORDS);
 
+    wg_stamp<knn16_args>(0);
     [[maybe_unused]] int ol_ph = 0;   // OL: the phase being run
     if constexpr (OL) { if (!ol_enter<knn16_args>(ol_ph)) return; }
   for (;;) {
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
     break;
   }
     cl_finish(cs, a.cl_stats, w == 0, lane);
+    wg_stamp<knn16_args>(1);
 }
 
 // Exact re-rank: one wave per query; lane j scores candidates j, j+64, ... with the fp32 chain arithmetic of the fp32

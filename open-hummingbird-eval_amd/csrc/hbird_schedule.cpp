@@ -4,6 +4,7 @@
 // lib/build/libhbird_plan_asan.so for the sanitizer leg of the CPU suite (tests/test_sanitizers_cpu.py).
 #include "hbird_schedule.h"
 #include <algorithm>
+#include <cmath>
 #include <map>
 
 #ifdef HB_PLAN_STANDALONE
@@ -120,6 +121,24 @@ static void hb_finish_schedule(hb_schedule& out, std::vector<std::vector<hb_seg>
     }
 }
 
+// Uneven shares (hb_index_set_xcd_weights).  The XCDs of one MI355X do not run at one speed: with equal work the workgroups of the odd XCDs
+// finish 1-2 % after those of the even ones (profiles/r05/xcd_speed_stamps_headline.txt: +1.3 % / -0.6 % around the median), and a launch
+// lasts as long as its slowest workgroup.  `cum[i]` = the share of a panel's units that the first i workers (logical workgroups, or clusters)
+// take together; the boundary of worker i in panel p is floor(W cum[i] + phi_p) with a per-panel dither phi_p (the golden-ratio sequence),
+// so that the rounding of one panel does not repeat in every panel (42.5 units per panel must not become 42 three hundred times).
+static std::vector<double> hb_cum_shares(int workers, int per_xcd, const std::vector<double>& xcd_w) {
+    std::vector<double> cum(workers + 1, 0.0);
+    for (int i = 0; i < workers; ++i) cum[i + 1] = cum[i] + xcd_w[std::min(7, i / std::max(1, per_xcd))];
+    for (int i = 0; i <= workers; ++i) cum[i] /= cum[workers];
+    return cum;
+}
+static long long hb_share_bound(long long W, const std::vector<double>& cum, int i, int workers, int panel_index) {
+    if (i <= 0) return 0;
+    if (i >= workers) return W;
+    const double phi = std::fmod(0.5 + 0.6180339887498949 * panel_index, 1.0);
+    return std::min<long long>(W, std::max<long long>(0, (long long)std::floor((double)W * cum[i] + phi)));
+}
+
 static void hb_build_clustered(int nqt, int nbt, int G, int panel, int cq, int cb, hb_schedule& out, bool xcd_share) {
     const int CS = cq * cb, NC = G / CS, NQG = (nqt + cq - 1) / cq;
     out.cq = cq; out.cb = cb; out.n_clusters = NC; out.xcd_share = xcd_share;
@@ -149,6 +168,9 @@ static void hb_build_clustered(int nqt, int nbt, int G, int panel, int cq, int c
     };
     const int per_xcd_c = NC / 8;
     int rot = 0;
+    // uneven shares: per cluster (plain clustered list) or per XCD range (XCD-level query sharing)
+    const std::vector<double> cum = (!out.xcd_w.empty() && !xcd_share && NC % 8 == 0) ? hb_cum_shares(NC, NC / 8, out.xcd_w) : std::vector<double>();
+    const std::vector<double> cumx = (!out.xcd_w.empty() && xcd_share) ? hb_cum_shares(8, 1, out.xcd_w) : std::vector<double>();
     for (int b0 = 0; b0 < nbt; b0 += panel) {
         const int pp = std::min(panel, nbt - b0);
         const int UB = (pp + cb - 1) / cb;        // bank groups of the panel (the last one may be partial)
@@ -161,7 +183,8 @@ static void hb_build_clustered(int nqt, int nbt, int G, int panel, int cq, int c
             // themselves need no sync for that.  The remainders of a run rotate over the clusters (balance within a tile or two).
             for (int x = 0; x < 8; ++x) {
                 long long e = (U * x) / 8;
-                const long long e1 = (U * (x + 1)) / 8;
+                long long e1 = (U * (x + 1)) / 8;
+                if (!cumx.empty()) { e = hb_share_bound(U, cumx, x, 8, b0 / panel); e1 = hb_share_bound(U, cumx, x + 1, 8, b0 / panel); }
                 while (e < e1) {
                     const int qg = (int)(e / UB), j0 = (int)(e % UB);
                     const int L = (int)std::min<long long>(UB - j0, e1 - e);
@@ -177,6 +200,7 @@ static void hb_build_clustered(int nqt, int nbt, int G, int panel, int cq, int c
         }
         for (int c = 0; c < NC; ++c) {
             long long e0 = (U * c) / NC, e1 = (U * (c + 1)) / NC;
+            if (!cum.empty()) { e0 = hb_share_bound(U, cum, c, NC, b0 / panel); e1 = hb_share_bound(U, cum, c + 1, NC, b0 / panel); }
             while (e0 < e1) {
                 const int qg = (int)(e0 / UB), j0 = (int)(e0 % UB);
                 const int cnt = (int)std::min<long long>(UB - j0, e1 - e0);
@@ -198,9 +222,14 @@ static void hb_build_clustered(int nqt, int nbt, int G, int panel, int cq, int c
     hb_finish_schedule(out, per_wg, logical_of_block, slots_of_qt);
 }
 
-void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out, int cq, int cb, bool phased, bool xcd_share) {
+void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out, int cq, int cb, bool phased, bool xcd_share, const double* xcd_w) {
     out = hb_schedule();
     out.nqt = nqt; out.nbt = nbt; out.panel = panel; out.phased = phased;
+    if (xcd_w) {
+        bool ok = true, equal = true;
+        for (int x = 0; x < 8; ++x) { ok = ok && xcd_w[x] > 0.25 && xcd_w[x] < 4.0; equal = equal && xcd_w[x] == xcd_w[0]; }
+        if (ok && !equal) out.xcd_w.assign(xcd_w, xcd_w + 8);      // (equal shares keep the exact integer split below)
+    }
     const long long total_pairs = (long long)nqt * nbt;
     if (total_pairs < G) G = (int)std::max<long long>(1, total_pairs);
     out.G = G;
@@ -228,11 +257,13 @@ void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out, int
     std::map<std::pair<int, int>, int> slot_of;   // (wg, q_tile) -> slot
     std::vector<std::vector<int>> slots_of_qt(nqt);
     std::vector<int> clock(G, 0);
+    const std::vector<double> cum = (!out.xcd_w.empty() && G % 8 == 0) ? hb_cum_shares(G, G / 8, out.xcd_w) : std::vector<double>();
     for (int b0 = 0; b0 < nbt; b0 += panel) {
         const int pp = std::min(panel, nbt - b0);
         const long long W = (long long)nqt * pp;
         for (int w = 0; w < G; ++w) {
             long long e0 = (W * w) / G, e1 = (W * (w + 1)) / G;
+            if (!cum.empty()) { e0 = hb_share_bound(W, cum, w, G, b0 / panel); e1 = hb_share_bound(W, cum, w + 1, G, b0 / panel); }
             while (e0 < e1) {
                 const int q = (int)(e0 / pp), b = (int)(e0 % pp);
                 const int cnt = (int)std::min<long long>(pp - b, e1 - e0);
@@ -276,7 +307,7 @@ void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out, int
 // Host-only: build the kNN work list for a (query tiles x bank tiles) grid without touching a GPU, for inspection
 // and tests.  segs_out receives up to max_segs rows of {block, q_tile, b_tile0, n_tiles, slot, first}.
 static int schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b, bool phased,
-                         int* segs_out, int64_t max_segs, int64_t stats[8], hb_schedule& sc, bool xcd_share = false) {
+                         int* segs_out, int64_t max_segs, int64_t stats[8], hb_schedule& sc, bool xcd_share = false, const double* xcd_w = nullptr) {
     if (!stats) return hb_fail("hb_schedule_plan: stats is NULL");
     if (nqt <= 0 || nbt <= 0 || workgroups <= 0 || d <= 0) return hb_fail("hb_schedule_plan: bad arguments");
     const int dp = (d + HB_KC - 1) / HB_KC * HB_KC;
@@ -285,7 +316,7 @@ static int schedule_plan(int nqt, int nbt, int workgroups, int panel_tiles, int 
     if (cq < 0 || cb < 0) hb_default_cluster(nqt, nbt, G, cq == -2, &cq, &cb);  // negative: the automatic shape (-1 fp16, -2 fp32 kernel)
     if (cq < 1 || cb < 1 || (long long)nqt * nbt < workgroups || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
     const int panel = panel_tiles > 0 ? panel_tiles : hb_default_panel(nqt, G, (size_t)HB_BT * dp * 4, cq, cb);
-    hb_build_schedule(nqt, nbt, workgroups, panel, sc, cq, cb, phased, xcd_share && cq * cb > 1);
+    hb_build_schedule(nqt, nbt, workgroups, panel, sc, cq, cb, phased, xcd_share && cq * cb > 1, xcd_w);
     stats[0] = sc.G; stats[1] = (int64_t)sc.segs.size(); stats[2] = sc.n_slots; stats[3] = sc.panel;
     stats[4] = sc.max_slots_per_qt; stats[5] = sc.nqt; stats[6] = sc.nbt; stats[7] = sc.cq * 16 + sc.cb;
     if (segs_out) {
@@ -322,6 +353,13 @@ extern "C" int hb_schedule_plan_phased(int nqt, int nbt, int workgroups, int pan
             for (int b = 0; b < sc.G; ++b) bounds_out[(size_t)p * sc.G + b] = sc.phase_bounds[(size_t)p * sc.G + b] - sc.wg_off[b];
     }
     return 0;
+}
+
+// hb_schedule_plan with per-XCD work shares (hb_index_set_xcd_weights): cluster_q / cluster_b as above, shared = XCD-level query sharing
+extern "C" int hb_schedule_plan_weighted(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b, int shared,
+                                         const double* xcd_w8, int* segs_out, int64_t max_segs, int64_t stats[8]) {
+    hb_schedule sc;
+    return schedule_plan(nqt, nbt, workgroups, panel_tiles, d, cluster_q, cluster_b, false, segs_out, max_segs, stats, sc, shared != 0, xcd_w8);
 }
 
 extern "C" int hb_schedule_plan_shared(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b, int phased,

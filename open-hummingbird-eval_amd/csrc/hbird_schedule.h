@@ -31,6 +31,7 @@ struct hb_schedule {
     int nqt = 0, nbt = 0, G = 0, panel = 0;
     int cq = 1, cb = 1;              // cluster shape: cq query tiles x cb interleaved bank tiles (1 x 1: no clusters)
     bool xcd_share = false;          // clusters: all clusters of an XCD walk the same query group (hb_build_clustered)
+    std::vector<double> xcd_w;       // work share per XCD group (blocks equal mod 8), empty = equal shares (hb_build_schedule)
     std::vector<hb_seg> segs;        // grouped by workgroup
     std::vector<int> wg_off;         // G+1 offsets into segs
     std::vector<int> wg_member;      // per block: cluster * HB_CLUSTER_LINE + member (progress word of the block)
@@ -45,7 +46,7 @@ struct hb_schedule {
 };
 
 void hb_build_schedule(int nqt, int nbt, int G, int panel_tiles, hb_schedule& out, int cq = 1, int cb = 1, bool phased = false,
-                       bool xcd_share = false);
+                       bool xcd_share = false, const double* xcd_w = nullptr);
 int hb_default_panel(int nqt, int G, size_t tile_bytes, int cq = 1, int cb = 1);
 // automatic cluster shape for a search (1 x 1 when clusters do not apply)
 void hb_default_cluster(int nqt, int nbt, int G, bool fp32_kernel, int* cq, int* cb);

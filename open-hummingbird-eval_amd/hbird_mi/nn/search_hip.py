@@ -290,6 +290,30 @@ class HipFlatIndex:
         keys = ["one_launch", "phases", "boundaries", "barrier1_ticks", "floor_ticks", "barrier2_ticks", "timeouts", "given_up"]
         return dict(zip(keys, [int(v) for v in out]))
 
+    def set_xcd_weights(self, mode: int = 0, w8=None):
+        """Work share per XCD group (blocks equal mod 8) of every panel of the work list (speed only, same results): mode 0 = calibrated from
+        the workgroups' own durations (default), 1 = equal shares, 2 = the eight shares `w8`."""
+        arr = None if w8 is None else (ctypes.c_double * 8)(*[float(v) for v in w8])
+        _lib.check(_lib.lib().hb_index_set_xcd_weights(self._h, int(mode), arr))
+
+    def xcd_weights(self):
+        """(the eight shares in use, calibration rounds so far)"""
+        arr = (ctypes.c_double * 8)(); r = ctypes.c_int(0)
+        _lib.check(_lib.lib().hb_index_xcd_weights(self._h, arr, ctypes.byref(r)))
+        return [float(v) for v in arr], int(r.value)
+
+    def wg_stamps(self):
+        """After a search with set_timing(True): int64 array [workgroups, 3] = (start, end) in 100 MHz ticks relative to the earliest start,
+        XCC id -- of the last kNN launch (hb_index_wg_stamps)."""
+        buf = np.zeros((1024, 4), dtype=np.uint32)
+        g = ctypes.c_int(0)
+        _lib.check(_lib.lib().hb_index_wg_stamps(self._h, _ptr(buf), 1024, ctypes.byref(g)))
+        t = buf[: g.value].astype(np.int64)
+        if t.size:
+            t0 = t[:, 0].min()
+            t[:, 0] = (t[:, 0] - t0) & 0xFFFFFFFF; t[:, 1] = (t[:, 1] - t0) & 0xFFFFFFFF
+        return t[:, :3]
+
     def one_launch_trace(self):
         """After a search with set_one_launch(inject=3 << 28): int64 array [boundaries, 4, workgroups] of 100 MHz ticks (relative to the
         earliest stamp): arrival at barrier 1, its pass, floors done, pass of barrier 2."""

@@ -724,3 +724,35 @@ def test_one_launch_search_beside_another_kernel(cuda_device):
         assert torch.equal(i1, ref_i) and torch.equal(d1.view(torch.int32), ref_d.view(torch.int32)), rnd
     torch.cuda.synchronize()
     print("one-launch searches beside a matmul stream: gave up", gave_up, "of 6")
+
+
+def test_per_xcd_work_shares_never_change_the_result(cuda_device):
+    """hb_index_set_xcd_weights: big fp32 searches give each XCD group (blocks equal mod 8) a share of the work list that follows its measured
+    speed (calibrated between searches from the workgroups' own time stamps, mode 0), equal shares (1) or given ones (2).  Speed only: ids and
+    distance bits are the same in every mode, also with wildly uneven shares and under the 2 x 4 clusters."""
+    M, D, nq, k = 2_000_000, 768, 21_904, 30
+    dev = torch.device("cuda:0")
+    ix = HipFlatIndex(D, 0, 0); ix.reserve(M)
+    g = torch.Generator(device=dev).manual_seed(77)
+    for r in range(0, M, 500_000):
+        rows = torch.randn((500_000, D), generator=g, device=dev)
+        ix.add(rows, normalize=True)
+    q = 3.0 * torch.randn((nq, D), generator=g, device=dev)
+    ix.set_xcd_weights(1)
+    ref_i, ref_d = ix.search(q, k)
+    assert ix.xcd_weights()[0] == [1.0] * 8
+    for w8, cluster in (([1.2, 0.85, 1.1, 0.9, 1.0, 1.05, 0.95, 1.15], (0, 0, -1)), ([0.9, 1.1, 0.9, 1.1, 0.9, 1.1, 0.9, 1.1], (2, 4, 16))):
+        ix.set_xcd_weights(2, w8); ix.set_cluster(*cluster)
+        i1, d1 = ix.search(q, k)
+        assert torch.equal(i1, ref_i) and torch.equal(d1.view(torch.int32), ref_d.view(torch.int32)), (w8, cluster)
+    ix.set_cluster(0, 0, -1)
+    ix.set_xcd_weights(0)
+    for _ in range(3):
+        i1, d1 = ix.search(q, k)
+        torch.cuda.synchronize()                       # (the stamps of this search have landed when the next one looks for them)
+        assert torch.equal(i1, ref_i) and torch.equal(d1.view(torch.int32), ref_d.view(torch.int32))
+    w, rounds = ix.xcd_weights()
+    assert rounds >= 1 and abs(sum(w) / 8 - 1.0) < 1e-6 and all(0.8 <= v <= 1.25 for v in w), (w, rounds)
+    print("calibrated shares", [round(v, 4) for v in w], "after", rounds, "rounds")
+    with pytest.raises(RuntimeError):
+        ix.set_xcd_weights(2, [1.0] * 7 + [9.0])

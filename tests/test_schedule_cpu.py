@@ -366,3 +366,57 @@ def test_multi_index_row_planning_without_a_gpu(monkeypatch):
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         assert search_hip.HipMultiIndex(4, 0, [0, 1], shard=True)._staged == set()
+
+
+@pytest.mark.parametrize("nqt,nbt,G,panel,cq,cb,shared", [
+    (86, 39063, 256, 0, 1, 1, 0),       # headline, plain list
+    (86, 39063, 256, 0, 2, 4, 0),       # headline, the fp32 kernel's 2 x 4 clusters
+    (86, 39063, 256, 0, 8, 1, 1),       # headline, the fp16 kernel's 8 x 1 clusters with XCD-level query sharing
+    (49, 8102, 256, 0, 1, 1, 0), (7, 1000, 64, 5, 1, 1, 0), (86, 4883, 256, 0, 2, 2, 0),
+])
+def test_weighted_work_list_invariants_and_shares(nqt, nbt, G, panel, cq, cb, shared):
+    """hb_index_set_xcd_weights: uneven work shares per XCD group (blocks equal mod 8).  Whatever the shares: every (query tile, bank tile)
+    pair exactly once, one owner and one query tile per slot, ascending bank tiles per slot -- and the groups' totals follow the shares to
+    within a fraction of a percent (the per-panel rounding is dithered, so it does not add up over 300 panels)."""
+    w = [1.006, 0.987, 1.005, 0.989, 1.004, 0.995, 1.004, 0.997]
+    stats = (ctypes.c_int64 * 8)()
+    wa = (ctypes.c_double * 8)(*w)
+    L = _lib.lib()
+    _lib.check(L.hb_schedule_plan_weighted(nqt, nbt, G, panel, 768, cq, cb, shared, wa, None, 0, stats))
+    nseg = stats[1]
+    buf = np.zeros((nseg, 10), dtype=np.int32)
+    _lib.check(L.hb_schedule_plan_weighted(nqt, nbt, G, panel, 768, cq, cb, shared, wa, buf.ctypes.data_as(ctypes.c_void_p), nseg, stats))
+    Gs = int(stats[0])
+    cover = np.zeros((nqt, nbt), dtype=np.int32)
+    per_block = np.zeros(Gs, dtype=np.int64)
+    slot_q, slot_blk, slot_last = {}, {}, {}
+    for blk, q, b0, n, slot, first, stride, tile0, next_tile0, member in buf.tolist():
+        tiles = b0 + stride * np.arange(n)
+        assert tiles[-1] < nbt
+        cover[q, tiles] += 1
+        per_block[blk] += n
+        if first:
+            assert slot not in slot_q
+            slot_q[slot] = q; slot_blk[slot] = blk
+        assert slot_q[slot] == q and slot_blk[slot] == blk
+        assert b0 > slot_last.get(slot, -1)
+        slot_last[slot] = int(tiles[-1])
+    assert (cover == 1).all()
+    # equal weights are the unweighted list, segment for segment
+    stats2 = (ctypes.c_int64 * 8)()
+    ones = (ctypes.c_double * 8)(*[1.0] * 8)
+    _lib.check(L.hb_schedule_plan_weighted(nqt, nbt, G, panel, 768, cq, cb, shared, ones, None, 0, stats2))
+    b1 = np.zeros((stats2[1], 10), dtype=np.int32); b2 = np.zeros((stats2[1], 10), dtype=np.int32)
+    _lib.check(L.hb_schedule_plan_weighted(nqt, nbt, G, panel, 768, cq, cb, shared, ones, b1.ctypes.data_as(ctypes.c_void_p), stats2[1], stats2))
+    if shared:
+        _lib.check(L.hb_schedule_plan_shared(nqt, nbt, G, panel, 768, cq, cb, 0, b2.ctypes.data_as(ctypes.c_void_p), stats2[1], stats2))
+    else:
+        _lib.check(L.hb_schedule_plan(nqt, nbt, G, panel, 768, cq, cb, b2.ctypes.data_as(ctypes.c_void_p), stats2[1], stats2))
+    assert np.array_equal(b1, b2)
+    # the groups' totals follow the shares, measured against the equal-share list (whose ragged last query group idles some members)
+    if Gs % 8 == 0 and nbt > 4000:      # (with under one pair per workgroup and panel the equal-share list itself is uneven)
+        base = np.zeros(Gs, dtype=np.int64)
+        np.add.at(base, b2[:, 0], b2[:, 3])
+        share = np.array([per_block[x::8].sum() / base[x::8].sum() for x in range(8)], dtype=np.float64)
+        want = np.array(w) / np.mean(w)
+        assert np.abs(share / want - 1.0).max() < 0.006, (share / want).tolist()
