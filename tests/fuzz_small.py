@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One-off differential fuzz of the small / medium search paths against the CPU oracle (bit-exact indices and distances):
 random shapes, both metrics, odd workgroup counts, lists and pools, fp16 mode on and off.  usage: python tests/fuzz_small.py [cases] [seed]   (lives under tests/: it uses the oracle as the checker)
-FUZZ_ONE_LAUNCH=1: phased searches as ONE launch with grid barriers (hb_index_set_one_launch(ix, 2)), with query counts that qualify."""
+FUZZ_ONE_LAUNCH=1: phased searches as ONE launch with grid barriers (hb_index_set_one_launch(ix, 2)), with query counts that qualify.
+FUZZ_XCD=1: random per-XCD work shares in [0.8, 1.25] (hb_index_set_xcd_weights(ix, 2, w8): weighted work lists), fp32 searches only."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "open-hummingbird-eval_amd"), ROOT]
@@ -18,7 +19,7 @@ for c in range(n_cases):
     k = int(rng.choice([1, 5, 30, 32, 40, 90]))
     metric = int(rng.integers(0, 2))
     G = int(rng.choice([0, 0, 17, 64, 256]))
-    fp16 = bool(rng.integers(0, 2)) and k <= 128
+    fp16 = bool(rng.integers(0, 2)) and k <= 128 and not os.environ.get("FUZZ_XCD")
     bank = rng.standard_normal((M, D), dtype=np.float32); bank /= np.linalg.norm(bank, axis=1, keepdims=True)
     if rng.integers(0, 2): bank[rng.integers(0, M, size=50)] = bank[0]          # duplicates: ties by id
     q = (3.0 * rng.standard_normal((nq, D))).astype(np.float32)
@@ -29,6 +30,7 @@ for c in range(n_cases):
     ix = HipFlatIndex(D, metric, 0); ix.add(torch.from_numpy(bank).cuda()); ix.set_fp16(fp16); ix.set_tuning(G, 0)
     ix.set_variant(variant); ix.set_cluster(*cl)
     if os.environ.get("FUZZ_ONE_LAUNCH"): ix.set_one_launch(2)
+    if os.environ.get("FUZZ_XCD"): ix.set_xcd_weights(2, rng.uniform(0.8, 1.25, size=8).tolist())
     idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
     ridx, rdist = oracle.knn_chain_f32(q, bank, k, "dot_product" if metric == 0 else "l2", 0)
     ok = np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(dist.cpu().numpy().view(np.uint32), rdist.view(np.uint32))

@@ -420,3 +420,34 @@ def test_weighted_work_list_invariants_and_shares(nqt, nbt, G, panel, cq, cb, sh
         share = np.array([per_block[x::8].sum() / base[x::8].sum() for x in range(8)], dtype=np.float64)
         want = np.array(w) / np.mean(w)
         assert np.abs(share / want - 1.0).max() < 0.006, (share / want).tolist()
+
+
+def test_weighted_work_list_random_small_shapes():
+    """Extreme shares (0.3 ... 3.5) on small and ragged shapes, every list form: still every pair exactly once, one owner and one query tile
+    per slot, ascending bank tiles, no empty segment (explicit shares apply to fp32 searches of any size: hb_index_set_xcd_weights mode 2)."""
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    for _ in range(150):
+        nqt = int(rng.integers(1, 60)); nbt = int(rng.integers(1, 900)); G = int(rng.choice([8, 16, 64, 256])); panel = int(rng.choice([0, 1, 4, 16]))
+        cq, cb = [(1, 1), (2, 2), (2, 4), (1, 1), (1, 2)][int(rng.integers(0, 5))]
+        shared = int(rng.integers(0, 2))
+        wa = (ctypes.c_double * 8)(*rng.uniform(0.3, 3.5, size=8).tolist())
+        stats = (ctypes.c_int64 * 8)()
+        if L.hb_schedule_plan_weighted(nqt, nbt, G, panel, 768, cq, cb, shared, wa, None, 0, stats) != 0:
+            continue          # (a cluster shape the planner refuses for this G)
+        nseg = stats[1]
+        buf = np.zeros((nseg, 10), dtype=np.int32)
+        _lib.check(L.hb_schedule_plan_weighted(nqt, nbt, G, panel, 768, cq, cb, shared, wa, buf.ctypes.data_as(ctypes.c_void_p), nseg, stats))
+        cover = np.zeros((nqt, nbt), dtype=np.int32)
+        slot_q, slot_blk, slot_last = {}, {}, {}
+        for blk, q, b0, n, slot, first, stride, tile0, next_tile0, member in buf.tolist():
+            assert n > 0 and q < nqt
+            tiles = b0 + stride * np.arange(n)
+            assert tiles[-1] < nbt
+            cover[q, tiles] += 1
+            if first:
+                assert slot not in slot_q
+                slot_q[slot] = q; slot_blk[slot] = blk
+            assert slot_q[slot] == q and slot_blk[slot] == blk and b0 > slot_last.get(slot, -1)
+            slot_last[slot] = int(tiles[-1])
+        assert (cover == 1).all(), (nqt, nbt, G, panel, cq, cb, shared)
