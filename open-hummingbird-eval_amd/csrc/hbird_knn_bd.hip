@@ -94,6 +94,11 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
         }
         thr = fmaxf(thr, floor_load(HB_KARG(knn_args, gthr), seg.q_tile * HB_QT + myq));
         [[maybe_unused]] bool bulk = seg.tile0 < 16;   // WIDE && COLD: loose floors at the start of a search (pool_epilogue_scan)
+        // COLD lists: which tiles exchange floors with the query tile's other slots (small_floor_*).  Every tile while floors are loose -- the
+        // first 64 tiles of the workgroup, the first 8 of a new slot --, then every 16th: the exchange costs a tile about 1 % (waves 4-7
+        // drain their run-ahead loads to read it) and the floors of a slot that has seen 16,000 rows move slowly (tools/exp_size_sweep.py).
+        auto floor_tile = [](int clock, bool first, int ti) { return clock < 64 || (first && ti < 8) || (clock & 15) == 0; };
+        [[maybe_unused]] bool fx = floor_tile(seg.tile0, seg.first, 0);
         const char* qsrc = reinterpret_cast<const char*>(a.q_tiles + ((size_t)(seg.q_tile * 8 + w) * g8) * HB_BLK);
         const int total = seg.n_tiles * g8;
         f32x16 acc[8];
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
             BD_WAIT(3, 1, bq[((U) + 1) & 3])   /* stage st + 1 has landed for me (st + 2 in flight) ... */              \
             __builtin_amdgcn_s_barrier();      /* ... and for everyone; the slot of stage st - 1 is free for st + 3 */   \
             /* small searches: this tile's floors, requested HERE so that they are older than the stage's own requests */ \
-            if constexpr (COLD && !WIDE && (U) == 0) { if (ks == BD_FLOOR_KS) small_floor_request(HB_KARG(knn_args, qfl), HB_KARG(knn_args, gthr), seg, w, lane, qf, sc); } \
+            if constexpr (COLD && !WIDE && (U) == 0) { if (ks == BD_FLOOR_KS && fx) small_floor_request(HB_KARG(knn_args, qfl), HB_KARG(knn_args, gthr), seg, w, lane, qf, sc); } \
             int slot_n = slot_c + 1; if (slot_n == BD_RING) slot_n = 0;                                                 \
             const f32x4* Ac = reinterpret_cast<const f32x4*>(smem + slot_c * BD_SLOT) + lane;                           \
             const f32x4* An = reinterpret_cast<const f32x4*>(smem + slot_n * BD_SLOT) + lane;                           \
@@ -227,10 +232,18 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
                     if (seg.first && bt == seg.b_tile0 && cold_start_needed(thr)) thr = fmaxf(thr, cold_start_threshold(acc, k));
                     // the floors requested at the tile's start (waves 4-7: behind their query fragments; waves 0-3 have passed
                     // counted waits that cover them)
-                    asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 .Lbfl_%=\n\ts_waitcnt vmcnt(0)\n.Lbfl_%=:" :: "s"(w) : "memory", "scc");
-                    thr = fmaxf(thr, small_floor_read(seg, qf, sc, lane));
+                    if (fx) {
+                        asm volatile("s_cmp_lt_u32 %0, 4\n\ts_cbranch_scc1 .Lbfl_%=\n\ts_waitcnt vmcnt(0)\n.Lbfl_%=:" :: "s"(w) : "memory", "scc");
+                        thr = fmaxf(thr, small_floor_read(seg, qf, sc, lane));
+                    }
                     list_epilogue_scan(acc, thr, lst_s, lst_i, w * 32, lane, k, (unsigned)bt);
-                    small_floor_publish(HB_KARG(knn_args, qfl), HB_KARG(knn_args, gthr), seg, lst_s, myq, k, thr, lane);
+                    if (fx) small_floor_publish(HB_KARG(knn_args, qfl), HB_KARG(knn_args, gthr), seg, lst_s, myq, k, thr, lane);
+                    {   // the next tile's turn (boundary-only fields: read again, not kept in scalars through the loop)
+                        const hb_seg* sn_ = HB_KARG(knn_args, segs) + si;
+                        asm volatile("" : "+s"(sn_));
+                        const int ti = bt + bstride - sn_->b_tile0;
+                        fx = floor_tile(sn_->tile0 + ti, sn_->first != 0, ti);
+                    }
                 } else tile_epilogue<true, false>(acc, thr, lst_s, lst_i, sc, w * 32, lane, k, (unsigned)bt);
                 ks = 0;
                 bt += bstride; cpar ^= 1;

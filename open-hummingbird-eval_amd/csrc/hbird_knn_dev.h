@@ -615,7 +615,8 @@ __device__ __forceinline__ void floor_publish(unsigned* gthr, int q, float thr) 
 
 // ---- per-tile floors of small searches (fewer than ~16 k stages per workgroup) ----------------------------------------------
 // A slot sees few rows there (37 tiles at 50,176 x 384) and would insert several times as much on its own bound, so the slots of
-// a query tile exchange floors every TILE, not only at the end of a segment.
+// a query tile exchange floors every TILE, not only at the end of a segment (hbird_knn_bd.hip: every tile while floors are loose, every
+// 16th afterwards -- an exchange costs a tile about 1 %).
 //  * Plain floor: the maximum of the slots' k-th bests (atomic max of a monotone key) -- the k-th best of ONE slot's share.
 //  * QUOTA floors (query tiles with up to seven slots): the slots see disjoint rows, so if each of the S slots knows
 //    c = ceil(k / S) rows that reach v_i, S * c >= k rows reach min v_i: every slot publishes its c-th best (a column of its own,
