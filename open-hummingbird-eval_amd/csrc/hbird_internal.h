@@ -66,6 +66,7 @@ struct hb_index {
     hipEvent_t stamp_ev = nullptr;                       // ... complete when this event is
     int stamp_pending = 0;                               // blocks of that launch (0: nothing to read)
     double stamp_w[8] = {1, 1, 1, 1, 1, 1, 1, 1};        // the shares that launch ran with
+    double stamp_frac = 1.0;                             // ... and its part of the search's work (phased searches stamp their LAST launch)
     int calib_rounds = 0;
     const int* cl_stats_dev = nullptr;                   // {checks, spins, timeouts} of the last clustered launch (in `state`)
     // fp16 candidate mode (use_fp16): fp16 copies of the bank / query fragment tiles, candidate buffers

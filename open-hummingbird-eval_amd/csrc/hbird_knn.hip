@@ -534,7 +534,8 @@ static void hb_xcd_calibrate(hb_index* ix) {
         all += med[x] / 8.0;
     }
     double w[8], mean = 0.0, change = 0.0;
-    for (int x = 0; x < 8; ++x) { w[x] = ix->stamp_w[x] * (all / med[x]); mean += w[x] / 8.0; }
+    // (a duration that is off by e in a launch holding the part f of the work is mended by e x f of the whole share)
+    for (int x = 0; x < 8; ++x) { w[x] = ix->stamp_w[x] * (1.0 + ix->stamp_frac * (all / med[x] - 1.0)); mean += w[x] / 8.0; }
     for (int x = 0; x < 8; ++x) {
         w[x] = std::min(1.25, std::max(0.8, w[x] / mean));
         change = std::max(change, std::fabs(w[x] / ix->xcd_w[x] - 1.0));
@@ -963,6 +964,9 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
             HB_HIP(hipEventRecord(ix->stamp_ev, s));
             ix->stamp_pending = sc.G;
             for (int x = 0; x < 8; ++x) ix->stamp_w[x] = shares[x];
+            // a phased search: the cuts are common clocks, so a group's extra share is all in this last launch -- its part of the work
+            const double per_wg = (double)nqt * (double)nbt / std::max(1, sc.G);
+            ix->stamp_frac = n_phases > 1 && per_wg > 0.0 ? std::min(1.0, std::max(0.25, 1.0 - (double)sc.phase_clock.back() / per_wg)) : 1.0;
         }
     }
     const float* qn2 = ix->q_aux;   // [nq] chain ||q||^2 (valid for L2)
