@@ -557,7 +557,13 @@ def claim_stdout():
         os.dup2(2, 1)
 
 
+_T_PROCESS = time.time()
+
+
 def emit(res):
+    # whole run of this process, imports excluded: the timed steps are ms_per_step x steps of it, the rest is the bank build, the warm-up
+    # and the reported-only legs (use_fp16, end to end, counter passes, CPU baseline)
+    res["wall_s"] = round(time.time() - _T_PROCESS, 1)
     sys.stdout.flush()
     os.write(_JSON_FD if _JSON_FD is not None else 1, (json.dumps(res) + "\n").encode())
 
