@@ -2,6 +2,8 @@
 """One-off differential fuzz of the small / medium search paths against the CPU oracle (bit-exact indices and distances):
 random shapes, both metrics, odd workgroup counts, lists and pools, fp16 mode on and off.  usage: python tests/fuzz_small.py [cases] [seed]   (lives under tests/: it uses the oracle as the checker)
 FUZZ_ONE_LAUNCH=1: phased searches as ONE launch with grid barriers (hb_index_set_one_launch(ix, 2)), with query counts that qualify.
+FUZZ_MID=1: few workgroups (8 / 16) on 300 k - 700 k rows at D = 384 / 768, k <= 32: 120 k - 400 k stages per workgroup, the small-search LIST kernel with its
+quota-floor exchange (the default cases never reach it: they run on pools).
 FUZZ_XCD=1: random per-XCD work shares in [0.8, 1.25] (hb_index_set_xcd_weights(ix, 2, w8): weighted work lists), fp32 searches only."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,8 +20,10 @@ for c in range(n_cases):
     nq = int(rng.integers(1, 3000)) if not os.environ.get("FUZZ_ONE_LAUNCH") else int(rng.integers(6000, 20000))
     k = int(rng.choice([1, 5, 30, 32, 40, 90]))
     metric = int(rng.integers(0, 2))
-    G = int(rng.choice([0, 0, 17, 64, 256]))
-    fp16 = bool(rng.integers(0, 2)) and k <= 128 and not os.environ.get("FUZZ_XCD")
+    if os.environ.get("FUZZ_MID"):
+        D = int(rng.choice([384, 768])); M = int(rng.integers(300_000, 700_000)); nq = int(rng.integers(1000, 2300)); k = int(rng.choice([1, 5, 8, 30, 32]))
+    G = int(rng.choice([0, 0, 17, 64, 256])) if not os.environ.get("FUZZ_MID") else int(rng.choice([8, 16]))
+    fp16 = bool(rng.integers(0, 2)) and k <= 128 and not os.environ.get("FUZZ_XCD") and not os.environ.get("FUZZ_MID")
     bank = rng.standard_normal((M, D), dtype=np.float32); bank /= np.linalg.norm(bank, axis=1, keepdims=True)
     if rng.integers(0, 2): bank[rng.integers(0, M, size=50)] = bank[0]          # duplicates: ties by id
     q = (3.0 * rng.standard_normal((nq, D))).astype(np.float32)
@@ -35,6 +39,6 @@ for c in range(n_cases):
     ridx, rdist = oracle.knn_chain_f32(q, bank, k, "dot_product" if metric == 0 else "l2", 0)
     ok = np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(dist.cpu().numpy().view(np.uint32), rdist.view(np.uint32))
     bad += not ok
-    print(f"case {c}: M {M} D {D} nq {nq} k {k} metric {metric} G {G} fp16 {fp16} variant {variant} cluster {cl} -> {'ok' if ok else 'MISMATCH'} {ix.schedule_info()['slots']} slots one_launch {ix.one_launch_stats()['one_launch']} given_up {ix.one_launch_stats()['given_up']}", flush=True)
+    print(f"case {c}: M {M} D {D} nq {nq} k {k} metric {metric} G {G} fp16 {fp16} variant {variant} cluster {cl} -> {'ok' if ok else 'MISMATCH'} {ix.schedule_info()['slots']} slots, {(lambda i: i['query_tiles'] * i['bank_tiles'] // max(1, i['workgroups']) * ((D + 7) // 8))(ix.schedule_info())} stages per workgroup, one_launch {ix.one_launch_stats()['one_launch']} given_up {ix.one_launch_stats()['given_up']}", flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
