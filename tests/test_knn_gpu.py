@@ -756,3 +756,28 @@ def test_per_xcd_work_shares_never_change_the_result(cuda_device):
     print("calibrated shares", [round(v, 4) for v in w], "after", rounds, "rounds")
     with pytest.raises(RuntimeError):
         ix.set_xcd_weights(2, [1.0] * 7 + [9.0])
+
+
+@pytest.mark.parametrize("D,k,metric,variant", [(768, 30, "dot_product", 0), (384, 8, "l2", 0), (768, 32, "dot_product", 4)])
+def test_small_search_list_kernel_against_the_oracle(cuda_device, D, k, metric, variant):
+    """Searches of 120 k - 400 k stages per workgroup run on the small-search LIST kernel (cold start, register-queue insertions, quota floors
+    exchanged every tile at first and every 16th later: hbird_knn_bd.hip; variant 4: the LDS-staged form).  With 21,904 queries that is a
+    1.25 - 3 M-row bank; here eight workgroups reach the same stage count on 500 k rows, so that the oracle can check EVERY query, twice
+    (other floors arrive at other times: the bits must not care)."""
+    dev = torch.device("cuda:0")
+    M, nq = 500_000 if D == 768 else 800_000, 2048
+    rng = np.random.default_rng(77 + D + k)
+    bank = rng.standard_normal((M, D), dtype=np.float32); bank /= np.linalg.norm(bank, axis=1, keepdims=True)
+    bank[rng.integers(0, M, size=64)] = bank[5]                   # ties by id
+    q = (3.0 * rng.standard_normal((nq, D))).astype(np.float32)
+    ix = HipFlatIndex(D, 0 if metric == "dot_product" else 1, 0)
+    ix.add(torch.from_numpy(bank).to(dev)); ix.set_tuning(8, 0); ix.set_variant(variant)
+    qd = torch.from_numpy(q).to(dev)
+    idx, dist = ix.search(qd, k)
+    info = ix.schedule_info()
+    stages = info["query_tiles"] * info["bank_tiles"] // info["workgroups"] * (D // 8)
+    assert 120_000 <= stages < 400_000 and tuple(info["cluster"]) == (1, 1), (stages, info)
+    _check_exact(idx, dist, q, bank, k, metric)
+    for _ in range(3):
+        idx2, dist2 = ix.search(qd, k)
+        assert torch.equal(idx, idx2) and torch.equal(dist, dist2)
