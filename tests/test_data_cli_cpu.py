@@ -89,6 +89,9 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in hbird_hip.h but not exported by libhbird_hip.so"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    # ... and INTEGRATION.md's entry-point map (C ABI <-> reference) names every one of them
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert not [n for n in sorted(declared) if n not in doc], "entries missing from INTEGRATION.md's map"
     assert _lib.device_count() == 0 or _lib.device_count() > 0
 
 
