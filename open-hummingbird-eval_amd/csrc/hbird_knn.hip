@@ -683,10 +683,11 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     if ((long long)nqt * nbt < G || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
     const int panel = ix->force_panel > 0 ? ix->force_panel
                                           : hb_default_panel(nqt, std::min<long long>(G, (long long)nqt * nbt), tile_bytes, cq, cb);
-    // per-XCD work shares (hb_xcd_calibrate above): calibrated for big fp32 searches only -- from about 100 ms of kernel per workgroup;
+    // per-XCD work shares (hb_xcd_calibrate above): calibrated for fp32 searches from 30,000 stages per workgroup (30-60 ms of kernel; from 150,000 until late in
+    // round 5: cfg-2's 2 M x 384 bank went without, 135.3 -> 134.7 ms with; phased searches gain in their last phase only);
     // shares given by the caller (mode 2) apply to fp32 searches of any size (tests/fuzz_small.py FUZZ_XCD=1)
     const bool balance = !f16 && G % 8 == 0 &&
-                         (ix->xcd_balance == 2 || (ix->xcd_balance == 0 && (long long)nqt * nbt / std::max(1, G) * ix->g8 >= 150000));
+                         (ix->xcd_balance == 2 || (ix->xcd_balance == 0 && (long long)nqt * nbt / std::max(1, G) * ix->g8 >= 30000));
     if (balance && ix->xcd_balance == 0) hb_xcd_calibrate(ix);
     static const double equal_shares[8] = {1, 1, 1, 1, 1, 1, 1, 1};
     const double* shares = balance ? ix->xcd_w : equal_shares;

@@ -42,7 +42,7 @@ for path in libs:
 res = {p: [] for p in libs}
 ROUND1 = 2 if os.environ.get("AB_MS2") else 1
 outs = {}
-for rnd in range(4):
+for rnd in range(int(os.environ.get("AB_ROUNDS", "4"))):
     for path, L, h in handles:
         idx = torch.empty((nq, k), dtype=torch.int64, device=dev); dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
         assert L.hb_index_search(h, ctypes.c_void_p(q.data_ptr()), nq, k, 0, ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(dist.data_ptr()), 1) == 0, L.hb_last_error()
