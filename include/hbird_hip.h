@@ -235,7 +235,8 @@ int hb_index_one_launch_trace(hb_index_t* ix, uint32_t* out, int64_t max_words, 
  * mode 0 (default) = calibrated: big fp32 searches stamp their workgroups' start and end, and the next such search turns each group's median
  * duration into its share (one round: 2275 -> 2258 ms at 10 M x 768; never waits for the stamps; the fp16 candidate kernel keeps equal
  * shares); 1 = equal shares; 2 = the eight shares given (fp32 searches of any size).  hb_index_xcd_weights: the shares in use and the calibration rounds so far.
- * hb_schedule_plan_weighted: the host-only planner with such shares (tests). */
+ * hb_schedule_plan_weighted: the host-only planner with such shares (tests; shared bit 0 = XCD-level query sharing, bit 1 = a phased list,
+ * whose cuts follow the shares). */
 int hb_index_set_xcd_weights(hb_index_t* ix, int mode, const double* w8);
 int hb_index_xcd_weights(const hb_index_t* ix, double* w8, int* rounds);
 int hb_schedule_plan_weighted(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b, int shared,

@@ -965,9 +965,10 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
             HB_HIP(hipEventRecord(ix->stamp_ev, s));
             ix->stamp_pending = sc.G;
             for (int x = 0; x < 8; ++x) ix->stamp_w[x] = shares[x];
-            // a phased search: the cuts are common clocks, so a group's extra share is all in this last launch -- its part of the work
+            // a phased search stamps its last launch.  Cuts that follow the shares (long lists, hb_finish_schedule) make it a fair sample; with
+            // common cuts a group's extra share is all in that launch -- its part of the work
             const double per_wg = (double)nqt * (double)nbt / std::max(1, sc.G);
-            ix->stamp_frac = n_phases > 1 && per_wg > 0.0 ? std::min(1.0, std::max(0.25, 1.0 - (double)sc.phase_clock.back() / per_wg)) : 1.0;
+            ix->stamp_frac = n_phases > 1 && !sc.cuts_scaled && per_wg > 0.0 ? std::min(1.0, std::max(0.25, 1.0 - (double)sc.phase_clock.back() / per_wg)) : 1.0;
         }
     }
     const float* qn2 = ix->q_aux;   // [nq] chain ||q||^2 (valid for L2)

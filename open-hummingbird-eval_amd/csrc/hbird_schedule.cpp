@@ -76,11 +76,33 @@ static void hb_finish_schedule(hb_schedule& out, std::vector<std::vector<hb_seg>
     const int n_cuts = (int)out.phase_clock.size();
     std::vector<std::vector<int>> rel(n_cuts, std::vector<int>(G, 0));   // per cut and logical workgroup: index of the first segment at or beyond it
     if (n_cuts) {
+        // Uneven shares (hb_cum_shares): a worker that is dealt 1 % more pairs has its cuts 1 % later, so that every phase -- not only the
+        // last one -- is as long for the fast XCDs as for the slow ones.  A worker = CS consecutive logical workgroups (a cluster: one clock).
+        const int CS = std::max(1, out.cq * out.cb);
+        std::vector<double> scale(G, 1.0);
+        if (!out.xcd_w.empty() && G % CS == 0) {
+            std::vector<double> end(G / CS, 0.0);
+            double mean = 0.0;
+            for (int w = 0; w < G; ++w)
+                if (!per_wg[w].empty()) end[w / CS] = std::max(end[w / CS], (double)(per_wg[w].back().tile0 + per_wg[w].back().n_tiles));
+            for (double e : end) mean += e / (double)end.size();
+            // (from 1,000 pairs per workgroup: below, a cut moved by one tile is a bigger error than the skew it mends -- 600 k x 768 x 12,544
+            // queries, 448 pairs: 78.3 -> 78.6 ms with moved cuts; 2 M x 384, 1,551 pairs: 135.4 -> 134.9; 10 M x 768 k = 90: 2265 -> 2255)
+            if (mean >= 1000.0) {
+                for (int w = 0; w < G; ++w) scale[w] = end[w / CS] > 0.0 ? end[w / CS] / mean : 1.0;
+                out.cuts_scaled = true;
+            }
+        }
+        std::vector<int> cuts(n_cuts);
         for (int w = 0; w < G; ++w) {
+            for (int p = 0; p < n_cuts; ++p) {
+                cuts[p] = std::max(1, (int)std::lround((double)out.phase_clock[p] * scale[w]));
+                if (p && cuts[p] <= cuts[p - 1]) cuts[p] = cuts[p - 1] + 1;
+            }
             std::vector<hb_seg> v;
             v.reserve(per_wg[w].size() + n_cuts);
             for (hb_seg sg : per_wg[w]) {
-                for (int t : out.phase_clock)
+                for (int t : cuts)
                     if (t > sg.tile0 && t < sg.tile0 + sg.n_tiles) {
                         hb_seg head = sg;
                         head.n_tiles = t - sg.tile0;
@@ -92,7 +114,7 @@ static void hb_finish_schedule(hb_schedule& out, std::vector<std::vector<hb_seg>
             per_wg[w].swap(v);
             for (int p = 0; p < n_cuts; ++p) {
                 int i = 0;
-                while (i < (int)per_wg[w].size() && per_wg[w][i].tile0 < out.phase_clock[p]) ++i;
+                while (i < (int)per_wg[w].size() && per_wg[w][i].tile0 < cuts[p]) ++i;
                 rel[p][w] = i;
             }
         }
@@ -355,11 +377,12 @@ extern "C" int hb_schedule_plan_phased(int nqt, int nbt, int workgroups, int pan
     return 0;
 }
 
-// hb_schedule_plan with per-XCD work shares (hb_index_set_xcd_weights): cluster_q / cluster_b as above, shared = XCD-level query sharing
+// hb_schedule_plan with per-XCD work shares (hb_index_set_xcd_weights): cluster_q / cluster_b as above, shared bit 0 = XCD-level query
+// sharing, bit 1 = a phased list (its cuts follow the shares)
 extern "C" int hb_schedule_plan_weighted(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b, int shared,
                                          const double* xcd_w8, int* segs_out, int64_t max_segs, int64_t stats[8]) {
     hb_schedule sc;
-    return schedule_plan(nqt, nbt, workgroups, panel_tiles, d, cluster_q, cluster_b, false, segs_out, max_segs, stats, sc, shared != 0, xcd_w8);
+    return schedule_plan(nqt, nbt, workgroups, panel_tiles, d, cluster_q, cluster_b, (shared & 2) != 0, segs_out, max_segs, stats, sc, (shared & 1) != 0, xcd_w8);
 }
 
 extern "C" int hb_schedule_plan_shared(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b, int phased,

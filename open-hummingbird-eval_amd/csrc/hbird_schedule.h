@@ -36,7 +36,8 @@ struct hb_schedule {
     std::vector<int> wg_off;         // G+1 offsets into segs
     std::vector<int> wg_member;      // per block: cluster * HB_CLUSTER_LINE + member (progress word of the block)
     bool phased = false;             // pool searches: the segment lists are cut at phase_clock (hb_finish_schedule) ...
-    std::vector<int> phase_clock;    // ... clock values (tiles dealt per workgroup) where a phase ends ...
+    std::vector<int> phase_clock;    // ... clock values (tiles dealt per workgroup; x the worker's share with uneven shares) where a phase ends ...
+    bool cuts_scaled = false;        // ... (true: the cuts of this list follow the workers' shares, hb_finish_schedule) ...
     std::vector<int> phase_bounds;   // ... [cuts][G]: per block the first segment at or beyond each of them
     std::vector<int> qt_off;         // nqt+1 offsets into qt_slots
     std::vector<int> qt_slots;       // slots that hold partial lists of each query tile

@@ -451,3 +451,35 @@ def test_weighted_work_list_random_small_shapes():
             assert slot_q[slot] == q and slot_blk[slot] == blk and b0 > slot_last.get(slot, -1)
             slot_last[slot] = int(tiles[-1])
         assert (cover == 1).all(), (nqt, nbt, G, panel, cq, cb, shared)
+
+
+@pytest.mark.parametrize("nqt,nbt,G,panel,cq,cb", [(49, 8102, 256, 0, 1, 1), (86, 39063, 256, 128, 1, 1), (86, 19532, 256, 128, 2, 4), (49, 196, 256, 0, 1, 1)])
+def test_phased_list_with_uneven_shares(nqt, nbt, G, panel, cq, cb):
+    """A phased list (pool searches) under uneven XCD shares: the cuts follow the shares (a worker with 1 % more pairs has its cuts 1 % later), and
+    still every pair exactly once, one owner per slot, ascending bank tiles per slot, every workgroup's clock strictly increasing."""
+    L = _lib.lib()
+    w = [1.012, 0.985, 1.01, 0.988, 1.008, 0.992, 1.006, 0.999]
+    wa = (ctypes.c_double * 8)(*w)
+    stats = (ctypes.c_int64 * 8)()
+    _lib.check(L.hb_schedule_plan_weighted(nqt, nbt, G, panel, 384, cq, cb, 2, wa, None, 0, stats))
+    nseg = stats[1]
+    buf = np.zeros((nseg, 10), dtype=np.int32)
+    _lib.check(L.hb_schedule_plan_weighted(nqt, nbt, G, panel, 384, cq, cb, 2, wa, buf.ctypes.data_as(ctypes.c_void_p), nseg, stats))
+    cover = np.zeros((nqt, nbt), dtype=np.int32)
+    slot_q, slot_blk, slot_last, clock = {}, {}, {}, {}
+    for blk, q, b0, n, slot, first, stride, tile0, next_tile0, member in buf.tolist():
+        assert n > 0
+        tiles = b0 + stride * np.arange(n)
+        cover[q, tiles] += 1
+        if slot not in slot_q:
+            assert first
+            slot_q[slot] = q; slot_blk[slot] = blk
+        assert slot_q[slot] == q and slot_blk[slot] == blk and b0 > slot_last.get(slot, -1)
+        slot_last[slot] = int(tiles[-1])
+        assert tile0 >= clock.get(blk, 0)
+        clock[blk] = tile0 + n
+    assert (cover == 1).all()
+    # the unweighted phased list has (many) more segments than the unphased one: the cuts are there
+    s0 = (ctypes.c_int64 * 8)(); s1 = (ctypes.c_int64 * 8)()
+    _lib.check(L.hb_schedule_plan_weighted(nqt, nbt, G, panel, 384, cq, cb, 0, wa, None, 0, s0))
+    assert stats[1] > s0[1]
