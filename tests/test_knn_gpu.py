@@ -754,6 +754,13 @@ def test_per_xcd_work_shares_never_change_the_result(cuda_device):
     w, rounds = ix.xcd_weights()
     assert rounds >= 1 and abs(sum(w) / 8 - 1.0) < 1e-6 and all(0.8 <= v <= 1.25 for v in w), (w, rounds)
     print("calibrated shares", [round(v, 4) for v in w], "after", rounds, "rounds")
+    # a PHASED search on a long list (k = 90: pools; 2,600 pairs per workgroup): its phase cuts follow the shares (hb_finish_schedule)
+    ix.set_xcd_weights(1)
+    ref_i, ref_d = ix.search(q[:12_544], 90)
+    for w8 in ([1.2, 0.85, 1.1, 0.9, 1.0, 1.05, 0.95, 1.15], [0.97, 1.03, 0.98, 1.02, 0.99, 1.01, 1.0, 1.0]):
+        ix.set_xcd_weights(2, w8)
+        i1, d1 = ix.search(q[:12_544], 90)
+        assert torch.equal(i1, ref_i) and torch.equal(d1.view(torch.int32), ref_d.view(torch.int32)), w8
     with pytest.raises(RuntimeError):
         ix.set_xcd_weights(2, [1.0] * 7 + [9.0])
 
