@@ -740,7 +740,8 @@ def main():
 
         def timed_leg(n_steps=3):
             """n_steps whole N-rank steps (search + exchange) of the current index settings: (max-over-ranks ms per step, this rank's kNN ms)."""
-            step(0); sync()
+            for _ in range(5):      # (warm-up; finished searches let the next ones calibrate the per-XCD work shares)
+                step(0); sync()
             index.set_timing(True)
             t1 = time.time(); km = []
             for i in range(n_steps):
@@ -853,7 +854,8 @@ def main():
             # extra, not the headline: the same step in use_fp16 mode (fp16 candidate pass + certified exact fp32
             # re-rank; returns the identical bits, see DESIGN.md, `use_fp16`)
             index.set_fp16(True)
-            index.search_aggregate(q, k, beta=0.02); torch.cuda.synchronize(device)
+            for _ in range(6):      # (finished warm-up searches let the next ones calibrate the fp16 kernel's per-XCD work shares)
+                index.search_aggregate(q, k, beta=0.02); torch.cuda.synchronize(device)
             index.set_timing(True)
             t1 = time.time()
             k16 = []
@@ -867,6 +869,7 @@ def main():
                                     "fallback_queries": index.last_fp16_fallbacks(),
                                     "candidate_kernel_ms": float(np.mean(k16)),
                                     "candidate_kernel_frac_of_fp16_mfma_peak": flops / (float(np.mean(k16)) * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
+                                    "xcd_shares": [round(v, 4) for v in index.xcd_weights(True)[0]],
                                     "note": "certified-exact fast mode, same outputs as the fp32 search"}
             index.set_fp16(False)
         if world == 1 and not dist_on and not a.no_e2e:

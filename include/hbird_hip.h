@@ -232,13 +232,15 @@ int hb_index_one_launch_trace(hb_index_t* ix, uint32_t* out, int64_t max_words, 
  * XCDs finish 1-2 % after those of the even ones, and a launch lasts as long as its slowest workgroup: profiles/r05/xcd_speed_stamps_
  * headline.txt), so the work list gives group x -- the blocks equal to x mod 8, which the hardware deals to one XCD -- the share
  * w[x] / sum(w) of every panel's pairs instead of one eighth.  Speed only: any shares give the same results.
- * mode 0 (default) = calibrated: big fp32 searches stamp their workgroups' start and end, and the next such search turns each group's median
- * duration into its share (one round: 2275 -> 2258 ms at 10 M x 768; never waits for the stamps; the fp16 candidate kernel keeps equal
- * shares); 1 = equal shares; 2 = the eight shares given (fp32 searches of any size).  hb_index_xcd_weights: the shares in use and the calibration rounds so far.
+ * mode 0 (default) = calibrated: searches from about 30 ms of fp32 kernel stamp their workgroups' start and end, and the next such search turns
+ * each group's median duration into its share (2275 -> 2258 ms at 10 M x 768; never waits for the stamps).  The fp32 kernels and the fp16
+ * candidate kernel (274 -> 270 ms) calibrate shares of their own; a phased search's cuts follow the shares.  1 = equal shares; 2 = the eight
+ * shares given (searches of any size, both families).  hb_index_xcd_weights: the shares in use by the fp32 kernels (fp16_kernel = 0) or the
+ * fp16 candidate kernel (1) and the calibration rounds so far.
  * hb_schedule_plan_weighted: the host-only planner with such shares (tests; shared bit 0 = XCD-level query sharing, bit 1 = a phased list,
  * whose cuts follow the shares). */
 int hb_index_set_xcd_weights(hb_index_t* ix, int mode, const double* w8);
-int hb_index_xcd_weights(const hb_index_t* ix, double* w8, int* rounds);
+int hb_index_xcd_weights(const hb_index_t* ix, int fp16_kernel, double* w8, int* rounds);
 int hb_schedule_plan_weighted(int nqt, int nbt, int workgroups, int panel_tiles, int d, int cluster_q, int cluster_b, int shared,
                               const double* xcd_w8, int* segs_out, int64_t max_segs, int64_t stats[8]);
 /* Diagnostics: with hb_index_set_timing on, every workgroup of the last kNN launch (the last phase's, for a phased search) stamps the 100 MHz

@@ -86,8 +86,7 @@ extern "C" int hb_index_free(hb_index_t* ix) {
     void* ptrs[] = {ix->tiles, ix->binit, ix->bnorm, ix->labels, ix->q_tiles, ix->q_aux, ix->state, ix->sched_dev, ix->tmp,
                     ix->tiles16, ix->q16, ix->cand, ix->bmax, ix->fb, ix->mtmp, ix->f16_flag, ix->labels16, ix->lab_flag, ix->rows32};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    if (ix->stamp_host) (void)hipHostFree(ix->stamp_host);
-    if (ix->stamp_ev) (void)hipEventDestroy(ix->stamp_ev);
+    for (auto& c : ix->xcal) { if (c.stamp_host) (void)hipHostFree(c.stamp_host); if (c.stamp_ev) (void)hipEventDestroy(c.stamp_ev); }
     if (ix->ev0) (void)hipEventDestroy(ix->ev0);
     if (ix->ev1) (void)hipEventDestroy(ix->ev1);
     delete ix;
@@ -217,16 +216,18 @@ extern "C" int hb_index_set_xcd_weights(hb_index_t* ix, int mode, const double* 
     for (int x = 0; x < 8; ++x) {
         const double w = mode == 2 ? w8[x] : 1.0;
         if (!(w > 0.25 && w < 4.0)) return hb_fail("hb_index_set_xcd_weights: every share must lie in (0.25, 4)");
-        ix->xcd_w[x] = w;
+        ix->xcal[0].w[x] = w; ix->xcal[1].w[x] = w;
     }
-    ix->xcd_balance = mode; ix->stamp_pending = 0; ix->calib_rounds = mode == 0 ? 0 : 1;
+    ix->xcd_balance = mode;
+    for (auto& c : ix->xcal) { c.stamp_pending = 0; c.rounds = mode == 0 ? 0 : 1; }
     ix->sched = hb_schedule();
     return 0;
 }
-extern "C" int hb_index_xcd_weights(const hb_index_t* ix, double* w8, int* rounds) {
+extern "C" int hb_index_xcd_weights(const hb_index_t* ix, int fp16_kernel, double* w8, int* rounds) {
     if (!ix || !w8) return hb_fail("hb_index_xcd_weights: NULL pointer");
-    for (int x = 0; x < 8; ++x) w8[x] = ix->xcd_w[x];
-    if (rounds) *rounds = ix->calib_rounds;
+    const hb_index::xcd_cal& c = ix->xcal[fp16_kernel ? 1 : 0];
+    for (int x = 0; x < 8; ++x) w8[x] = c.w[x];
+    if (rounds) *rounds = c.rounds;
     return 0;
 }
 extern "C" int hb_index_wg_stamps(hb_index_t* ix, uint32_t* out, int max_blocks, int* workgroups) {

@@ -60,14 +60,18 @@ struct hb_index {
     int force_cq = 0, force_cb = 0;                      // cluster shape override (0 = automatic)
     int sync_lag = -1;                                   // soft-sync lag in stages (-1 = automatic, 0 = no sync)
     int xcd_share = 0;                                   // clustered work lists: 0 = automatic, 1 = off, 2 = on (hb_index_set_cluster_sharing)
-    double xcd_w[8] = {1, 1, 1, 1, 1, 1, 1, 1};          // work share per XCD group (blocks equal mod 8): hb_index_set_xcd_weights / calibrated
+    // work shares per XCD group (blocks equal mod 8): hb_index_set_xcd_weights / calibrated from the workgroups' own time stamps.
+    // Two families with shares of their own: [0] the fp32 kernels, [1] the fp16 candidate kernel (power-limited: its XCDs differ by other amounts)
+    struct xcd_cal {
+        double w[8] = {1, 1, 1, 1, 1, 1, 1, 1};          // shares in use
+        unsigned* stamp_host = nullptr;                  // pinned copy of the last calibrating launch's per-block stamps ...
+        hipEvent_t stamp_ev = nullptr;                   // ... complete when this event is
+        int stamp_pending = 0;                           // blocks of that launch (0: nothing to read)
+        double stamp_w[8] = {1, 1, 1, 1, 1, 1, 1, 1};    // the shares that launch ran with
+        double stamp_frac = 1.0;                         // ... and its part of the search's work (phased searches stamp their LAST launch)
+        int rounds = 0;
+    } xcal[2];
     int xcd_balance = 0;                                 // 0 = automatic (big fp32 searches calibrate the shares from their own workgroups' durations), 1 = equal shares, 2 = as set
-    unsigned* stamp_host = nullptr;                      // pinned copy of the last calibrating launch's per-block stamps ...
-    hipEvent_t stamp_ev = nullptr;                       // ... complete when this event is
-    int stamp_pending = 0;                               // blocks of that launch (0: nothing to read)
-    double stamp_w[8] = {1, 1, 1, 1, 1, 1, 1, 1};        // the shares that launch ran with
-    double stamp_frac = 1.0;                             // ... and its part of the search's work (phased searches stamp their LAST launch)
-    int calib_rounds = 0;
     const int* cl_stats_dev = nullptr;                   // {checks, spins, timeouts} of the last clustered launch (in `state`)
     // fp16 candidate mode (use_fp16): fp16 copies of the bank / query fragment tiles, candidate buffers
     int fp16 = 0, dp16 = 0;

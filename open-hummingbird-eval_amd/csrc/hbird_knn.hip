@@ -504,27 +504,29 @@ __global__ __launch_bounds__(256) void pool_floor_kernel(const float* __restrict
 // host memory behind the launch, and the NEXT such search -- if that copy has completed; it never waits for it -- turns each XCD group's
 // median duration into its share of the work list: share_x <- share_x x (median of all / median of group x).  One round brings the groups
 // within 0.1-0.3 % of each other (10 M x 768: 2275 -> 2258 ms, 2.5 M x 768: 573.7 -> 568.4; profiles/r05/xcd_weights_iterated.txt); later
-// rounds only act on a change beyond 0.3 %.  Speed only: any shares give the same results.  The fp16 candidate kernel keeps equal shares: it
-// is power-limited, its groups' durations follow the work list's ragged ends more than the XCDs' speeds, and shares derived from them made
-// it slower (281 -> 288-297 ms).  Shares are remembered per device for indexes created later.
+// rounds only act on a change beyond 0.3 %.  Speed only: any shares give the same results.  The fp16 candidate kernel calibrates shares of its own (its
+// XCDs differ by other amounts: it runs on the chip's power budget): 274.0 -> 270.0 ms at 10 M x 768, 18.6 -> 18.4 at 2 M x 384 -- but only
+// since a phased list's cuts follow the shares (hb_finish_schedule); with common cuts, where a group's extra share lands in the last phase,
+// the same shares made it SLOWER (281 -> 288-297 ms).  Shares are remembered per device and family for indexes created later.
 static std::mutex g_xcd_mu;
-static std::map<int, std::array<double, 8>> g_xcd_known;     // device -> last calibrated shares
-static void hb_xcd_calibrate(hb_index* ix) {
-    if (ix->calib_rounds == 0 && !ix->stamp_pending) {        // a new index starts from what this device is known to need
+static std::map<std::pair<int, int>, std::array<double, 8>> g_xcd_known;     // (device, kernel family) -> last calibrated shares
+static void hb_xcd_calibrate(hb_index* ix, int fam) {
+    hb_index::xcd_cal& c = ix->xcal[fam];
+    if (c.rounds == 0 && !c.stamp_pending) {        // a new index starts from what this device is known to need
         std::lock_guard<std::mutex> lock(g_xcd_mu);
-        auto it = g_xcd_known.find(ix->device);
+        auto it = g_xcd_known.find({ix->device, fam});
         if (it != g_xcd_known.end()) {
             bool differs = false;
-            for (int x = 0; x < 8; ++x) { differs = differs || ix->xcd_w[x] != it->second[x]; ix->xcd_w[x] = it->second[x]; }
+            for (int x = 0; x < 8; ++x) { differs = differs || c.w[x] != it->second[x]; c.w[x] = it->second[x]; }
             if (differs) ix->sched = hb_schedule();
-            ix->calib_rounds = 1;
+            c.rounds = 1;
         }
     }
-    if (!ix->stamp_pending || !ix->stamp_ev || hipEventQuery(ix->stamp_ev) != hipSuccess) { (void)hipGetLastError(); return; }
-    const int G = ix->stamp_pending;
-    ix->stamp_pending = 0;
+    if (!c.stamp_pending || !c.stamp_ev || hipEventQuery(c.stamp_ev) != hipSuccess) { (void)hipGetLastError(); return; }
+    const int G = c.stamp_pending;
+    c.stamp_pending = 0;
     std::vector<unsigned> dur[8];
-    for (int b = 0; b < G; ++b) dur[b & 7].push_back(ix->stamp_host[4 * b + 1] - ix->stamp_host[4 * b]);     // (mod 2^32: a launch is far shorter than 43 s)
+    for (int b = 0; b < G; ++b) dur[b & 7].push_back(c.stamp_host[4 * b + 1] - c.stamp_host[4 * b]);     // (mod 2^32: a launch is far shorter than 43 s)
     double med[8], all = 0.0;
     for (int x = 0; x < 8; ++x) {
         if (dur[x].empty()) return;
@@ -533,22 +535,41 @@ static void hb_xcd_calibrate(hb_index* ix) {
         if (!(med[x] > 0.0)) return;
         all += med[x] / 8.0;
     }
-    double w[8], mean = 0.0, change = 0.0;
     // (a duration that is off by e in a launch holding the part f of the work is mended by e x f of the whole share)
-    for (int x = 0; x < 8; ++x) { w[x] = ix->stamp_w[x] * (1.0 + ix->stamp_frac * (all / med[x] - 1.0)); mean += w[x] / 8.0; }
+    double w[8], mean = 0.0, change = 0.0;
+    for (int x = 0; x < 8; ++x) { w[x] = c.stamp_w[x] * (1.0 + c.stamp_frac * (all / med[x] - 1.0)); mean += w[x] / 8.0; }
     for (int x = 0; x < 8; ++x) {
         w[x] = std::min(1.25, std::max(0.8, w[x] / mean));
-        change = std::max(change, std::fabs(w[x] / ix->xcd_w[x] - 1.0));
+        if (fam && c.rounds >= 2) w[x] = 0.5 * (w[x] + c.w[x]);      // the fp16 kernel's durations scatter by +- 0.5 % from search to search: damped ...
+        change = std::max(change, std::fabs(w[x] / c.w[x] - 1.0));
     }
-    if (change > (ix->calib_rounds < 2 ? 0.0015 : 0.003)) {
-        for (int x = 0; x < 8; ++x) ix->xcd_w[x] = w[x];
+    // ... and a new work list (10 M x 768: 8 ms of host time) only for a change that is worth it
+    const double worth = fam ? (c.rounds < 2 ? 0.003 : c.rounds < 4 ? 0.006 : 0.012) : (c.rounds < 2 ? 0.0015 : 0.003);
+    if (change > worth) {
+        for (int x = 0; x < 8; ++x) c.w[x] = w[x];
         ix->sched = hb_schedule();                            // rebuilt with the new shares by the caller
         std::lock_guard<std::mutex> lock(g_xcd_mu);
         std::array<double, 8> keep;
         for (int x = 0; x < 8; ++x) keep[x] = w[x];
-        g_xcd_known[ix->device] = keep;
+        g_xcd_known[{ix->device, fam}] = keep;
     }
-    ++ix->calib_rounds;
+    ++c.rounds;
+}
+// behind a calibrating launch: its per-block stamps -> pinned host memory, read by the next big search of the family if the copy has completed by then
+static int hb_xcd_collect(hb_index* ix, int fam, const unsigned* stamps_dev, const hb_schedule& sc, const double* shares, int n_phases, int nqt, int nbt,
+                          hipStream_t s) {
+    hb_index::xcd_cal& c = ix->xcal[fam];
+    if (!stamps_dev || sc.G > 1024 || c.stamp_pending) return 0;
+    if (!c.stamp_host) { HB_HIP(hipHostMalloc((void**)&c.stamp_host, 1024 * 16, hipHostMallocDefault)); HB_HIP(hipEventCreateWithFlags(&c.stamp_ev, hipEventDisableTiming)); }
+    HB_HIP(hipMemcpyAsync(c.stamp_host, stamps_dev, (size_t)sc.G * 16, hipMemcpyDeviceToHost, s));
+    HB_HIP(hipEventRecord(c.stamp_ev, s));
+    c.stamp_pending = sc.G;
+    for (int x = 0; x < 8; ++x) c.stamp_w[x] = shares[x];
+    // a phased search stamps its last launch.  Cuts that follow the shares (long lists, hb_finish_schedule) make it a fair sample; with
+    // common cuts a group's extra share is all in that launch -- its part of the work
+    const double per_wg = (double)nqt * (double)nbt / std::max(1, sc.G);
+    c.stamp_frac = n_phases > 1 && !sc.cuts_scaled && per_wg > 0.0 ? std::min(1.0, std::max(0.25, 1.0 - (double)sc.phase_clock.back() / per_wg)) : 1.0;
+    return 0;
 }
 
 // q_tiles / q_aux must already be prepared by the caller (hb_index_search).
@@ -685,12 +706,13 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
                                           : hb_default_panel(nqt, std::min<long long>(G, (long long)nqt * nbt), tile_bytes, cq, cb);
     // per-XCD work shares (hb_xcd_calibrate above): calibrated for fp32 searches from 30,000 stages per workgroup (30-60 ms of kernel; from 150,000 until late in
     // round 5: cfg-2's 2 M x 384 bank went without, 135.3 -> 134.7 ms with; phased searches gain in their last phase only);
-    // shares given by the caller (mode 2) apply to fp32 searches of any size (tests/fuzz_small.py FUZZ_XCD=1)
-    const bool balance = !f16 && G % 8 == 0 &&
+    // shares given by the caller (mode 2) apply to searches of any size, both kernel families (tests/fuzz_small.py FUZZ_XCD=1)
+    const int fam = f16 ? 1 : 0;
+    const bool balance = G % 8 == 0 &&
                          (ix->xcd_balance == 2 || (ix->xcd_balance == 0 && (long long)nqt * nbt / std::max(1, G) * ix->g8 >= 30000));
-    if (balance && ix->xcd_balance == 0) hb_xcd_calibrate(ix);
+    if (balance && ix->xcd_balance == 0) hb_xcd_calibrate(ix, fam);
     static const double equal_shares[8] = {1, 1, 1, 1, 1, 1, 1, 1};
-    const double* shares = balance ? ix->xcd_w : equal_shares;
+    const double* shares = balance ? ix->xcal[fam].w : equal_shares;
     hb_schedule& sc = ix->sched;
     // phased searches (pools only: "Phased searches" above hb_launch_knn); hb_index_set_search_options(ix, 0, ...) turns them off (A/B, tests)
     const bool phased = wide && ix->phases_on;
@@ -851,6 +873,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
             }
         }
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
+        if (balance && ix->xcd_balance == 0 && !ol.gb && hb_xcd_collect(ix, 1, a.wg_stamp, sc, shares, n_phases, nqt, nbt, s)) return -1;
         if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, pool_cnt ? a.state_thr : nullptr, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
                          reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, kc, klw, 0, 0, nullptr,
                          cand_idx, cand_dist, s)) return -1;
@@ -957,20 +980,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         }
     }
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
-    if (balance && ix->xcd_balance == 0 && a.wg_stamp && sc.G <= 1024) {
-        // this launch's per-block stamps -> pinned host memory, read by the next big search if the copy has completed by then
-        if (!ix->stamp_host) { HB_HIP(hipHostMalloc((void**)&ix->stamp_host, 1024 * 16, hipHostMallocDefault)); HB_HIP(hipEventCreateWithFlags(&ix->stamp_ev, hipEventDisableTiming)); }
-        if (!ix->stamp_pending) {
-            HB_HIP(hipMemcpyAsync(ix->stamp_host, a.wg_stamp, (size_t)sc.G * 16, hipMemcpyDeviceToHost, s));
-            HB_HIP(hipEventRecord(ix->stamp_ev, s));
-            ix->stamp_pending = sc.G;
-            for (int x = 0; x < 8; ++x) ix->stamp_w[x] = shares[x];
-            // a phased search stamps its last launch.  Cuts that follow the shares (long lists, hb_finish_schedule) make it a fair sample; with
-            // common cuts a group's extra share is all in that launch -- its part of the work
-            const double per_wg = (double)nqt * (double)nbt / std::max(1, sc.G);
-            ix->stamp_frac = n_phases > 1 && !sc.cuts_scaled && per_wg > 0.0 ? std::min(1.0, std::max(0.25, 1.0 - (double)sc.phase_clock.back() / per_wg)) : 1.0;
-        }
-    }
+    if (balance && ix->xcd_balance == 0 && hb_xcd_collect(ix, 0, a.wg_stamp, sc, shares, n_phases, nqt, nbt, s)) return -1;
     const float* qn2 = ix->q_aux;   // [nq] chain ||q||^2 (valid for L2)
     if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, pool_cnt ? a.state_thr : nullptr, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
                      reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, k, klw, id_base, out_metric,

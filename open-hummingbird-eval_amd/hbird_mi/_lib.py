@@ -87,7 +87,7 @@ SIGNATURES = {
     "hb_index_one_launch_stats": (c_int, [c_void_p, POINTER(c_int64)]),
     "hb_index_wg_stamps": (c_int, [c_void_p, c_void_p, c_int, POINTER(c_int)]),
     "hb_index_set_xcd_weights": (c_int, [c_void_p, c_int, POINTER(c_double)]),
-    "hb_index_xcd_weights": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int)]),
+    "hb_index_xcd_weights": (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_int)]),
     "hb_schedule_plan_weighted": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_double), c_void_p, c_int64, POINTER(c_int64)]),
     "hb_index_one_launch_trace": (c_int, [c_void_p, c_void_p, c_int64, POINTER(c_int), POINTER(c_int)]),
     "hb_index_set_rerank_copy": (c_int, [c_void_p, c_int]),

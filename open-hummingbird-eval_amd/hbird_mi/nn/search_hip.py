@@ -296,10 +296,10 @@ class HipFlatIndex:
         arr = None if w8 is None else (ctypes.c_double * 8)(*[float(v) for v in w8])
         _lib.check(_lib.lib().hb_index_set_xcd_weights(self._h, int(mode), arr))
 
-    def xcd_weights(self):
-        """(the eight shares in use, calibration rounds so far)"""
+    def xcd_weights(self, fp16_kernel: bool = False):
+        """(the eight shares in use by the fp32 kernels / by the fp16 candidate kernel, calibration rounds so far)"""
         arr = (ctypes.c_double * 8)(); r = ctypes.c_int(0)
-        _lib.check(_lib.lib().hb_index_xcd_weights(self._h, arr, ctypes.byref(r)))
+        _lib.check(_lib.lib().hb_index_xcd_weights(self._h, int(bool(fp16_kernel)), arr, ctypes.byref(r)))
         return [float(v) for v in arr], int(r.value)
 
     def wg_stamps(self):

@@ -4,7 +4,7 @@ random shapes, both metrics, odd workgroup counts, lists and pools, fp16 mode on
 FUZZ_ONE_LAUNCH=1: phased searches as ONE launch with grid barriers (hb_index_set_one_launch(ix, 2)), with query counts that qualify.
 FUZZ_MID=1: few workgroups (8 / 16) on 300 k - 700 k rows at D = 384 / 768, k <= 32: 120 k - 400 k stages per workgroup, the small-search LIST kernel with its
 quota-floor exchange (the default cases never reach it: they run on pools).
-FUZZ_XCD=1: random per-XCD work shares in [0.8, 1.25] (hb_index_set_xcd_weights(ix, 2, w8): weighted work lists), fp32 searches only."""
+FUZZ_XCD=1: random per-XCD work shares in [0.8, 1.25] (hb_index_set_xcd_weights(ix, 2, w8): weighted work lists), fp32 and use_fp16 searches."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "open-hummingbird-eval_amd"), ROOT]
@@ -23,7 +23,7 @@ for c in range(n_cases):
     if os.environ.get("FUZZ_MID"):
         D = int(rng.choice([384, 768])); M = int(rng.integers(300_000, 700_000)); nq = int(rng.integers(1000, 2300)); k = int(rng.choice([1, 5, 8, 30, 32]))
     G = int(rng.choice([0, 0, 17, 64, 256])) if not os.environ.get("FUZZ_MID") else int(rng.choice([8, 16]))
-    fp16 = bool(rng.integers(0, 2)) and k <= 128 and not os.environ.get("FUZZ_XCD") and not os.environ.get("FUZZ_MID")
+    fp16 = bool(rng.integers(0, 2)) and k <= 128 and not os.environ.get("FUZZ_MID")
     bank = rng.standard_normal((M, D), dtype=np.float32); bank /= np.linalg.norm(bank, axis=1, keepdims=True)
     if rng.integers(0, 2): bank[rng.integers(0, M, size=50)] = bank[0]          # duplicates: ties by id
     q = (3.0 * rng.standard_normal((nq, D))).astype(np.float32)

@@ -761,6 +761,23 @@ def test_per_xcd_work_shares_never_change_the_result(cuda_device):
         ix.set_xcd_weights(2, w8)
         i1, d1 = ix.search(q[:12_544], 90)
         assert torch.equal(i1, ref_i) and torch.equal(d1.view(torch.int32), ref_d.view(torch.int32)), w8
+    # the fp16 candidate kernel has shares of its own (use_fp16: the fp32 search's bits, whatever the shares)
+    ix.set_xcd_weights(1)
+    f32_i, f32_d = ix.search(q, k)
+    ix.set_fp16(True)
+    ix.set_xcd_weights(2, [1.2, 0.85, 1.1, 0.9, 1.0, 1.05, 0.95, 1.15])
+    i1, d1 = ix.search(q, k)
+    assert torch.equal(i1, f32_i) and torch.equal(d1.view(torch.int32), f32_d.view(torch.int32))
+    ix.set_xcd_weights(0)
+    for _ in range(4):
+        i1, d1 = ix.search(q, k)
+        torch.cuda.synchronize()
+        assert torch.equal(i1, f32_i) and torch.equal(d1.view(torch.int32), f32_d.view(torch.int32))
+        assert ix.last_fp16_fallbacks() < nq // 100
+    w16, rounds16 = ix.xcd_weights(True)
+    assert rounds16 >= 1 and abs(sum(w16) / 8 - 1.0) < 1e-6 and all(0.8 <= v <= 1.25 for v in w16), (w16, rounds16)
+    print("fp16 candidate kernel: calibrated shares", [round(v, 4) for v in w16], "after", rounds16, "rounds")
+    ix.set_fp16(False)
     with pytest.raises(RuntimeError):
         ix.set_xcd_weights(2, [1.0] * 7 + [9.0])
 

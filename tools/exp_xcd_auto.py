@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """The library's own per-XCD calibration (hb_index_set_xcd_weights mode 0) search after search, beside equal shares (mode 1), for either
 kernel family: kernel ms per search, the shares in use, and that the results never change.  args = rows dim queries k mode[f16|f32] ...
-(The library calibrates the fp32 kernels only: profiles/r05/xcd_auto_fp16_negative.txt is this script on a build that also calibrated the
-fp16 candidate kernel from per-tile speeds -- 648 -> 660 ms, slower, so that build was dropped.)"""
+(Both kernel families calibrate shares of their own; profiles/r05/xcd_auto_fp16_negative.txt is this script on an earlier build whose phased lists
+had common cuts: there the fp16 kernel got slower with shares.)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,6 +26,6 @@ for i in range(0, len(a), 5):
             ms = ix.last_knn_ms(); ix.set_timing(False)
             if ref is None: ref = (idx.clone(), dist.clone())
             assert torch.equal(idx, ref[0]) and torch.equal(dist, ref[1])
-            w, rounds = ix.xcd_weights()
+            w, rounds = ix.xcd_weights(mode == "f16")
             print((M, D, nq, k, mode), label, f"search {r}: kernel {ms:.2f} ms, whole search {wall:.2f} ms, shares {np.round(w, 4).tolist()} after {rounds} rounds", flush=True)
     del ix
