@@ -802,7 +802,7 @@ def main():
                        "use_fp16": bool(a.fp16), "fp16_fallback_queries": index.last_fp16_fallbacks() if a.fp16 else None,
                        # work share per XCD group of the fp32 work list, calibrated from the workgroups' own durations during the warm-up
                        # steps (hb_index_set_xcd_weights: the XCDs of one chip differ by 1-2 % in speed), and the calibration rounds
-                       "xcd_shares": [round(v, 4) for v in index.xcd_weights()[0]], "xcd_calibration_rounds": index.xcd_weights()[1]},
+                       "xcd_shares": [round(v, 4) for v in index.xcd_weights(bool(a.fp16))[0]], "xcd_calibration_rounds": index.xcd_weights(bool(a.fp16))[1]},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach / peak, "traffic": None,
                          "traffic_unit": "bytes/launch (L2-miss side, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE; Infinity-Cache hits included)",
