@@ -854,7 +854,7 @@ def main():
             # extra, not the headline: the same step in use_fp16 mode (fp16 candidate pass + certified exact fp32
             # re-rank; returns the identical bits, see DESIGN.md, `use_fp16`)
             index.set_fp16(True)
-            for _ in range(6):      # (finished warm-up searches let the next ones calibrate the fp16 kernel's per-XCD work shares)
+            for _ in range(8):      # (finished warm-up searches let the next ones calibrate the fp16 kernel's per-XCD work shares)
                 index.search_aggregate(q, k, beta=0.02); torch.cuda.synchronize(device)
             index.set_timing(True)
             t1 = time.time()

@@ -544,7 +544,7 @@ static void hb_xcd_calibrate(hb_index* ix, int fam) {
         change = std::max(change, std::fabs(w[x] / c.w[x] - 1.0));
     }
     // ... and a new work list (10 M x 768: 8 ms of host time) only for a change that is worth it
-    const double worth = fam ? (c.rounds < 2 ? 0.003 : c.rounds < 4 ? 0.006 : 0.012) : (c.rounds < 2 ? 0.0015 : 0.003);
+    const double worth = fam ? (c.rounds < 2 ? 0.003 : c.rounds < 4 ? 0.006 : 0.012) : (c.rounds < 2 ? 0.0015 : 0.003);   // (fp16: 0.5 % / 0.8 % kept the shares moving: slower)
     if (change > worth) {
         for (int x = 0; x < 8; ++x) c.w[x] = w[x];
         ix->sched = hb_schedule();                            // rebuilt with the new shares by the caller

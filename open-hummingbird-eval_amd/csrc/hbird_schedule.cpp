@@ -102,24 +102,26 @@ static void hb_finish_schedule(hb_schedule& out, std::vector<std::vector<hb_seg>
             std::vector<hb_seg> v;
             v.reserve(per_wg[w].size() + n_cuts);
             for (hb_seg sg : per_wg[w]) {
-                for (int t : cuts)
-                    if (t > sg.tile0 && t < sg.tile0 + sg.n_tiles) {
+                // (the cuts ascend: only those inside the segment are visited)
+                for (auto ct = std::upper_bound(cuts.begin(), cuts.end(), sg.tile0); ct != cuts.end() && *ct < sg.tile0 + sg.n_tiles; ++ct) {
+                    const int t = *ct;
+                    {
                         hb_seg head = sg;
                         head.n_tiles = t - sg.tile0;
                         v.push_back(head);
                         sg.b_tile0 += sg.stride * head.n_tiles; sg.tile0 = t; sg.n_tiles -= head.n_tiles; sg.first = 0;
                     }
+                }
                 v.push_back(sg);
             }
             per_wg[w].swap(v);
-            for (int p = 0; p < n_cuts; ++p) {
-                int i = 0;
+            for (int p = 0, i = 0; p < n_cuts; ++p) {      // (cuts and clocks both ascend: one pass)
                 while (i < (int)per_wg[w].size() && per_wg[w][i].tile0 < cuts[p]) ++i;
                 rel[p][w] = i;
             }
         }
     }
-    std::map<int, std::pair<int, int>> ord_of;   // slot -> (ordinal among its query tile's slots, their number)
+    std::vector<std::pair<int, int>> ord_of((size_t)std::max(1, out.n_slots), std::make_pair(0, 0));   // slot -> (ordinal among its query tile's slots, their number)
     for (const auto& sl : slots_of_qt)
         for (size_t i = 0; i < sl.size(); ++i) ord_of[sl[i]] = {(int)i, (int)sl.size()};
     for (auto& v : per_wg)
@@ -165,7 +167,7 @@ static void hb_build_clustered(int nqt, int nbt, int G, int panel, int cq, int c
     const int CS = cq * cb, NC = G / CS, NQG = (nqt + cq - 1) / cq;
     out.cq = cq; out.cb = cb; out.n_clusters = NC; out.xcd_share = xcd_share;
     std::vector<std::vector<hb_seg>> per_wg(G);   // logical workgroup = cluster * CS + member
-    std::map<std::pair<int, int>, int> slot_of;   // (logical wg, q_tile) -> slot
+    std::vector<int> slot_of((size_t)G * nqt, -1);   // (logical wg, q_tile) -> slot
     std::vector<std::vector<int>> slots_of_qt(nqt);
     std::vector<int> clock(NC, 0);                // cluster clock: tiles each member has been dealt (idle ones included)
     // units [qg][j0, j0 + cnt) of the panel at bank tile b0 (pp tiles) -> the members of cluster c
@@ -177,13 +179,12 @@ static void hb_build_clustered(int nqt, int nbt, int G, int panel, int cq, int c
             if (q >= nqt || n <= 0) continue;             // idle for these units (its clock still advances)
             hb_seg sg;
             sg.q_tile = q; sg.b_tile0 = b0 + j0 * cb + ib; sg.n_tiles = n; sg.stride = cb; sg.tile0 = clock[c]; sg.next_tile0 = 0;
-            auto key = std::make_pair(w, q);
-            auto it = slot_of.find(key);
-            if (it == slot_of.end()) {
+            int& known = slot_of[(size_t)w * nqt + q];
+            if (known < 0) {
                 sg.slot = out.n_slots++; sg.first = 1;
-                slot_of[key] = sg.slot;
+                known = sg.slot;
                 slots_of_qt[q].push_back(sg.slot);
-            } else { sg.slot = it->second; sg.first = 0; }
+            } else { sg.slot = known; sg.first = 0; }
             per_wg[w].push_back(sg);
         }
         clock[c] += cnt;
@@ -276,7 +277,7 @@ void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out, int
     if (cq < 1 || cb < 1 || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
     if (cq * cb > 1) { hb_build_clustered(nqt, nbt, G, panel, cq, cb, out, xcd_share); return; }
     std::vector<std::vector<hb_seg>> per_wg(G);
-    std::map<std::pair<int, int>, int> slot_of;   // (wg, q_tile) -> slot
+    std::vector<int> slot_of((size_t)G * nqt, -1);   // (wg, q_tile) -> slot
     std::vector<std::vector<int>> slots_of_qt(nqt);
     std::vector<int> clock(G, 0);
     const std::vector<double> cum = (!out.xcd_w.empty() && G % 8 == 0) ? hb_cum_shares(G, G / 8, out.xcd_w) : std::vector<double>();
@@ -289,16 +290,15 @@ void hb_build_schedule(int nqt, int nbt, int G, int panel, hb_schedule& out, int
             while (e0 < e1) {
                 const int q = (int)(e0 / pp), b = (int)(e0 % pp);
                 const int cnt = (int)std::min<long long>(pp - b, e1 - e0);
-                auto key = std::make_pair(w, q);
-                auto it = slot_of.find(key);
+                int& known = slot_of[(size_t)w * nqt + q];
                 hb_seg sg;
                 sg.q_tile = q; sg.b_tile0 = b0 + b; sg.n_tiles = cnt; sg.stride = 1; sg.tile0 = clock[w]; sg.next_tile0 = 0;
                 clock[w] += cnt;
-                if (it == slot_of.end()) {
+                if (known < 0) {
                     sg.slot = out.n_slots++; sg.first = 1;
-                    slot_of[key] = sg.slot;
+                    known = sg.slot;
                     slots_of_qt[q].push_back(sg.slot);
-                } else { sg.slot = it->second; sg.first = 0; }
+                } else { sg.slot = known; sg.first = 0; }
                 // coalesce with the previous segment when it continues the same slot contiguously
                 if (!per_wg[w].empty()) {
                     hb_seg& pv = per_wg[w].back();
