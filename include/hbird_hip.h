@@ -206,28 +206,8 @@ int hb_index_set_variant(hb_index_t* ix, int variant);
  * phases; small_limit_stages > 0 moves the size (k8 stages per workgroup) below which a search takes the small-search kernels (0 =
  * the built-in 400,000). */
 int hb_index_set_search_options(hb_index_t* ix, int phases, int64_t small_limit_stages);
-/* A phased search (see above; the reference's one `index.search` call, search_faiss.py:89) can run as ONE launch: the workgroups stay
- * resident over all phases, meet at a grid barrier at each phase boundary and compute the next phase's floors themselves, instead of one
- * launch per phase with a floor kernel between two.  Same results bit for bit.  OPT-IN (mode 2): measured on MI355X it is 2-10 % slower
- * than a launch per phase at every size tried -- what a phase boundary costs is the arrival skew of the workgroups and the floor
- * computation, which eight waves per CU hide worse than a launch of its own does, not the launches (profiles/r05/README.md).
- * A workgroup that waits at a barrier for more than the timeout (a peer is not resident: the GPU shared with another process) gives the
- * launch up -- every workgroup leaves, a second launch that is always enqueued behind the first finishes the search without barriers --
- * so the device cannot hang; spins are bounded by the 100 MHz real-time counter.
- * mode 0 = automatic (today: a launch per phase), 1 = a launch per phase, 2 = one launch wherever the search qualifies (pools, every
- * workgroup resident, at most 32 slots per query tile whose pools fit the LDS between two phases).  timeout_us 0 = automatic (20 ms +
- * twice the search's estimated time).  inject (tests and diagnostics; 0 = nothing): (kind << 28) | (phase << 16) | (block + 1) makes that
- * block fail at that phase boundary -- kind 1: it raises the abort flag, kind 2: it leaves silently and the others run into their timeout;
- * kind 3: no failure, every workgroup stamps the real-time counter at each boundary (hb_index_one_launch_trace); kind 4: the block passes
- * both barriers of that boundary and raises the flag afterwards (the others are already in the next phase). */
-int hb_index_set_one_launch(hb_index_t* ix, int mode, int64_t timeout_us, int inject);
-/* What the last search did about it (one stream synchronisation): out[0] = 1 if it ran as one launch, [1] = its phases, [2] = phase
- * boundaries passed by block 0, [3] / [4] / [5] = ticks (100 MHz) block 0 spent in the first barrier / the floor computation / the second
- * barrier over all boundaries, [6] = workgroups that timed out, [7] = 1 if the launch was given up and the completion launch finished it. */
-int hb_index_one_launch_stats(hb_index_t* ix, int64_t out[8]);
-/* Diagnostics: with inject = 3 << 28 every workgroup of a one-launch search stamps the 100 MHz real-time counter (low 32 bits) at each phase
- * boundary -- out[boundary][4][workgroup]: arrival at the first barrier, its pass, floors done, pass of the second barrier. */
-int hb_index_one_launch_trace(hb_index_t* ix, uint32_t* out, int64_t max_words, int* n_boundaries, int* workgroups);
+/* (Round 5's opt-in "one launch per phased search" -- hb_index_set_one_launch / _one_launch_stats / _one_launch_trace -- measured 2-10 % slower
+ * than a launch per phase at every size and was removed in round 6; numbers: profiles/r05/README.md.) */
 /* Work shares per XCD.  The eight XCDs of one MI355X do not run the fp32 kNN kernel at one speed (with equal work the workgroups of the odd
  * XCDs finish 1-2 % after those of the even ones, and a launch lasts as long as its slowest workgroup: profiles/r05/xcd_speed_stamps_
  * headline.txt), so the work list gives group x -- the blocks equal to x mod 8, which the hardware deals to one XCD -- the share
@@ -247,6 +227,19 @@ int hb_schedule_plan_weighted(int nqt, int nbt, int workgroups, int panel_tiles,
  * real-time counter when it starts and when it ends, and notes the XCD it ran on: out[block][4] = {start, end, XCC id, 0} (low 32 bits).
  * Shows per-XCD speed differences: the launch lasts as long as its slowest workgroup. */
 int hb_index_wg_stamps(hb_index_t* ix, uint32_t* out, int max_blocks, int* workgroups);
+/* The clock the last stamped kNN launch ran at, WITHOUT a profiler attached: every workgroup also stamps the shader-cycle counter
+ * (s_memtime) beside the real-time counter, and (cycles / 10 ns ticks) x 100 MHz is the clock its CU held over the launch.  out[0] = median
+ * over the workgroups (GHz), [1] / [2] = slowest / fastest workgroup, [3] = the launch's span in ms by the stamps (first start to last end).
+ * Zeros when the last launch did not stamp (hb_index_set_timing off and no share calibration).  One stream synchronisation. */
+int hb_index_kernel_clock(hb_index_t* ix, double out[4]);
+/* State of the share calibration of one kernel family (fp16_kernel as above): out[0] = calibration rounds, [1] = 1 when the GUARD has locked
+ * the shares -- a share set whose launches (same shape, shortest of at least two) measured 0.15 % slower than the best set seen is dropped, the
+ * best set returns and this index stops calibrating --, 2 when the map from block groups to XCDs kept moving (equal shares from then on),
+ * [2] = reverts by the guard, [3] = stamp sets read, [4] = stamp sets rejected (a workgroup that did not stamp, blocks equal mod 8 that did not
+ * share an XCD, a time far from the others'), [5] / [6] = shortest launch in ms with the best / the current share set, [7] = work lists built
+ * for this index so far (a re-plan costs host time: 8 ms at 10 M x 768), [8] = moves of the group -> XCD map, [9] = the XCD block 0 was last
+ * seen on.  In calibrated mode the shares (hb_index_xcd_weights) belong to the PHYSICAL XCDs 0-7 as HW_REG_XCC_ID numbers them. */
+int hb_index_xcd_stats(const hb_index_t* ix, int fp16_kernel, double out[12]);
 /* use_fp16 searches re-rank their candidates in exact fp32 arithmetic.  In the fragment tiles a bank row is 2 x D/8 sixteen-byte pieces
  * 512 B apart, so that pass pulls eight times the bytes it uses; a second, row-major fp32 copy of the bank lets it read whole lines (a
  * use_fp16 search at 300,000 x 768: 8.0 -> 6.6 ms, k = 90: 18.0 -> 12.4; results identical).  mode 0 = automatic: the copy is made at the first use_fp16

@@ -1,6 +1,7 @@
 // extern "C" surface of libhbird_hip.so (declared in include/hbird_hip.h).
 #include "../../include/hbird_hip.h"
 #include "hbird_internal.h"
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <dlfcn.h>
@@ -177,38 +178,6 @@ extern "C" int hb_index_set_search_options(hb_index_t* ix, int phases, int64_t s
     ix->phases_on = phases ? 1 : 0; ix->small_limit = small_limit_stages; ix->sched = hb_schedule();
     return 0;
 }
-extern "C" int hb_index_set_one_launch(hb_index_t* ix, int mode, int64_t timeout_us, int inject) {
-    if (!ix) return hb_fail("hb_index_set_one_launch: NULL index handle");
-    if (mode < 0 || mode > 2) return hb_fail("hb_index_set_one_launch: mode must be 0 (automatic), 1 (a launch per phase) or 2 (one launch)");
-    if (timeout_us < 0 || timeout_us > 40000000) return hb_fail("hb_index_set_one_launch: timeout_us must be in [0, 40,000,000]");
-    ix->one_launch = mode; ix->ol_timeout_us = timeout_us; ix->ol_inject = inject;
-    return 0;
-}
-extern "C" int hb_index_one_launch_stats(hb_index_t* ix, int64_t out[8]) {
-    if (!ix || !out) return hb_fail("hb_index_one_launch_stats: NULL pointer");
-    for (int i = 0; i < 8; ++i) out[i] = 0;
-    out[1] = ix->ol_last_phases;
-    if (!ix->ol_words_dev) return 0;
-    HB_HIP(hipSetDevice(ix->device));
-    unsigned h[2 * 32];     // the abort line and the statistics line (hbird_knn_dev.h: HB_GB_ABORT, HB_GB_STATS)
-    HB_HIP(hipMemcpyAsync(h, ix->ol_words_dev + 17 * 32, sizeof(h), hipMemcpyDeviceToHost, ix->stream));
-    HB_HIP(hipStreamSynchronize(ix->stream));
-    out[0] = 1; out[2] = h[32]; out[3] = h[33]; out[4] = h[34]; out[5] = h[35]; out[6] = h[36]; out[7] = h[0] != 0;
-    return 0;
-}
-extern "C" int hb_index_one_launch_trace(hb_index_t* ix, uint32_t* out, int64_t max_words, int* n_boundaries, int* workgroups) {
-    if (!ix || !out || !n_boundaries || !workgroups) return hb_fail("hb_index_one_launch_trace: NULL pointer");
-    *n_boundaries = 0; *workgroups = 0;
-    if (!ix->ol_words_dev) return 0;
-    const int G = ix->sched.G, nb = ix->ol_last_phases - 1;
-    const int64_t words = (int64_t)nb * 4 * G;
-    if (words > max_words) return hb_fail("hb_index_one_launch_trace: the buffer is too small");
-    HB_HIP(hipSetDevice(ix->device));
-    HB_HIP(hipMemcpyAsync(out, ix->ol_words_dev + (20 * 32 + (G + 31) / 32 * 32), (size_t)words * 4, hipMemcpyDeviceToHost, ix->stream));
-    HB_HIP(hipStreamSynchronize(ix->stream));
-    *n_boundaries = nb; *workgroups = G;
-    return 0;
-}
 extern "C" int hb_index_set_xcd_weights(hb_index_t* ix, int mode, const double* w8) {
     if (!ix) return hb_fail("hb_index_set_xcd_weights: NULL index handle");
     if (mode < 0 || mode > 2) return hb_fail("hb_index_set_xcd_weights: mode must be 0 (calibrated), 1 (equal shares) or 2 (the given shares)");
@@ -219,7 +188,7 @@ extern "C" int hb_index_set_xcd_weights(hb_index_t* ix, int mode, const double* 
         ix->xcal[0].w[x] = w; ix->xcal[1].w[x] = w;
     }
     ix->xcd_balance = mode;
-    for (auto& c : ix->xcal) { c.stamp_pending = 0; c.rounds = mode == 0 ? 0 : 1; }
+    for (auto& c : ix->xcal) { c.stamp_pending = 0; c.rounds = mode == 0 ? 0 : 1; c.locked = 0; c.cur_n = 0; c.best_span = 0.0; c.perm_moves = 0; }
     ix->sched = hb_schedule();
     return 0;
 }
@@ -236,9 +205,47 @@ extern "C" int hb_index_wg_stamps(hb_index_t* ix, uint32_t* out, int max_blocks,
     if (!ix->wg_stamp_dev) return 0;
     if (ix->wg_stamp_blocks > max_blocks) return hb_fail("hb_index_wg_stamps: the buffer is too small");
     HB_HIP(hipSetDevice(ix->device));
-    HB_HIP(hipMemcpyAsync(out, ix->wg_stamp_dev, (size_t)ix->wg_stamp_blocks * 16, hipMemcpyDeviceToHost, ix->stream));
+    std::vector<unsigned> h((size_t)ix->wg_stamp_blocks * 8);     // device layout: [block][start | end][4] (wg_stamp, hbird_knn_dev.h)
+    HB_HIP(hipMemcpyAsync(h.data(), ix->wg_stamp_dev, h.size() * 4, hipMemcpyDeviceToHost, ix->stream));
     HB_HIP(hipStreamSynchronize(ix->stream));
+    for (int b = 0; b < ix->wg_stamp_blocks; ++b) { out[4 * b] = h[8 * b]; out[4 * b + 1] = h[8 * b + 4]; out[4 * b + 2] = h[8 * b + 1]; out[4 * b + 3] = 0; }
     *workgroups = ix->wg_stamp_blocks;
+    return 0;
+}
+extern "C" int hb_index_kernel_clock(hb_index_t* ix, double out[4]) {
+    if (!ix || !out) return hb_fail("hb_index_kernel_clock: NULL pointer");
+    out[0] = out[1] = out[2] = out[3] = 0.0;
+    if (!ix->wg_stamp_dev || ix->wg_stamp_blocks <= 0) return 0;
+    HB_HIP(hipSetDevice(ix->device));
+    const int G = ix->wg_stamp_blocks;
+    std::vector<unsigned> h((size_t)G * 8);
+    HB_HIP(hipMemcpyAsync(h.data(), ix->wg_stamp_dev, (size_t)G * 32, hipMemcpyDeviceToHost, ix->stream));
+    HB_HIP(hipStreamSynchronize(ix->stream));
+    std::vector<double> ghz;
+    long long first = 0, last = 0;
+    bool any = false;
+    for (int b = 0; b < G; ++b) {
+        const unsigned* sb = h.data() + 8 * (size_t)b;
+        const unsigned t0 = sb[0], t1 = sb[4];
+        if (t0 == 0u && t1 == 0u) continue;             // the block did not stamp
+        const unsigned d = t1 - t0;
+        const long long rs = (long long)(int)(t0 - h[0]), re = rs + (long long)d;
+        if (!any) { first = rs; last = re; any = true; }
+        first = std::min(first, rs); last = std::max(last, re);
+        const unsigned long long c0 = ((unsigned long long)sb[3] << 32) | sb[2], c1 = ((unsigned long long)sb[7] << 32) | sb[6];
+        if (c1 > c0 && d >= 100u && d < 0x7FFFFFFFu) ghz.push_back((double)(c1 - c0) / (double)d * 0.1);
+    }
+    if (ghz.empty()) return 0;
+    std::sort(ghz.begin(), ghz.end());
+    out[0] = ghz[ghz.size() / 2]; out[1] = ghz.front(); out[2] = ghz.back(); out[3] = (double)(last - first) * 1e-5;   // 10 ns ticks -> ms
+    return 0;
+}
+extern "C" int hb_index_xcd_stats(const hb_index_t* ix, int fp16_kernel, double out[12]) {
+    if (!ix || !out) return hb_fail("hb_index_xcd_stats: NULL pointer");
+    const hb_index::xcd_cal& c = ix->xcal[fp16_kernel ? 1 : 0];
+    out[0] = c.rounds; out[1] = c.locked; out[2] = c.reverts; out[3] = c.samples; out[4] = c.rejected;
+    out[5] = c.best_span * 1e-5; out[6] = c.cur_span * 1e-5; out[7] = (double)ix->sched_builds;
+    out[8] = c.perm_moves; out[9] = c.perm[0]; out[10] = out[11] = 0.0;
     return 0;
 }
 extern "C" int hb_index_set_rerank_copy(hb_index_t* ix, int mode) {

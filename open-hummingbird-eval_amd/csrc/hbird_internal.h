@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <array>
 #include <string>
 #include <vector>
 #include "hbird_schedule.h"
@@ -70,7 +71,16 @@ struct hb_index {
         double stamp_w[8] = {1, 1, 1, 1, 1, 1, 1, 1};    // the shares that launch ran with
         double stamp_frac = 1.0;                         // ... and its part of the search's work (phased searches stamp their LAST launch)
         int rounds = 0;
+        int samples = 0, rejected = 0;                   // stamp sets read / thrown away (hb_stamps_summarise)
+        // the guard (hb_xcd_calibrate): shares stay only while launches of the same shape measure faster with them
+        std::array<int, 6> key{{0, 0, 0, 0, 0, 0}}, stamp_key{{0, 0, 0, 0, 0, 0}};   // shape of the launches being compared / of the pending stamps
+        double cur_w[8] = {1, 1, 1, 1, 1, 1, 1, 1}, best_w[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+        double cur_span = 0.0, best_span = 0.0;          // shortest launch (100 MHz ticks, first start to last end) with the current / the best share set
+        int cur_n = 0, locked = 0, reverts = 0;          // locked: 1 = by the guard, 2 = the group -> XCD map kept moving (equal shares)
+        int perm[8] = {0, 1, 2, 3, 4, 5, 6, 7};          // XCD that group g (blocks equal to g mod 8) was last seen on; the shares w[] are per physical XCD
+        int perm_moves = 0;
     } xcal[2];
+    int64_t sched_builds = 0;                            // work lists built for this index (a re-plan costs host time: 8 ms at 10 M x 768)
     int xcd_balance = 0;                                 // 0 = automatic (big fp32 searches calibrate the shares from their own workgroups' durations), 1 = equal shares, 2 = as set
     const int* cl_stats_dev = nullptr;                   // {checks, spins, timeouts} of the last clustered launch (in `state`)
     // fp16 candidate mode (use_fp16): fp16 copies of the bank / query fragment tiles, candidate buffers
@@ -90,13 +100,7 @@ struct hb_index {
     int score_output = 0;                                // 1: searches return ordering scores instead of distances
     int variant = 0;                                     // kernel selection for A/B runs and tests (hb_index_set_variant)
     int phases_on = 1;                                   // pool searches are launched in phases (hb_index_set_search_options)
-    // phased searches in ONE launch (grid barrier + in-kernel floors, hbird_knn_dev.h): hb_index_set_one_launch
-    int one_launch = 0;                                  // 0 = automatic (today: a launch per phase: measured faster), 1 = a launch per phase, 2 = one launch where the search qualifies
-    int64_t ol_timeout_us = 0;                           // barrier timeout (0 = automatic: 20 ms + twice the search's estimated time)
-    int ol_inject = 0;                                   // tests: make one block fail at one boundary (hb_one_launch::inject)
-    const unsigned* ol_words_dev = nullptr;              // barrier words of the last one-launch search (in `state`), nullptr: it was not one
-    int ol_last_phases = 0;
-    const unsigned* wg_stamp_dev = nullptr; int wg_stamp_blocks = 0;   // per-block stamps of the last timed kNN launch (hb_index_wg_stamps)
+    const unsigned* wg_stamp_dev = nullptr; int wg_stamp_blocks = 0;   // per-block stamps of the last timed kNN launch (hb_index_wg_stamps, hb_index_kernel_clock)
     long long small_limit = 0;                           // stages per workgroup below which a search counts as small (0 = default)
     double last_knn_ms = 0.0;                            // HIP-event time of the last knn kernel launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

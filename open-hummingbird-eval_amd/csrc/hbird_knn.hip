@@ -54,6 +54,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
     cl_sync cs;
     if constexpr (CL) cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + KN_CLWORDS);
 
+    wg_stamp<knn_args>(0);   // (every kNN kernel stamps: the share calibration reads whatever kernel the launcher picked)
     const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_end[blockIdx.x];   // this launch's share of the block's segments (phases: hb_launch_knn)
     // "everything before my first segment is done" (a member without any work: everything)
     if constexpr (CL) { if (w == 0) cl_publish(cs, seg_begin < seg_end ? a.segs[seg_begin].tile0 * g8 : 0x7FFFFFFF, lane); }
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
         __syncthreads();   // the ring is reused by the next segment's prologue
     }
     if constexpr (CL) cl_finish(cs, a.cl_stats, w == 0, lane);
+    wg_stamp<knn_args>(1);
 }
 
 // ---- merge of the partial lists of one query: rank by counting over <= slots*k candidates --------
@@ -510,6 +512,53 @@ __global__ __launch_bounds__(256) void pool_floor_kernel(const float* __restrict
 // the same shares made it SLOWER (281 -> 288-297 ms).  Shares are remembered per device and family for indexes created later.
 static std::mutex g_xcd_mu;
 static std::map<std::pair<int, int>, std::array<double, 8>> g_xcd_known;     // (device, kernel family) -> last calibrated shares
+// A launch's stamps, read on the host: per block, at its start and at its end, {100 MHz real-time counter (low word), XCC id, shader-cycle
+// counter lo, hi} (wg_stamp, hbird_knn_dev.h).  -> false when the sample cannot be trusted (the region is zeroed
+// before a stamping launch: a block that never stamped reads 0 / 0; blocks equal mod 8 that did NOT share an XCD, or two such groups on one
+// XCD, say the dispatch order is not what the share groups assume; a duration far from the others' is a wrap or a preempted block).
+// WHICH XCD a group ran on is an output (xcc[g]): HIP promises no placement, block 0 usually lands on XCD 0 but need not
+// (MI355X_MICROARCH.md, "Workgroup dispatch"), and the shares belong to the physical XCDs.
+struct hb_stamp_summary { double med[8]; int xcc[8]; double all; double span_ticks; double ghz_med, ghz_min, ghz_max; };
+static bool hb_stamps_summarise(const unsigned* st, int G, hb_stamp_summary& o) {
+    if (G < 8 || G % 8 != 0) return false;
+    std::vector<double> dur[8], every, ghz;
+    const unsigned s0 = st[0];
+    long long first = 0, last = 0;
+    for (int b = 0; b < G; ++b) {
+        const unsigned* sb = st + 8 * (size_t)b;
+        const unsigned t0 = sb[0], t1 = sb[4], xcc = sb[1];
+        if (t0 == 0u && t1 == 0u) return false;
+        if (xcc > 7u || sb[5] != xcc) return false;
+        if (b < 8) o.xcc[b] = (int)xcc;
+        else if ((int)xcc != o.xcc[b & 7]) return false;
+        const unsigned d = t1 - t0;                       // (mod 2^32: a launch is far shorter than 43 s)
+        if (d == 0u || d > 0x7FFFFFFFu) return false;
+        dur[b & 7].push_back((double)d); every.push_back((double)d);
+        const long long rs = (long long)(int)(t0 - s0), re = rs + (long long)d;
+        if (b == 0) { first = rs; last = re; }
+        first = std::min(first, rs); last = std::max(last, re);
+        const unsigned long long c0 = ((unsigned long long)sb[3] << 32) | sb[2], c1 = ((unsigned long long)sb[7] << 32) | sb[6];
+        if (c1 > c0 && d >= 100u) ghz.push_back((double)(c1 - c0) / (double)d * 0.1);       // cycles per 10 ns tick -> GHz
+    }
+    for (int x = 0, seen = 0; x < 8; ++x) { if (seen & (1 << o.xcc[x])) return false; seen |= 1 << o.xcc[x]; }
+    std::nth_element(every.begin(), every.begin() + every.size() / 2, every.end());
+    const double m_all = every[every.size() / 2];
+    o.all = 0.0;
+    for (int x = 0; x < 8; ++x) {
+        if (dur[x].empty()) return false;
+        std::nth_element(dur[x].begin(), dur[x].begin() + dur[x].size() / 2, dur[x].end());
+        o.med[x] = dur[x][dur[x].size() / 2];
+        if (!(o.med[x] > 0.5 * m_all && o.med[x] < 1.5 * m_all)) return false;
+        o.all += o.med[x] / 8.0;
+    }
+    o.span_ticks = (double)(last - first);
+    o.ghz_med = o.ghz_min = o.ghz_max = 0.0;
+    if (!ghz.empty()) {
+        std::sort(ghz.begin(), ghz.end());
+        o.ghz_med = ghz[ghz.size() / 2]; o.ghz_min = ghz.front(); o.ghz_max = ghz.back();
+    }
+    return true;
+}
 static void hb_xcd_calibrate(hb_index* ix, int fam) {
     hb_index::xcd_cal& c = ix->xcal[fam];
     if (c.rounds == 0 && !c.stamp_pending) {        // a new index starts from what this device is known to need
@@ -522,22 +571,50 @@ static void hb_xcd_calibrate(hb_index* ix, int fam) {
             c.rounds = 1;
         }
     }
-    if (!c.stamp_pending || !c.stamp_ev || hipEventQuery(c.stamp_ev) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (!c.stamp_pending || !c.stamp_ev || !c.stamp_host || hipEventQuery(c.stamp_ev) != hipSuccess) { (void)hipGetLastError(); return; }
     const int G = c.stamp_pending;
     c.stamp_pending = 0;
-    std::vector<unsigned> dur[8];
-    for (int b = 0; b < G; ++b) dur[b & 7].push_back(c.stamp_host[4 * b + 1] - c.stamp_host[4 * b]);     // (mod 2^32: a launch is far shorter than 43 s)
-    double med[8], all = 0.0;
-    for (int x = 0; x < 8; ++x) {
-        if (dur[x].empty()) return;
-        std::nth_element(dur[x].begin(), dur[x].begin() + dur[x].size() / 2, dur[x].end());
-        med[x] = (double)dur[x][dur[x].size() / 2];
-        if (!(med[x] > 0.0)) return;
-        all += med[x] / 8.0;
+    hb_stamp_summary sm;
+    if (!hb_stamps_summarise(c.stamp_host, G, sm)) { ++c.rejected; return; }
+    ++c.samples;
+    // Everything below is in terms of the PHYSICAL XCDs: group g of this launch ran on XCD sm.xcc[g] with the share stamp_w[g].  A launch
+    // whose groups sat on other XCDs than the work list assumed (c.perm) moves the map (and the list is rebuilt for it); a map that keeps
+    // moving makes shares meaningless: after three moves this index keeps equal shares.
+    double run_w[8], med[8];
+    for (int g = 0; g < 8; ++g) { run_w[sm.xcc[g]] = c.stamp_w[g]; med[sm.xcc[g]] = sm.med[g]; }
+    if (!std::equal(sm.xcc, sm.xcc + 8, c.perm)) {
+        std::copy(sm.xcc, sm.xcc + 8, c.perm);
+        ix->sched = hb_schedule();
+        if (++c.perm_moves >= 3) { for (int x = 0; x < 8; ++x) c.w[x] = 1.0; c.locked = 2; }
     }
+    if (c.locked == 2) return;
+    // The GUARD: shares are kept only while they measure faster.  Launches of one shape (the key) are compared by their span (first start to
+    // last end, the minimum over a share set's launches: clock dips only ever lengthen one); a share set that has had two launches and is still
+    // 0.15 % slower than the best set seen goes, the best set comes back, and this index stops calibrating that family (round 5's driver box
+    // ran 1.6 % slower than the builder's boxes with shares spread +- 2.8 %, and its record could not say whether the shares were the reason).
+    if (c.key != c.stamp_key) { c.key = c.stamp_key; c.best_span = 0.0; c.cur_n = 0; c.locked = 0; }
+    if (c.cur_n > 0 && std::equal(run_w, run_w + 8, c.cur_w)) { c.cur_span = std::min(c.cur_span, sm.span_ticks); ++c.cur_n; }
+    else {
+        if (c.cur_n > 0 && (c.best_span == 0.0 || c.cur_span < c.best_span)) { c.best_span = c.cur_span; std::copy(c.cur_w, c.cur_w + 8, c.best_w); }
+        std::copy(run_w, run_w + 8, c.cur_w); c.cur_span = sm.span_ticks; c.cur_n = 1;
+    }
+    auto remember = [&]() {
+        std::lock_guard<std::mutex> lock(g_xcd_mu);
+        std::array<double, 8> keep;
+        for (int x = 0; x < 8; ++x) keep[x] = c.w[x];
+        g_xcd_known[{ix->device, fam}] = keep;
+    };
+    if (c.best_span > 0.0 && c.cur_n >= 2 && c.cur_span > c.best_span * 1.0015 && !std::equal(c.cur_w, c.cur_w + 8, c.best_w)) {
+        for (int x = 0; x < 8; ++x) c.w[x] = c.best_w[x];
+        ix->sched = hb_schedule();
+        c.locked = 1; ++c.reverts; ++c.rounds;
+        remember();
+        return;
+    }
+    if (c.locked) return;
     // (a duration that is off by e in a launch holding the part f of the work is mended by e x f of the whole share)
     double w[8], mean = 0.0, change = 0.0;
-    for (int x = 0; x < 8; ++x) { w[x] = c.stamp_w[x] * (1.0 + c.stamp_frac * (all / med[x] - 1.0)); mean += w[x] / 8.0; }
+    for (int x = 0; x < 8; ++x) { w[x] = run_w[x] * (1.0 + c.stamp_frac * (sm.all / med[x] - 1.0)); mean += w[x] / 8.0; }
     for (int x = 0; x < 8; ++x) {
         w[x] = std::min(1.25, std::max(0.8, w[x] / mean));
         if (fam && c.rounds >= 2) w[x] = 0.5 * (w[x] + c.w[x]);      // the fp16 kernel's durations scatter by +- 0.5 % from search to search: damped ...
@@ -548,23 +625,22 @@ static void hb_xcd_calibrate(hb_index* ix, int fam) {
     if (change > worth) {
         for (int x = 0; x < 8; ++x) c.w[x] = w[x];
         ix->sched = hb_schedule();                            // rebuilt with the new shares by the caller
-        std::lock_guard<std::mutex> lock(g_xcd_mu);
-        std::array<double, 8> keep;
-        for (int x = 0; x < 8; ++x) keep[x] = w[x];
-        g_xcd_known[{ix->device, fam}] = keep;
+        remember();
     }
     ++c.rounds;
 }
 // behind a calibrating launch: its per-block stamps -> pinned host memory, read by the next big search of the family if the copy has completed by then
 static int hb_xcd_collect(hb_index* ix, int fam, const unsigned* stamps_dev, const hb_schedule& sc, const double* shares, int n_phases, int nqt, int nbt,
-                          hipStream_t s) {
+                          int k, hipStream_t s) {
     hb_index::xcd_cal& c = ix->xcal[fam];
     if (!stamps_dev || sc.G > 1024 || c.stamp_pending) return 0;
-    if (!c.stamp_host) { HB_HIP(hipHostMalloc((void**)&c.stamp_host, 1024 * 16, hipHostMallocDefault)); HB_HIP(hipEventCreateWithFlags(&c.stamp_ev, hipEventDisableTiming)); }
-    HB_HIP(hipMemcpyAsync(c.stamp_host, stamps_dev, (size_t)sc.G * 16, hipMemcpyDeviceToHost, s));
+    if (!c.stamp_ev) HB_HIP(hipEventCreateWithFlags(&c.stamp_ev, hipEventDisableTiming));
+    if (!c.stamp_host) HB_HIP(hipHostMalloc((void**)&c.stamp_host, 1024 * 32, hipHostMallocDefault));
+    HB_HIP(hipMemcpyAsync(c.stamp_host, stamps_dev, (size_t)sc.G * 32, hipMemcpyDeviceToHost, s));
     HB_HIP(hipEventRecord(c.stamp_ev, s));
     c.stamp_pending = sc.G;
     for (int x = 0; x < 8; ++x) c.stamp_w[x] = shares[x];
+    c.stamp_key = {nqt, nbt, sc.G, n_phases, k, sc.cq * 16 + sc.cb};
     // a phased search stamps its last launch.  Cuts that follow the shares (long lists, hb_finish_schedule) make it a fair sample; with
     // common cuts a group's extra share is all in that launch -- its part of the work
     const double per_wg = (double)nqt * (double)nbt / std::max(1, sc.G);
@@ -626,7 +702,9 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
                 // 2.5 x the bank) may take up to 55 % of the device: 10 M x 768 (77 of 288 GB) gets the copy, 20 M x 1024 (207 GB) does not; an
                 // allocation that fails all the same just means no copy
                 const size_t bank_b = (size_t)ix->cap_rows * ix->dp * 4;
-                if (ix->rerank_copy == 1 || (bank_b + bank_b / 2 + need <= total_b / 100 * 55 && free_b > need)) {
+                // (and with room to spare: the search's own workspace -- candidate lists, pools, the work list -- is allocated after the copy,
+                // and a device shared with a model or another rank must not be filled to the brim by an optional copy)
+                if (ix->rerank_copy == 1 || (bank_b + bank_b / 2 + need <= total_b / 100 * 55 && free_b > need + std::max<size_t>(total_b / 16, (size_t)2 << 30))) {
                     if (hipMalloc((void**)&ix->rows32, need) == hipSuccess) { ix->rows32_cap_rows = ix->cap_rows; ix->rows32_rs = rs; ix->rows32_rows = 0; ix->rows32_declined_cap = -1; }
                     else { (void)hipGetLastError(); ix->rows32 = nullptr; if (ix->rerank_copy == 1) return hb_fail("hb_index_search: no memory for the re-rank copy of the bank"); }
                 }
@@ -712,7 +790,18 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
                          (ix->xcd_balance == 2 || (ix->xcd_balance == 0 && (long long)nqt * nbt / std::max(1, G) * ix->g8 >= 30000));
     if (balance && ix->xcd_balance == 0) hb_xcd_calibrate(ix, fam);
     static const double equal_shares[8] = {1, 1, 1, 1, 1, 1, 1, 1};
-    const double* shares = balance ? ix->xcal[fam].w : equal_shares;
+    // (shares divided by their mean: eight equal shares of any size are the equal list, which is cached as such)
+    double shares_n[8];
+    const double* shares = equal_shares;
+    if (balance) {
+        double mean = 0.0;
+        bool uneven = false;
+        // calibrated shares belong to the physical XCDs: group g (blocks equal to g mod 8) gets the share of the XCD it was last seen on
+        const hb_index::xcd_cal& xc = ix->xcal[fam];
+        for (int x = 0; x < 8; ++x) mean += xc.w[x] / 8.0;
+        for (int g = 0; g < 8; ++g) { shares_n[g] = xc.w[ix->xcd_balance == 0 ? xc.perm[g] : g] / mean; uneven = uneven || std::fabs(shares_n[g] - 1.0) > 1e-9; }
+        if (uneven) shares = shares_n;
+    }
     hb_schedule& sc = ix->sched;
     // phased searches (pools only: "Phased searches" above hb_launch_knn); hb_index_set_search_options(ix, 0, ...) turns them off (A/B, tests)
     const bool phased = wide && ix->phases_on;
@@ -724,7 +813,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     const bool rebuilt = !(sc.nqt == nqt && sc.nbt == nbt && sc.panel == panel && sc.cq == cq && sc.cb == cb && sc.phased == phased &&
                            sc.xcd_share == xs && (sc.G == G || (long long)nqt * nbt < G) &&
                            (sc.xcd_w.empty() ? std::equal(shares, shares + 8, equal_shares) : std::equal(shares, shares + 8, sc.xcd_w.begin())));
-    if (rebuilt) hb_build_schedule(nqt, nbt, G, panel, sc, cq, cb, phased, xs, shares);
+    if (rebuilt) { hb_build_schedule(nqt, nbt, G, panel, sc, cq, cb, phased, xs, shares); ++ix->sched_builds; }
     // device copy of the work list: [segs][wg_off][qt_off][qt_slots][wg_member]
     const size_t b_segs = sc.segs.size() * sizeof(hb_seg), b_wg = sc.wg_off.size() * 4, b_qo = sc.qt_off.size() * 4,
                  b_qs = sc.qt_slots.size() * 4, b_wm = sc.wg_member.size() * 4;
@@ -747,14 +836,13 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     const size_t state_aux = wide ? (size_t)sc.n_slots * HB_QT * 4 : 0;   // pools: fill counts + thresholds
     const size_t floor_bytes = (size_t)nqt * HB_QT * 4 * 17;              // shared threshold floors, one per query, + 16 quota-floor keys per query
     const size_t prog_bytes = ((size_t)std::max(1, sc.n_clusters) * HB_CLUSTER_MAX + 1) * HB_CLUSTER_LINE * 4;   // progress words, a line each, + statistics
-    const size_t stamp_bytes = (size_t)sc.G * 16;                       // per-block {start, end, XCC id} stamps of the last kNN launch (diagnostics, with hb_index_set_timing)
-    const size_t gb_bytes = ((size_t)HB_GB_WORDS(sc.G) + (size_t)HB_PHASE_CUTS * 4 * sc.G) * 4;   // grid-barrier words of a one-launch search (zeroed per search) + time stamps (diagnostics)
-    if (ensure_bytes(&ix->state, &ix->state_bytes, 2 * state_half + 2 * state_aux + floor_bytes + prog_bytes + gb_bytes + stamp_bytes)) return -1;
+    const size_t stamp_bytes = (size_t)sc.G * 32;                       // per-block {start, end, XCC id} stamps of the last kNN launch with its shader-cycle counts (wg_stamp, hbird_knn_dev.h)
+    if (ensure_bytes(&ix->state, &ix->state_bytes, 2 * state_half + 2 * state_aux + floor_bytes + prog_bytes + stamp_bytes)) return -1;
 
     knn_args a;
-    memset(&a.ol, 0, sizeof(a.ol));
-    a.wg_stamp = (ix->time_kernels || (balance && ix->xcd_balance == 0)) ? reinterpret_cast<unsigned*>(ix->state + 2 * state_half + 2 * state_aux + floor_bytes + prog_bytes + gb_bytes) : nullptr;
+    a.wg_stamp = (ix->time_kernels || (balance && ix->xcd_balance == 0)) ? reinterpret_cast<unsigned*>(ix->state + 2 * state_half + 2 * state_aux + floor_bytes + prog_bytes) : nullptr;
     ix->wg_stamp_dev = a.wg_stamp; ix->wg_stamp_blocks = sc.G;
+    if (a.wg_stamp) HB_HIP(hipMemsetAsync(a.wg_stamp, 0, stamp_bytes, s));   // a block that never stamps reads 0 / 0 (hb_stamps_summarise)
     a.bank_tiles = ix->tiles; a.binit = ix->binit; a.q_tiles = ix->q_tiles;
     a.segs = reinterpret_cast<const hb_seg*>(ix->sched_dev);
     a.wg_off = reinterpret_cast<const int*>(ix->sched_dev + o_wg);
@@ -807,37 +895,6 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         HB_HIP(hipGetLastError());
         return 0;
     };
-    // ONE launch for all phases (hbird_knn_dev.h, "One launch per phased search"; hb_index_set_one_launch(ix, 2, ...)): the kernels with
-    // register-resident query fragments and the fp16 candidate kernel, every workgroup resident (one per CU), a query tile's pools within
-    // the LDS that is free between two phases.  The completion launch behind it costs about 2 us when nothing went wrong.
-    // OPT-IN, not the default: what a launch per phase costs beyond its tiles is the arrival skew of the workgroups at the phase's end
-    // (10-60 us: they wait for the slowest either way, at a grid barrier as at a kernel's tail) and the floor computation (25-30 us as a
-    // launch of its own with 28 waves per CU, 36-48 us inside a kernel that has eight), not the launches (about 2 us each).  Same box,
-    // whole searches, a launch per phase / one launch: 50,176 x 384 fp32 3.81 / 3.99 ms, use_fp16 1.36 / 1.50; 300,000 x 768 use_fp16 6.57 /
-    // 6.88; 2,074,072 x 384 use_fp16 20.1 / 20.7 (profiles/r05/one_launch_*.txt).
-    hb_one_launch ol;
-    memset(&ol, 0, sizeof(ol));
-    ix->ol_words_dev = nullptr; ix->ol_last_phases = n_phases;
-    {
-        const size_t per_wave = (size_t)sc.max_slots_per_qt * klw;
-        const bool kernel_ok = f16 || (bd_shape && (ix->variant == 0 || ix->variant == 3 || ix->variant == 6));
-        const size_t lds_free = f16 ? (size_t)hb_knn_f16_floor_lds_bytes() : (size_t)hb_knn_bd_floor_lds_bytes();
-        if (wide && n_phases > 1 && ix->one_launch == 2 && kernel_ok && sc.G <= ix->num_cu && sc.max_slots_per_qt <= 32 &&
-            2 * per_wave * 4 * HB_WAVES <= lds_free && nq < (1ll << 31)) {
-            ol.gb = reinterpret_cast<unsigned*>(ix->state + 2 * state_half + 2 * state_aux + floor_bytes + prog_bytes);
-            ol.phase_bounds = pb;
-            ol.qt_off = reinterpret_cast<const int*>(ix->sched_dev + o_qo);
-            ol.qt_slots = reinterpret_cast<const int*>(ix->sched_dev + o_qs);
-            ol.n_phases = n_phases; ol.G = sc.G; ol.nq = (int)nq; ol.per_wave = (int)per_wave;
-            // a barrier waits for the slowest workgroup of a phase: never longer than the whole search at a third of the fp32 rate
-            const double est_ms = 2.0 * (double)nq * (double)ix->ntotal * (double)ix->d / 47e12 * 1e3;
-            const double to_us = ix->ol_timeout_us > 0 ? (double)ix->ol_timeout_us : 20000.0 + 2000.0 * est_ms;
-            ol.timeout = (unsigned)std::min(4.0e9, to_us * 100.0);          // ticks of the 100 MHz real-time counter
-            ol.inject = ix->ol_inject;
-            HB_HIP(hipMemsetAsync(ol.gb, 0, gb_bytes, s));
-            ix->ol_words_dev = ol.gb;
-        }
-    }
     if (f16) {
         // fp16 copy of the query fragment tiles (the bank's is up to date: top of this function)
         const int64_t nqp = (int64_t)nqt * HB_QT;
@@ -847,7 +904,6 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         int64_t* cand_idx = reinterpret_cast<int64_t*>(ix->cand);
         float* cand_dist = reinterpret_cast<float*>(ix->cand + (size_t)nq * kc * 8);
         knn16_args h;
-        memset(&h.ol, 0, sizeof(h.ol));
         h.wg_stamp = a.wg_stamp;
         h.bank16 = reinterpret_cast<const _Float16*>(ix->tiles16); h.binit = ix->binit; h.q16 = reinterpret_cast<const _Float16*>(ix->q16); h.segs = a.segs; h.wg_off = a.wg_off; h.wg_end = a.wg_end;
         h.state_s = a.state_s; h.state_i = a.state_i; h.g16 = ix->dp16 / 16; h.k = kc; h.klw = klw;
@@ -858,12 +914,6 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
             HB_HIP(hipMemsetAsync(a.state_cnt, 0, state_aux, s));
             HB_HIP(hipMemsetD32Async((hipDeviceptr_t)a.state_thr, 0xFF800000u, state_aux / 4, s));
         }
-        h.ol = ol;
-        if (ol.gb) {      // all phases in one launch, then the completion launch (a no-op unless a barrier was given up)
-            if (hb_knn_f16_launch(h, sc.G, s)) return -1;
-            h.ol.resume = 1;
-            if (hb_knn_f16_launch(h, sc.G, s)) return -1;
-        } else
         for (int ph = 0; ph < n_phases; ++ph) {
             h.wg_off = phase_begin(ph); h.wg_end = phase_end(ph);
             if (hb_knn_f16_launch(h, sc.G, s)) return -1;
@@ -873,7 +923,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
             }
         }
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
-        if (balance && ix->xcd_balance == 0 && !ol.gb && hb_xcd_collect(ix, 1, a.wg_stamp, sc, shares, n_phases, nqt, nbt, s)) return -1;
+        if (balance && ix->xcd_balance == 0 && hb_xcd_collect(ix, 1, a.wg_stamp, sc, shares, n_phases, nqt, nbt, kc, s)) return -1;
         if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, pool_cnt ? a.state_thr : nullptr, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
                          reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, kc, klw, 0, 0, nullptr,
                          cand_idx, cand_dist, s)) return -1;
@@ -953,7 +1003,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // fp32 MFMA peak), same bits.  Default for the big LDS-list searches whose stage count per tile is a multiple of four
     // (D = 384, 768, 1024, ...); variant 3 forces it wherever it applies (tests), variant 4 keeps the LDS-staged kernel.
     if (bd_shape && (ix->variant == 0 || ix->variant == 3 || ix->variant == 6)) {
-        fn = hb_knn_bd_kernel(wide, a.cl > 1, small, ol.gb != nullptr);
+        fn = hb_knn_bd_kernel(wide, a.cl > 1, small);
         lds_bytes = hb_knn_bd_lds_bytes(small && !wide);
     }
     if (hb_ensure_dyn_lds((const void*)fn, lds_bytes)) return -1;   // per (kernel, device)
@@ -962,14 +1012,6 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         HB_HIP(hipMemsetAsync(a.state_cnt, 0, state_aux, s));
         HB_HIP(hipMemsetD32Async((hipDeviceptr_t)a.state_thr, 0xFF800000u, state_aux / 4, s));
     }
-    a.ol = ol;
-    if (ol.gb) {      // all phases in one launch, then the completion launch (a no-op unless a barrier was given up)
-        fn<<<dim3((unsigned)sc.G), dim3(threads), lds_bytes, s>>>(a);
-        HB_HIP(hipGetLastError());
-        a.ol.resume = 1;
-        fn<<<dim3((unsigned)sc.G), dim3(threads), lds_bytes, s>>>(a);
-        HB_HIP(hipGetLastError());
-    } else
     for (int ph = 0; ph < n_phases; ++ph) {
         a.wg_off = phase_begin(ph); a.wg_end = phase_end(ph);
         fn<<<dim3((unsigned)sc.G), dim3(threads), lds_bytes, s>>>(a);
@@ -980,7 +1022,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         }
     }
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
-    if (balance && ix->xcd_balance == 0 && hb_xcd_collect(ix, 0, a.wg_stamp, sc, shares, n_phases, nqt, nbt, s)) return -1;
+    if (balance && ix->xcd_balance == 0 && hb_xcd_collect(ix, 0, a.wg_stamp, sc, shares, n_phases, nqt, nbt, k, s)) return -1;
     const float* qn2 = ix->q_aux;   // [nq] chain ||q||^2 (valid for L2)
     if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, pool_cnt ? a.state_thr : nullptr, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
                      reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, k, klw, id_base, out_metric,

@@ -45,10 +45,9 @@
 // WIDE: k > HB_KL, candidate pools in global memory; CL: member of an L2-sharing cluster (strided segments on a common
 // clock, soft sync from wave 0); COLD: small search (radix-select cold start, scan epilogue, per-tile floors) -- all as in
 // hbird_knn.hip
-// OL: the instantiation that can run all phases of a pool search in one launch (hbird_knn_dev.h, "One launch per phased search") -- its own
-// instantiation, so that the others keep their register allocation (a call on the boundary path costs the stage loop four reloads of spilled
-// scalars: +0.4 % at k = 90, 5 M x 768)
-template <bool WIDE, bool CL, bool COLD = false, bool OL = false>
+// (Round 5's OL instantiations -- all phases of a pool search in ONE launch behind a grid barrier -- measured 2-10 % slower than a launch per
+// phase and were removed in round 6: profiles/r05/one_launch_*.txt, git history.)
+template <bool WIDE, bool CL, bool COLD = false>
 __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -69,11 +68,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
     if constexpr (CL) cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + BD_CLWORDS);
 
     wg_stamp<knn_args>(0);
-    [[maybe_unused]] int ol_ph = 0;   // OL: the phase being run
-    if constexpr (OL) { if (!ol_enter<knn_args>(ol_ph)) return; }
-  for (;;) {
-    int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_end[blockIdx.x];   // this launch's share of the block's segments (phases: hb_launch_knn)
-    if constexpr (OL) ol_range<knn_args>(ol_ph, HB_KARG(knn_args, wg_off), HB_KARG(knn_args, wg_end), seg_begin, seg_end);
+    const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_end[blockIdx.x];   // this launch's share of the block's segments (phases: hb_launch_knn)
     // "everything before my first segment is done" (a member without any work: everything)
     if constexpr (CL) { if (w == 0) cl_publish(cs, seg_begin < seg_end ? a.segs[seg_begin].tile0 * g8 : 0x7FFFFFFF, lane); }
     for (int si = seg_begin; si < seg_end; ++si) {
@@ -266,21 +261,13 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_bd_kernel(knn_args a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // the ring and the lists are reused by the next segment
     }
-    if constexpr (OL) { if (ol_boundary<knn_args>(ol_ph, smem, w, lane)) continue; }
-    break;
-  }
     if constexpr (CL) cl_finish(cs, a.cl_stats, w == 0, lane);
     wg_stamp<knn_args>(1);
 }
 
-hb_knn_fn hb_knn_bd_kernel(bool wide, bool clustered, bool small, bool one_launch) {
-    if (one_launch && wide) {
-        if (small && !clustered) return knn_fused_bd_kernel<true, false, true, true>;
-        return clustered ? knn_fused_bd_kernel<true, true, false, true> : knn_fused_bd_kernel<true, false, false, true>;
-    }
+hb_knn_fn hb_knn_bd_kernel(bool wide, bool clustered, bool small) {
     if (small && !clustered) return wide ? knn_fused_bd_kernel<true, false, true> : knn_fused_bd_kernel<false, false, true>;
     if (clustered) return wide ? knn_fused_bd_kernel<true, true> : knn_fused_bd_kernel<false, true>;
     return wide ? knn_fused_bd_kernel<true, false> : knn_fused_bd_kernel<false, false>;
 }
 int hb_knn_bd_lds_bytes(bool small_lists) { return small_lists ? BD_LDS_TOTAL_COLD : BD_LDS_TOTAL; }
-int hb_knn_bd_floor_lds_bytes() { return BD_CLWORDS; }   // what the floor computation of a one-launch search may use between two phases

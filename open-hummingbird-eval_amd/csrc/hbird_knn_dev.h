@@ -9,22 +9,6 @@ typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
 struct knn_args_pool_view { int* cnt; float* thr; };
 
-// One launch per phased search (kernel arguments; all zero: the classic one-launch-per-phase form, wg_off / wg_end give the range).
-struct hb_one_launch {
-    unsigned* gb;             // grid-barrier words (HB_GB_*), zeroed before the launch; nullptr: off
-    const int* phase_bounds;  // [n_phases - 1][G]: per cut and block the first segment of the next phase (hb_schedule::phase_bounds)
-    const int* qt_off;        // slots of each query tile (the floor computation between two phases reads their pools)
-    const int* qt_slots;
-    int n_phases;
-    int G;
-    int nq;                   // queries (without the padding of the last tile)
-    int per_wave;             // floats of LDS scratch per QUERY of the floor computation (max slots per query tile x pool capacity; a wave holds two queries)
-    int resume;               // 1: the completion launch -- does nothing unless the first launch gave up at a barrier, then finishes every block's list
-    unsigned timeout;         // ticks of s_memrealtime (100 MHz) a workgroup waits at a barrier before it gives up
-    int inject;               // tests: (mode << 28) | (phase << 16) | block + 1 -- that block fails at that boundary (mode 1: raises the abort flag; 2: leaves silently)
-    int pad_;
-};
-
 struct knn_args {
     const float* bank_tiles;
     const float* binit;
@@ -46,8 +30,7 @@ struct knn_args {
     int lag;                // soft sync: a member waits while another one is more than `lag` stages behind (0: never)
     int* cl_stats;          // {checks, spins, timeouts} of the launch
     unsigned* qfl;          // [query][16]: quota floors of small searches (monotone keys; columns 0-6 / 8-14 per slot of the query tile, 7 the plain floor)
-    hb_one_launch ol;       // phased searches in ONE launch (grid barrier + in-kernel floors): "One launch per phased search" below
-    unsigned* wg_stamp;     // diagnostics (hb_index_set_timing): [block][4] = {start, end} low words of s_memrealtime, XCC id, 0; nullptr: off
+    unsigned* wg_stamp;     // diagnostics (hb_index_set_timing) and share calibration: [block][2][4], see wg_stamp(); nullptr: off
 };
 
 // A kernel argument read again from the kernarg segment at the point of use (through a laundered pointer, so that the
@@ -82,22 +65,29 @@ struct knn16_args {
     int cl;
     int lag;
     int* cl_stats;
-    hb_one_launch ol;
     unsigned* wg_stamp;
 };
 
-// Diagnostics: when and where a workgroup ran (per-XCD speed differences show up as the last blocks of every launch belonging to one XCD)
+// Diagnostics: when and where a workgroup ran (per-XCD speed differences show up as the last blocks of every launch belonging to one XCD),
+// and at which clock: s_memtime counts shader cycles, s_memrealtime 10 ns ticks, so (d cycles / d ticks) x 100 MHz is the clock the
+// workgroup's CU held over the launch -- read without any profiler attached (MI355X_MICROARCH.md, "DVFS give-back" item 6).  Two stamps per
+// workgroup and launch, outside every loop: [block][which] = {s_memrealtime (low word), XCC id, s_memtime lo, hi}, 16 bytes in ONE store.
+// The store is inline asm WITHOUT a memory clobber (nothing in the kernel reads the stamps), and there is one per stamp: the variants with
+// several stores, or with a table offset read from the arguments, made hipcc turn the segment loop's work-list loads into vector loads,
+// whose values the stage loops feed to "s" operands ("illegal VGPR to SGPR copy").
 template <class ARGS>
 __device__ __forceinline__ void wg_stamp(int which) {
     unsigned* st = HB_KARG(ARGS, wg_stamp);
     if (st == nullptr || threadIdx.x != 0) return;
-    st += 4 * blockIdx.x;
-    if (which == 0) {
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        st[2] = xcc & 0xFu;
-    }
-    st[which] = (unsigned)__builtin_amdgcn_s_memrealtime();
+    st += 8 * blockIdx.x + 4 * which;
+    unsigned long long cyc, rt;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(cyc), "=s"(rt));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v;
+    v[0] = (unsigned)rt; v[1] = xcc & 0xFu; v[2] = (unsigned)cyc; v[3] = (unsigned)(cyc >> 32);
+    asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(st), "v"(v));
 }
 
 // ---- soft sync of an L2-sharing cluster (hb_build_clustered) ---------------------------------------------------------
@@ -743,84 +733,19 @@ __device__ __forceinline__ float cold_start_threshold(f32x16 (&acc)[8], int k) {
     return lo;
 }
 
-// ---- one launch per phased search ------------------------------------------------------------------------------------------
-// A phased search (pools: k > HB_KL, small fp32 searches, the fp16 candidate pass) used to be one launch per phase with a floor kernel
-// between two launches: 40-70 us per launch beyond its tiles plus 20-33 us per floor kernel (profiles/LABBOOK.md 7.3) -- a quarter of the fp16
-// candidate kernel's time at BASELINE cfg-1.  Here the workgroups stay resident over all phases.  At a phase boundary every workgroup
-//   1. has stored its pools' fill counts / thresholds (pool_end; every wave drained its stores), releases them (agent scope) and
-//      arrives at a grid barrier;
-//   2. behind the barrier acquires, and computes the floors of ITS share of the queries from all slots' pools (pool_floor_query: what
-//      pool_floor_kernel did in a launch of its own), publishing them by atomic max;
-//   3. arrives at a second barrier (no data behind it: it only keeps the next phase's appends and compactions away from pools that
-//      another workgroup still reads) and goes on.
-// Unlike every other exchange in these kernels -- floors and progress clocks are hints -- step 2 reads data that must be COMPLETE: a pool
-// read while its owner compacts it can show one entry twice, and a floor that k rows do not reach loses neighbours.  Hence the rule:
-// NOBODY WRITES A POOL AFTER A FAILED BARRIER IN THIS LAUNCH.  A workgroup that waits longer than `timeout` (a peer that is not resident:
-// the device shared with another kernel) raises the abort flag, records how many phases it has completed and EXITS; so does every
-// workgroup that sees the flag at a barrier, and a workgroup that only starts after the flag was raised.  The host always enqueues a
-// second, "completion" launch of the same kernel behind it: it returns at once when the flag is down (about 2 us), otherwise every block
-// finishes its list from its recorded phase on, without barriers, on the floors published so far (any valid floors give the same
-// final bits).  Spins are bounded by the 100 MHz real-time counter, so the device cannot hang.
-// Barrier (MI355X_MICROARCH.md, price list, "barrier-xcd" with one difference): arrivals are counted on eight sharded counters (blocks
-// equal mod 8 -- normally one XCD), the last arriver of a shard adds to a top counter, the last of those sets every shard's generation
-// word, which the shard's workgroups poll (relaxed sc1 loads, s_sleep).  Every workgroup releases for ITSELF (buffer_wbl2 sc1 from one
-// lane behind the workgroup's barrier) instead of one leader per XCD for its whole L2: which blocks share an XCD is placement, and
-// results must not depend on placement.
-#define HB_GB_LINE 32                       // words per 128-byte line
-#define HB_GB_TOP (8 * HB_GB_LINE)
-#define HB_GB_GEN (9 * HB_GB_LINE)          // eight lines
-#define HB_GB_ABORT (17 * HB_GB_LINE)
-#define HB_GB_STATS (18 * HB_GB_LINE)       // {boundaries passed by block 0, ticks block 0 spent in barrier 1, in the floors, in barrier 2, timeouts}
-#define HB_GB_PROGRESS (20 * HB_GB_LINE)    // [G]: phases completed by each block when it left the launch
-#define HB_GB_WORDS(G) (HB_GB_PROGRESS + ((G) + 31) / 32 * 32)
-// behind them, diagnostics (inject kind 3): [boundary][4][G] low words of s_memrealtime -- arrival at barrier 1, its pass, floors done, pass of barrier 2
-
+// ---- floors between two phases of a pool search ---------------------------------------------------------------------------
+// (Round 5 also ran all phases in ONE launch -- resident workgroups, a grid barrier and the floor computation inside the kNN kernels; it
+// measured 2-10 % slower than a launch per phase, whose cost is arrival skew and the floor computation, not the launches, and was removed in
+// round 6: profiles/r05/one_launch_*.txt, profiles/LABBOOK.md, git history.)
 typedef __attribute__((address_space(1))) unsigned hb_gu32;
 __device__ __forceinline__ unsigned gb_load(const unsigned* p) {
     return __hip_atomic_load((const hb_gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void gb_store(unsigned* p, unsigned v) { __hip_atomic_store((hb_gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned gb_add(unsigned* p, unsigned v) {
-    return __hip_atomic_fetch_add((hb_gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// One grid-wide arrival + wait, called by ONE wave of the workgroup (after the workgroup's own barrier): generation gen = 1, 2, ...
-// `release`: this workgroup's plain stores are handed over (write-back before the arrival); the caller acquires after a pass.
-// Returns 1 when all G workgroups have arrived, 0 when the launch is given up (abort flag seen, or raised here after `timeout` ticks).
-__device__ __forceinline__ int gb_arrive_wait(unsigned* gb, unsigned gen, int G, unsigned timeout, bool release, int lane) {
-    int ok = 1;
-    if (lane == 0) {
-        if (release) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the pass that drops the fence's own wait does not see inline asm)
-        }
-        const int grp = blockIdx.x & 7, ngrp = G < 8 ? G : 8;
-        const unsigned gsize = (unsigned)((G - grp + 7) >> 3);
-        if (gb_add(gb + grp * HB_GB_LINE, 1u) + 1u == gsize * gen) {
-            if (gb_add(gb + HB_GB_TOP, 1u) + 1u == (unsigned)ngrp * gen)
-                for (int x = 0; x < ngrp; ++x) gb_store(gb + HB_GB_GEN + x * HB_GB_LINE, gen);
-        }
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        for (;;) {
-            if (gb_load(gb + HB_GB_GEN + grp * HB_GB_LINE) >= gen) break;
-            if (gb_load(gb + HB_GB_ABORT) != 0u) { ok = 0; break; }
-            if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)timeout) {
-                gb_store(gb + HB_GB_ABORT, 1u);
-                gb_add(gb + HB_GB_STATS + 4, 1u);
-                ok = 0;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(4);
-        }
-    }
-    return __builtin_amdgcn_readfirstlane(ok);
 }
 
 // The floor of query q from its slots' pools: the scores that can matter (at or above the best threshold a full pool already has) are
 // gathered into `cs` (LDS, per_wave floats of this wave) and a score that at least kk of them EXCEED is found by 14 halvings between the
 // smallest and the largest (any such score is a valid floor: cold_start_threshold).  One wave; called by pool_floor_kernel (a launch
-// between two phases) and by the kNN kernels themselves at the phase boundaries of a one-launch search.  Loads bypass the L1 (sc1): inside
-// a launch the pools were written by other workgroups.  All of a slot's entries are requested before the first is looked at, and the
+// between two phases).  Loads bypass the L1 (sc1).  All of a slot's entries are requested before the first is looked at, and the
 // next slot's while one is compacted into LDS.
 __device__ __forceinline__ float pf_load(const float* p) {
     return __builtin_bit_cast(float, __hip_atomic_load((const hb_gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -904,231 +829,6 @@ static __device__ __attribute__((noinline, unused)) void pool_floor_query(const 
     if (lane == 0 && lo > -INFINITY) atomicMax(gthr + q, pool_key(lo));   // kk rows exceed lo
 }
 
-// The same for TWO queries at a time, one per lane half (query tiles with at most 32 slots -- every search that qualifies for one launch,
-// and most others).  The floor computation is latency-bound (two dependent round trips per query: fill counts, then entries -- bytes that
-// other workgroups wrote, so they come from beyond the L2 -- against about a microsecond of compares and ballots), and a persistent kNN
-// kernel has only eight waves per CU to hide it with: as one query per wave it took 43-60 us per phase boundary for 12,544 queries,
-// twice the launch it replaced.  Here a wave's two halves work on different queries under the same instructions (ballots are split by
-// half, every per-query scalar lives in a VGPR that is uniform within its half), and the fill counts / thresholds of the NEXT pair are
-// requested before the current pair's entries: one round trip and half the compute per pair.
-//   q0, q1: the two queries (q1 < 0: none); cs: 2 x per_half floats of LDS of this wave; pre_*: this lane's prefetched (fill count,
-//   threshold, slot) of its half's query (lane hl = slot hl), or call with have_pre = false.
-struct pf_pre { int cnt; float thr; int slot; int ns; int s0; };
-__device__ __forceinline__ pf_pre pool_floor_prefetch(const int* __restrict__ cnts, const float* __restrict__ pthr, const int* __restrict__ qt_off,
-                                                       const int* __restrict__ qt_slots, int64_t q, int kk, int lane) {
-    pf_pre p; p.cnt = 0; p.thr = -INFINITY; p.slot = 0; p.ns = 0; p.s0 = 0;
-    if (q < 0) return p;
-    const int qt = (int)(q / HB_QT), ql = (int)(q % HB_QT), hl = lane & 31;
-    p.s0 = qt_off[qt]; p.ns = qt_off[qt + 1] - p.s0;
-    if (hl < p.ns) {
-        p.slot = qt_slots[p.s0 + hl];
-        const size_t oq = (size_t)p.slot * HB_QT + ql;
-        p.cnt = (int)gb_load(reinterpret_cast<const unsigned*>(cnts) + oq);
-        p.thr = pf_load(pthr + oq);
-    }
-    return p;
-}
-static __device__ __attribute__((noinline)) void pool_floor_pair(const float* __restrict__ state_s, int64_t q, const pf_pre pre, int kk, int klw,
-                                                                 float* cs_wave, int per_half, unsigned* __restrict__ gthr, int lane) {
-    const int H = lane >> 5, hl = lane & 31;
-    const unsigned long long hmask = H ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
-    const unsigned long long below = ((1ull << hl) - 1ull) << (H * 32);          // lanes of my half below me
-    float* cs = cs_wave + (size_t)H * per_half;
-    const int ql = q < 0 ? 0 : (int)(q % HB_QT);
-    const int ns = pre.ns;
-    // tstar: the best threshold a full pool of this query already has
-    float tstar = (hl < ns && pre.cnt >= kk) ? pre.thr : -INFINITY;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) tstar = fmaxf(tstar, __shfl_xor(tstar, o));
-    int ns_max = max(ns, __shfl_xor(ns, 32));       // the halves loop together
-    int n = 0;
-    float hi = -INFINITY, mn = INFINITY;
-    constexpr int EM = HB_POOL_MAX / 32;            // entries per lane and slot
-    const int eu = (klw + 31) >> 5;
-    for (int j = 0; j < ns_max; ++j) {
-        const int c = __shfl(pre.cnt, (lane & 32) + j), slot = __shfl(pre.slot, (lane & 32) + j);
-        const int nv = j < ns ? min(klw, c) : 0;
-        const float* src = state_s + ((size_t)slot * HB_QT + ql) * klw;
-        float v[EM];
-#pragma unroll
-        for (int u = 0; u < EM; ++u) {
-            v[u] = -INFINITY;
-            if (u < eu) { const int e = u * 32 + hl; if (e < nv) v[u] = pf_load(src + e); }
-        }
-#pragma unroll
-        for (int u = 0; u < EM; ++u) {
-            if (u < eu) {
-                const int e = u * 32 + hl;
-                const bool keep = e < nv && (v[u] >= tstar || tstar == -INFINITY);
-                const unsigned long long m = __ballot(keep);
-                if (keep) { cs[n + __popcll(m & below)] = v[u]; hi = fmaxf(hi, v[u]); mn = fminf(mn, v[u]); }
-                n += __popcll(m & hmask);
-            }
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are visible to its lanes
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) { hi = fmaxf(hi, __shfl_xor(hi, o)); mn = fminf(mn, __shfl_xor(mn, o)); }
-    const bool have = q >= 0 && n >= kk;           // fewer than kk rows seen so far: no floor yet
-    hi = fminf(hi, 3.4028234664e38f);
-    float lo = mn - fmaxf(fabsf(mn) * 1e-6f, 1.2e-38f);   // all n exceed it (cold_start_threshold)
-    // the first 256 gathered scores of each half in registers (usually all of them): a round is then compares and ballots only
-    float r[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = (i * 32 + hl < n) ? cs[i * 32 + hl] : -INFINITY;
-    const bool stretched = !(hi - mn <= 1e30f);   // an astronomically large score: halve the interval of the monotone keys (cold_start_threshold)
-    const int n_max = max(n, __shfl_xor(n, 32));
-    for (int it = 0; it < 14; ++it) {
-        float mid = 0.5f * lo + 0.5f * hi;
-        if (stretched) {
-            const unsigned klo = pool_key(lo), khi = pool_key(hi);
-            unsigned km = klo + ((khi - klo) >> 1);
-            if (km == 0x7FFFFFFFu) km = 0x7FFFFFFEu;
-            mid = __builtin_bit_cast(float, (km & 0x80000000u) ? (km ^ 0x80000000u) : ~km);
-        }
-        int c = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) c += __popcll(__ballot(r[i] > mid) & hmask);
-        for (int base = 256; base < n_max; base += 32) c += __popcll(__ballot(base + hl < n && cs[base + hl] > mid) & hmask);
-        if (c >= kk) lo = mid; else hi = mid;
-    }
-    __builtin_amdgcn_wave_barrier();      // (the next pair of this wave reuses `cs`)
-    if (hl == 0 && have && lo > -INFINITY) atomicMax(gthr + q, pool_key(lo));   // kk rows exceed lo
-}
-
-// The floors of queries q_first, q_first + q_step, ... (< nq) by one wave, two at a time; cs_wave: 2 x per_half floats of LDS.
-__device__ __forceinline__ void pool_floor_wave(const float* __restrict__ state_s, const int* __restrict__ cnts, const float* __restrict__ pthr,
-                                                const int* __restrict__ qt_off, const int* __restrict__ qt_slots, int64_t q_first, int64_t q_step,
-                                                int64_t nq, int kk, int klw, float* cs_wave, int per_half, unsigned* __restrict__ gthr, int lane) {
-    const int H = lane >> 5;
-    int64_t q = q_first + H * q_step;
-    pf_pre pre = pool_floor_prefetch(cnts, pthr, qt_off, qt_slots, q < nq ? q : -1, kk, lane);
-    for (; q_first < nq; q_first += 2 * q_step) {
-        const int64_t qc = q < nq ? q : -1;
-        const pf_pre cur = pre;
-        q += 2 * q_step;
-        pre = pool_floor_prefetch(cnts, pthr, qt_off, qt_slots, q < nq ? q : -1, kk, lane);   // the next pair's counts: in flight under this pair's entries
-        pool_floor_pair(state_s, qc, cur, kk, klw, cs_wave, per_half, gthr, lane);
-    }
-}
-
-// What a kNN kernel does about the one-launch protocol, by the whole workgroup (every wave calls these with the same arguments).
-// `lds` = the workgroup's LDS, free between two phases (at least 8 x per_wave floats).
-// The only state a kernel keeps across its stage loops is the phase index `ph`; everything else is re-read from the kernarg segment at
-// the boundaries (HB_KARG), so that the stage loops' own scalars are not crowded into spills.
-// kernel start -> false: nothing to do in this launch; `ph` = the first phase to run
-template <class ARGS>
-__device__ __forceinline__ bool ol_enter(int& ph) {
-    ph = 0;
-    unsigned* gb = HB_KARG(ARGS, ol.gb);
-    if (gb == nullptr) return true;
-    const unsigned ab = (unsigned)__builtin_amdgcn_readfirstlane((int)gb_load(gb + HB_GB_ABORT));
-    if (HB_KARG(ARGS, ol.resume)) {
-        if (ab == 0u) return false;                                // the first launch ran to its end
-        ph = __builtin_amdgcn_readfirstlane((int)gb_load(gb + HB_GB_PROGRESS + blockIdx.x));   // written by this block in the first launch (a kernel boundary ago)
-        return ph < HB_KARG(ARGS, ol.n_phases);
-    }
-    return ab == 0u;        // started after the launch was given up: the completion launch does this block's whole list (progress stays 0)
-}
-// this launch's segments of the block for phase ph (resume: from there to the end of the list)
-template <class ARGS>
-__device__ __forceinline__ void ol_range(int ph, const int* wg_off, const int* wg_end, int& seg_begin, int& seg_end) {
-    seg_begin = wg_off[blockIdx.x]; seg_end = wg_end[blockIdx.x];
-    if (HB_KARG(ARGS, ol.gb) == nullptr) return;
-    const int* pb = HB_KARG(ARGS, ol.phase_bounds);
-    const int G = HB_KARG(ARGS, ol.G);
-    if (ph > 0) seg_begin = pb[(size_t)(ph - 1) * G + blockIdx.x];
-    if (!HB_KARG(ARGS, ol.resume) && ph < HB_KARG(ARGS, ol.n_phases) - 1) seg_end = pb[(size_t)ph * G + blockIdx.x];
-    // (inside the phase loop these are vector loads -- stores in the loop may alias -- and the kernels feed values derived from them to
-    // inline-asm "s" operands: move them to scalar registers here)
-    seg_begin = __builtin_amdgcn_readfirstlane(seg_begin); seg_end = __builtin_amdgcn_readfirstlane(seg_end);
-}
-// after the segments of phase ph -> true: go on with the next phase; false: this block is done with this launch
-// NOT inlined: inlined, the floor computation's registers (two queries' entries and their bisection) leaked into the register allocation of
-// the stage loops -- reloads of spilled SGPRs and scratch loads between the hand-counted LDS-DMA requests (tools/loop_spills.py).  Everything
-// it needs arrives as ARGUMENTS: the inlined caller reads the kernarg segment (HB_KARG), a callee does not touch it.
-struct ol_pools { const float* state_s; const int* cnts; const float* pthr; unsigned* gthr; int kk, klw; };
-static inline __device__ __attribute__((noinline)) int ol_boundary_call(int ph, char* lds, int w, int lane, const hb_one_launch ol, const ol_pools pl) {
-    if (ol.gb == nullptr || ol.resume) return 0;
-    const int done = ph + 1;
-    if (done >= ol.n_phases) return 0;
-    int* flag = reinterpret_cast<int*>(lds);             // [0]: the barrier's verdict for the other waves
-    const int inj = ol.inject;
-    const bool hit_here = inj != 0 && ((inj >> 16) & 0xFFF) == ph && ((inj & 0xFFFF) - 1) == (int)blockIdx.x;
-    const bool hit = hit_here && ((inj >> 28) == 1 || (inj >> 28) == 2);    // fails AT the first barrier
-    const bool hit_late = hit_here && (inj >> 28) == 4;                      // passes both barriers, THEN raises the flag and leaves
-    unsigned long long t0 = 0, t1 = 0, t2 = 0;
-    unsigned* trace = (inj >> 28) == 3 ? ol.gb + HB_GB_WORDS(ol.G) + (size_t)(done - 1) * 4 * ol.G + blockIdx.x : nullptr;
-    if (trace && w == 0 && lane == 0) gb_store(trace, (unsigned)__builtin_amdgcn_s_memrealtime());
-    // every wave of the workgroup has drained its stores and passed the workgroup's barrier (end of the last segment)
-    int ok = 1;
-    if (w == 0) {
-        if (blockIdx.x == 0) t0 = __builtin_amdgcn_s_memrealtime();
-        if (hit) { if ((inj >> 28) == 1 && lane == 0) gb_store(ol.gb + HB_GB_ABORT, 1u); ok = 0; }
-        else ok = gb_arrive_wait(ol.gb, (unsigned)(2 * done - 1), ol.G, ol.timeout, true, lane);
-        if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) flag[0] = ok;
-    }
-    __syncthreads();
-    ok = __builtin_amdgcn_readfirstlane(flag[0]);
-    __syncthreads();                                      // (flag[0] is scratch of the floors below)
-    if (ok) {
-        if (w == 0 && blockIdx.x == 0) t1 = __builtin_amdgcn_s_memrealtime();
-        if (trace && w == 0 && lane == 0) gb_store(trace + ol.G, (unsigned)__builtin_amdgcn_s_memrealtime());
-        float* cs = reinterpret_cast<float*>(lds) + (size_t)w * 2 * ol.per_wave;     // two queries per wave: per_wave floats per lane half
-        pool_floor_wave(pl.state_s, pl.cnts, pl.pthr, ol.qt_off, ol.qt_slots, (int64_t)blockIdx.x * HB_WAVES + w, (int64_t)ol.G * HB_WAVES, ol.nq,
-                        pl.kk, pl.klw, cs, ol.per_wave, pl.gthr, lane);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();                                  // every wave's reads of foreign pools are over
-        if (w == 0) {
-            if (blockIdx.x == 0) t2 = __builtin_amdgcn_s_memrealtime();
-            if (trace && lane == 0) gb_store(trace + 2 * ol.G, (unsigned)__builtin_amdgcn_s_memrealtime());
-            ok = gb_arrive_wait(ol.gb, (unsigned)(2 * done), ol.G, ol.timeout, false, lane);
-            if (hit_late) { if (lane == 0) gb_store(ol.gb + HB_GB_ABORT, 1u); ok = 0; }     // (the others have passed: they run on, some to their end)
-            if (lane == 0) flag[0] = ok;
-            if (trace && lane == 0) gb_store(trace + 3 * ol.G, (unsigned)__builtin_amdgcn_s_memrealtime());
-            if (blockIdx.x == 0 && lane == 0) {
-                const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
-                gb_add(ol.gb + HB_GB_STATS, 1u); gb_add(ol.gb + HB_GB_STATS + 1, (unsigned)(t1 - t0));
-                gb_add(ol.gb + HB_GB_STATS + 2, (unsigned)(t2 - t1)); gb_add(ol.gb + HB_GB_STATS + 3, (unsigned)(t3 - t2));
-            }
-        }
-        __syncthreads();
-        ok = __builtin_amdgcn_readfirstlane(flag[0]);
-        __syncthreads();
-    }
-    if (!ok) {      // given up: say where this block stands and leave -- the completion launch goes on from there
-        if (w == 0 && lane == 0) gb_store(ol.gb + HB_GB_PROGRESS + blockIdx.x, (unsigned)done);
-        return 0;
-    }
-    return 1;
-}
-template <class ARGS>
-__device__ __forceinline__ bool ol_boundary(int& ph, char* lds, int w, int lane) {
-    // (boundary-only arguments come from the kernarg segment HERE: nothing of this is live in the stage loops)
-    hb_one_launch ol;
-    ol.gb = HB_KARG(ARGS, ol.gb);
-    if (ol.gb == nullptr) return false;
-    ol.resume = HB_KARG(ARGS, ol.resume); ol.n_phases = HB_KARG(ARGS, ol.n_phases); ol.phase_bounds = nullptr;
-    if (!ol.resume && ph + 1 >= ol.n_phases) {
-        // the end of this block's list: "all phases done" goes on record, so that a completion launch -- which runs when ANY block gave a
-        // barrier up, possibly after this one had passed its last barrier -- does not start this block's list again (its rows would enter
-        // the pools twice)
-        if (w == 0 && lane == 0) gb_store(ol.gb + HB_GB_PROGRESS + blockIdx.x, (unsigned)ol.n_phases);
-        return false;
-    }
-    ol.qt_off = HB_KARG(ARGS, ol.qt_off); ol.qt_slots = HB_KARG(ARGS, ol.qt_slots); ol.G = HB_KARG(ARGS, ol.G); ol.nq = HB_KARG(ARGS, ol.nq);
-    ol.per_wave = HB_KARG(ARGS, ol.per_wave); ol.timeout = HB_KARG(ARGS, ol.timeout); ol.inject = HB_KARG(ARGS, ol.inject); ol.pad_ = 0;
-    ol_pools pl;
-    pl.state_s = HB_KARG(ARGS, state_s); pl.cnts = HB_KARG(ARGS, state_cnt); pl.pthr = HB_KARG(ARGS, state_thr); pl.gthr = HB_KARG(ARGS, gthr);
-    pl.kk = HB_KARG(ARGS, k); pl.klw = HB_KARG(ARGS, klw);
-    if (!__builtin_amdgcn_readfirstlane(ol_boundary_call(ph, lds, w, lane, ol, pl))) return false;
-    ++ph;
-    return true;
-}
-
 // LDS map shared by the variants (bytes): a 4-slot ring of k8 stages, two row-init buffers, the lists, the scratch
 #define KN_SLOT_BYTES 16384                 // 8 KiB bank fragments + 8 KiB query fragments (32 rows x 8 k blocks)
 #define KN_RING 4
@@ -1142,7 +842,5 @@ __device__ __forceinline__ bool ol_boundary(int& ph, char* lds, int w, int lane)
 #define KN_FENCE __builtin_amdgcn_sched_barrier(0);
 
 typedef void (*hb_knn_fn)(knn_args);
-hb_knn_fn hb_knn_bd_kernel(bool wide, bool clustered, bool small, bool one_launch = false);   // query fragments straight into registers, hbird_knn_bd.hip
+hb_knn_fn hb_knn_bd_kernel(bool wide, bool clustered, bool small);   // query fragments straight into registers, hbird_knn_bd.hip
 int hb_knn_bd_lds_bytes(bool small);
-int hb_knn_bd_floor_lds_bytes();
-int hb_knn_f16_floor_lds_bytes();

@@ -93,9 +93,8 @@ static_assert(F2_LDS_TOTAL <= 160 * 1024, "LDS budget");
 // a query-fragment load into registers (untracked by the compiler: the hand-counted vmcnt below names the registers it releases)
 #define F2_BL(REG, SRC, OFF) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "+v"(REG) : "v"(lane_off), "s"(SRC) : "memory");
 
-// EMAX: pool capacity / 64 that the instantiation can compact (registers of the rare compaction path); OL: the instantiation that can run all
-// phases of a search in one launch (hbird_knn_dev.h) -- its own, so that the per-phase kernel keeps its register allocation
-template <int EMAX, bool OL = false>
+// EMAX: pool capacity / 64 that the instantiation can compact (registers of the rare compaction path)
+template <int EMAX>
 __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -113,11 +112,7 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
     cl_sync cs = cl_init(a.wg_member, a.prog, a.cl, a.lag, blockIdx.x, w == 0, smem + F2_CLWORDS);
 
     wg_stamp<knn16_args>(0);
-    [[maybe_unused]] int ol_ph = 0;   // OL: the phase being run
-    if constexpr (OL) { if (!ol_enter<knn16_args>(ol_ph)) return; }
-  for (;;) {
-    int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_end[blockIdx.x];   // this launch's share of the block's segments (phases: hb_launch_knn)
-    if constexpr (OL) ol_range<knn16_args>(ol_ph, HB_KARG(knn16_args, wg_off), HB_KARG(knn16_args, wg_end), seg_begin, seg_end);
+    const int seg_begin = a.wg_off[blockIdx.x], seg_end = a.wg_end[blockIdx.x];   // this launch's share of the block's segments (phases: hb_launch_knn)
     // "everything before my first segment is done" (a member without any work: everything)
     if (w == 0) cl_publish(cs, seg_begin < seg_end ? a.segs[seg_begin].tile0 * NS : 0x7FFFFFFF, lane);
     for (int si = seg_begin; si < seg_end; ++si) {
@@ -266,9 +261,6 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if constexpr (OL) { if (ol_boundary<knn16_args>(ol_ph, smem, w, lane)) continue; }
-    break;
-  }
     cl_finish(cs, a.cl_stats, w == 0, lane);
     wg_stamp<knn16_args>(1);
 }
@@ -544,12 +536,9 @@ int hb_launch_rerank_rows(const float* rows, int rs, const float* binit, int d, 
     return 0;
 }
 
-int hb_knn_f16_floor_lds_bytes() { return F2_CLWORDS; }
-
 int hb_knn_f16_launch(const knn16_args& args, int grid, hipStream_t s) {
     // <4> compacts pools of up to 256 entries (k <= 64), <8> up to HB_POOL_MAX = 512 (its rare compaction path holds twice the registers)
     void (*fn)(knn16_args) = args.klw <= 256 ? knn_f16v2_kernel<4> : knn_f16v2_kernel<8>;
-    if (args.ol.gb) fn = args.klw <= 256 ? knn_f16v2_kernel<4, true> : knn_f16v2_kernel<8, true>;
     if (args.klw > 512) return hb_fail("hb_index_search: candidate pools beyond 512 entries");
     if (hb_ensure_dyn_lds((const void*)fn, F2_LDS_TOTAL)) return -1;
     fn<<<dim3((unsigned)grid), dim3(HB_THREADS), F2_LDS_TOTAL, s>>>(args);

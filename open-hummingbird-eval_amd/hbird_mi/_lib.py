@@ -83,13 +83,12 @@ SIGNATURES = {
     "hb_index_cluster_stats": (c_int, [c_void_p, POINTER(c_int64)]),
     "hb_index_set_variant": (c_int, [c_void_p, c_int]),
     "hb_index_set_search_options": (c_int, [c_void_p, c_int, c_int64]),
-    "hb_index_set_one_launch": (c_int, [c_void_p, c_int, c_int64, c_int]),
-    "hb_index_one_launch_stats": (c_int, [c_void_p, POINTER(c_int64)]),
     "hb_index_wg_stamps": (c_int, [c_void_p, c_void_p, c_int, POINTER(c_int)]),
     "hb_index_set_xcd_weights": (c_int, [c_void_p, c_int, POINTER(c_double)]),
     "hb_index_xcd_weights": (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_int)]),
     "hb_schedule_plan_weighted": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_double), c_void_p, c_int64, POINTER(c_int64)]),
-    "hb_index_one_launch_trace": (c_int, [c_void_p, c_void_p, c_int64, POINTER(c_int), POINTER(c_int)]),
+    "hb_index_kernel_clock": (c_int, [c_void_p, POINTER(c_double)]),
+    "hb_index_xcd_stats": (c_int, [c_void_p, c_int, POINTER(c_double)]),
     "hb_index_set_rerank_copy": (c_int, [c_void_p, c_int]),
     "hb_index_rerank_copy_bytes": (c_int, [c_void_p, POINTER(c_int64)]),
     "hb_index_schedule_info": (c_int, [c_void_p, POINTER(c_int64)]),

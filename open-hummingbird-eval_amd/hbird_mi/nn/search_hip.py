@@ -278,18 +278,6 @@ class HipFlatIndex:
         """A/B switches (same results): pool searches in one launch instead of phases; the size below which a search is "small"."""
         _lib.check(_lib.lib().hb_index_set_search_options(self._h, int(bool(phases)), int(small_limit_stages)))
 
-    def set_one_launch(self, mode: int = 0, timeout_us: int = 0, inject: int = 0):
-        """Phased searches as ONE launch with grid barriers: mode 2 (opt-in: measured 2-10 % slower than a launch per phase, which modes
-        0 / 1 select); same results.  `inject` (tests): (kind << 28) | (phase << 16) | (block + 1) makes one block fail at one phase
-        boundary; 3 << 28 records per-workgroup time stamps (hb_index_set_one_launch)."""
-        _lib.check(_lib.lib().hb_index_set_one_launch(self._h, int(mode), int(timeout_us), int(inject)))
-
-    def one_launch_stats(self) -> dict:
-        out = (ctypes.c_int64 * 8)()
-        _lib.check(_lib.lib().hb_index_one_launch_stats(self._h, out))
-        keys = ["one_launch", "phases", "boundaries", "barrier1_ticks", "floor_ticks", "barrier2_ticks", "timeouts", "given_up"]
-        return dict(zip(keys, [int(v) for v in out]))
-
     def set_xcd_weights(self, mode: int = 0, w8=None):
         """Work share per XCD group (blocks equal mod 8) of every panel of the work list (speed only, same results): mode 0 = calibrated from
         the workgroups' own durations (default), 1 = equal shares, 2 = the eight shares `w8`."""
@@ -314,14 +302,23 @@ class HipFlatIndex:
             t[:, 0] = (t[:, 0] - t0) & 0xFFFFFFFF; t[:, 1] = (t[:, 1] - t0) & 0xFFFFFFFF
         return t[:, :3]
 
-    def one_launch_trace(self):
-        """After a search with set_one_launch(inject=3 << 28): int64 array [boundaries, 4, workgroups] of 100 MHz ticks (relative to the
-        earliest stamp): arrival at barrier 1, its pass, floors done, pass of barrier 2."""
-        buf = np.zeros(24 * 4 * 1024, dtype=np.uint32)
-        nb, g = ctypes.c_int(0), ctypes.c_int(0)
-        _lib.check(_lib.lib().hb_index_one_launch_trace(self._h, _ptr(buf), buf.size, ctypes.byref(nb), ctypes.byref(g)))
-        t = buf[: nb.value * 4 * g.value].reshape(nb.value, 4, g.value).astype(np.int64)
-        return (t - t.min()) & 0xFFFFFFFF if t.size else t
+    def kernel_clock(self) -> dict:
+        """Clock of the last stamped kNN launch without a profiler attached (hb_index_kernel_clock): median / slowest / fastest workgroup in
+        GHz (shader cycles per real-time tick) and the launch's span in ms; zeros when the launch did not stamp."""
+        out = (ctypes.c_double * 4)()
+        _lib.check(_lib.lib().hb_index_kernel_clock(self._h, out))
+        return {"ghz": float(out[0]), "ghz_min": float(out[1]), "ghz_max": float(out[2]), "span_ms": float(out[3])}
+
+    def xcd_stats(self, fp16_kernel: bool = False) -> dict:
+        """State of the share calibration (hb_index_xcd_stats): rounds, the guard's lock / reverts, stamp sets read / rejected, shortest launch
+        with the best / the current shares (ms), work lists built for this index."""
+        out = (ctypes.c_double * 12)()
+        _lib.check(_lib.lib().hb_index_xcd_stats(self._h, int(bool(fp16_kernel)), out))
+        keys = ["rounds", "locked", "reverts", "samples", "rejected"]
+        d = {k: int(out[i]) for i, k in enumerate(keys)}
+        d.update({"best_span_ms": float(out[5]), "cur_span_ms": float(out[6]), "work_lists_built": int(out[7]), "xcd_map_moves": int(out[8]),
+                  "xcd_of_block0": int(out[9])})
+        return d
 
     def set_rerank_copy(self, mode: int = 0):
         """use_fp16 searches: a second, row-major fp32 copy of the bank for the exact re-rank (speed only; 0 automatic -- made when

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """One-off differential fuzz of the small / medium search paths against the CPU oracle (bit-exact indices and distances):
 random shapes, both metrics, odd workgroup counts, lists and pools, fp16 mode on and off.  usage: python tests/fuzz_small.py [cases] [seed]   (lives under tests/: it uses the oracle as the checker)
-FUZZ_ONE_LAUNCH=1: phased searches as ONE launch with grid barriers (hb_index_set_one_launch(ix, 2)), with query counts that qualify.
 FUZZ_MID=1: few workgroups (8 / 16) on 300 k - 700 k rows at D = 384 / 768, k <= 32: 120 k - 400 k stages per workgroup, the small-search LIST kernel with its
 quota-floor exchange (the default cases never reach it: they run on pools).
 FUZZ_XCD=1: random per-XCD work shares in [0.8, 1.25] (hb_index_set_xcd_weights(ix, 2, w8): weighted work lists), fp32 and use_fp16 searches."""
@@ -17,7 +16,7 @@ bad = 0
 for c in range(n_cases):
     D = int(rng.choice([32, 64, 96, 100, 384]))
     M = int(rng.integers(300, int(os.environ.get("FUZZ_MAX_ROWS", 150_000)) if D < 384 else int(os.environ.get("FUZZ_MAX_ROWS", 150_000)) * 2 // 5))
-    nq = int(rng.integers(1, 3000)) if not os.environ.get("FUZZ_ONE_LAUNCH") else int(rng.integers(6000, 20000))
+    nq = int(rng.integers(1, 3000))
     k = int(rng.choice([1, 5, 30, 32, 40, 90]))
     metric = int(rng.integers(0, 2))
     if os.environ.get("FUZZ_MID"):
@@ -33,12 +32,11 @@ for c in range(n_cases):
     variant = int(rng.choice([0, 0, 3, 4, 6])); cl = [(0, 0, -1), (0, 0, -1), (2, 2, 4), (2, 4, 16)][int(rng.integers(0, 4))]
     ix = HipFlatIndex(D, metric, 0); ix.add(torch.from_numpy(bank).cuda()); ix.set_fp16(fp16); ix.set_tuning(G, 0)
     ix.set_variant(variant); ix.set_cluster(*cl)
-    if os.environ.get("FUZZ_ONE_LAUNCH"): ix.set_one_launch(2)
     if os.environ.get("FUZZ_XCD"): ix.set_xcd_weights(2, rng.uniform(0.8, 1.25, size=8).tolist())
     idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
     ridx, rdist = oracle.knn_chain_f32(q, bank, k, "dot_product" if metric == 0 else "l2", 0)
     ok = np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(dist.cpu().numpy().view(np.uint32), rdist.view(np.uint32))
     bad += not ok
-    print(f"case {c}: M {M} D {D} nq {nq} k {k} metric {metric} G {G} fp16 {fp16} variant {variant} cluster {cl} -> {'ok' if ok else 'MISMATCH'} {ix.schedule_info()['slots']} slots, {(lambda i: i['query_tiles'] * i['bank_tiles'] // max(1, i['workgroups']) * ((D + 7) // 8))(ix.schedule_info())} stages per workgroup, one_launch {ix.one_launch_stats()['one_launch']} given_up {ix.one_launch_stats()['given_up']}", flush=True)
+    print(f"case {c}: M {M} D {D} nq {nq} k {k} metric {metric} G {G} fp16 {fp16} variant {variant} cluster {cl} -> {'ok' if ok else 'MISMATCH'} {ix.schedule_info()['slots']} slots, {(lambda i: i['query_tiles'] * i['bank_tiles'] // max(1, i['workgroups']) * ((D + 7) // 8))(ix.schedule_info())} stages per workgroup", flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)

@@ -42,7 +42,7 @@ def test_no_kernel_spills_more_than_the_baseline():
                 problems.append(f"{k}: {f} {d.get(f, 0)} > baseline {b.get(f, 0)}")
     assert not problems, "\n".join(problems)
     # the two kernels the bench times keep their stage loops free of scratch traffic beyond these few bytes (prologue / segment ends)
-    assert now["knn_fused_bd_kernel<false, true, false, false>"]["scratch"] <= 36 and now["knn_f16v2_kernel<4, false>"]["scratch"] == 0
+    assert now["knn_fused_bd_kernel<false, true, false>"]["scratch"] <= 36 and now["knn_f16v2_kernel<4>"]["scratch"] == 0
 
 
 @pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"))), reason="needs hipcc")
@@ -64,7 +64,7 @@ def test_stage_loops_hold_no_scratch_traffic_and_no_new_scalar_reloads(tmp_path)
     for out, p in procs:
         assert p.wait() == 0, p.stdout.read().decode()[-2000:]
         now.update(loop_spills.summary(out))
-    assert len(now) >= 13, sorted(now)
+    assert len(now) >= 8, sorted(now)
     problems = []
     for k, d in now.items():
         if d["scratch"]:

@@ -634,96 +634,23 @@ def test_phased_and_unphased_pool_searches_return_the_same_bits(cuda_device):
     bit for bit, in all four."""
     bank = gi.unit_bank(70001, 64, seed=5); q = torch.from_numpy(gi.vit_like_queries(1301, 64, seed=6)).cuda()
     results = []
-    for setup in ("default", "one_launch", "unphased", "lists", "never_small"):
+    for setup in ("default", "unphased", "lists", "never_small"):
         out = []
         for k, fp16 in ((30, False), (90, False), (30, True)):
             ix = HipFlatIndex(64, 0, 0); ix.add(torch.from_numpy(bank).cuda()); ix.set_fp16(fp16)
-            if setup == "one_launch":
-                ix.set_one_launch(2)            # all phases in ONE launch with grid barriers, where the search qualifies (opt-in)
-            elif setup == "unphased":
+            if setup == "unphased":
                 ix.set_search_options(phases=False)
             elif setup == "lists":
                 ix.set_variant(6)
             elif setup == "never_small":
                 ix.set_search_options(small_limit_stages=1)
             out.append(ix.search(q, k))
-            st = ix.one_launch_stats()
-            # (six query tiles over 256 workgroups: 43 pools per query do not fit the LDS between two phases, so even mode 2 keeps a
-            # launch per phase here; test_one_launch_search_... below has shapes that qualify)
-            assert st["given_up"] == 0 and (setup == "one_launch" or st["one_launch"] == 0), st
         results.append(out)
     for other in results[1:]:
         for (i0, d0), (i1, d1) in zip(results[0], other):
             assert torch.equal(i0, i1) and torch.equal(d0.view(torch.int32), d1.view(torch.int32))
     with pytest.raises(RuntimeError):
         HipFlatIndex(8, 0, 0).set_search_options(small_limit_stages=-1)
-
-
-@pytest.mark.parametrize("fp16", [False, True])
-def test_one_launch_search_against_the_oracle_and_its_escape_paths(cuda_device, fp16):
-    """A phased search as ONE launch (grid barrier + in-kernel floors at every phase boundary): ids and distance bits of the chain oracle.
-    Then the ways out, all with the same bits: a block that raises the abort flag at a boundary (everyone leaves, the completion launch
-    finishes every block's list from its recorded phase), a block that leaves silently (the others run into their timeout -- a bounded
-    spin, 2 ms here -- and give up), both at the first and at a late boundary; and repeated searches (the barrier words are re-zeroed)."""
-    M, D = 120_000, 128
-    bank = gi.unit_bank(M, D, seed=15)
-    # (more queries for k = 90: a search qualifies when the pools of a query tile's slots -- about 256 workgroups / query tiles + 2 of
-    # them, capacity 192 at k = 30, 256 / 384 at k = 90 -- fit the LDS that is free between two phases, two queries per wave)
-    for k, nq in ((30, 12_800), (90, 22_016)):
-        qn = gi.vit_like_queries(nq, D, seed=16)
-        q = torch.from_numpy(qn).cuda()
-        ix = HipFlatIndex(D, 0, 0); ix.add(torch.from_numpy(bank).cuda()); ix.set_fp16(fp16)
-        ridx, rdist = oracle.knn_chain_f32(qn[:400], bank, k)
-        ip, dp = ix.search(q, k)                                            # the default: a launch per phase
-        assert ix.one_launch_stats()["one_launch"] == 0
-        ix.set_one_launch(2)
-        i0, d0 = ix.search(q, k)
-        assert torch.equal(i0, ip) and torch.equal(d0.view(torch.int32), dp.view(torch.int32))
-        st = ix.one_launch_stats()
-        assert st["one_launch"] == 1 and st["given_up"] == 0 and st["boundaries"] == st["phases"] - 1 >= 2, st
-        assert ix.last_fp16_fallbacks() == 0
-        assert np.array_equal(i0[:400].cpu().numpy(), ridx) and np.array_equal(d0[:400].cpu().numpy().view(np.uint32), rdist.view(np.uint32))
-        last = st["phases"] - 2
-        # kind 4: the block passes both barriers of the boundary and only THEN raises the flag -- the others are already running the next
-        # phase, at the last boundary to their end: they must be on record as done, or the completion launch would run their lists again
-        for kind, phase, block in ((1, 0, 7), (1, last, 200), (2, 0, 255), (2, last, 3), (1, 1, 0), (4, last, 100), (4, 0, 31)):
-            ix.set_one_launch(2, timeout_us=2000, inject=(kind << 28) | (phase << 16) | (block + 1))
-            i1, d1 = ix.search(q, k)
-            st = ix.one_launch_stats()
-            assert st["one_launch"] == 1 and st["given_up"] == 1, (kind, phase, block, st)
-            assert (st["timeouts"] > 0) == (kind == 2), (kind, st)
-            assert torch.equal(i0, i1) and torch.equal(d0.view(torch.int32), d1.view(torch.int32)), (kind, phase, block)
-        ix.set_one_launch(2)
-        for _ in range(3):
-            i1, d1 = ix.search(q, k)
-            assert ix.one_launch_stats()["given_up"] == 0
-            assert torch.equal(i0, i1) and torch.equal(d0.view(torch.int32), d1.view(torch.int32))
-
-
-def test_one_launch_search_beside_another_kernel(cuda_device):
-    """The case the escape hatch exists for: another kernel holds CUs while a one-launch search runs, so some of its workgroups are not
-    resident when the others reach a grid barrier.  A side stream keeps the device busy with large matrix products; the searches either
-    complete as one launch or give a barrier up after the (here 2 ms) timeout and finish in the completion launch -- the same bits either
-    way, and the device never hangs (every spin is bounded)."""
-    M, D, nq, k = 120_000, 128, 12_800, 30
-    bank = gi.unit_bank(M, D, seed=25); q = torch.from_numpy(gi.vit_like_queries(nq, D, seed=26)).cuda()
-    ix = HipFlatIndex(D, 0, 0); ix.add(torch.from_numpy(bank).cuda())
-    ref_i, ref_d = ix.search(q, k)
-    ix.set_one_launch(2, timeout_us=2000)
-    side = torch.cuda.Stream()
-    a = torch.randn((8192, 8192), device="cuda"); b = torch.randn((8192, 8192), device="cuda")
-    gave_up = 0
-    for rnd in range(6):
-        with torch.cuda.stream(side):
-            for _ in range(4):
-                c = a @ b
-        i1, d1 = ix.search(q, k)
-        st = ix.one_launch_stats()
-        assert st["one_launch"] == 1
-        gave_up += st["given_up"]
-        assert torch.equal(i1, ref_i) and torch.equal(d1.view(torch.int32), ref_d.view(torch.int32)), rnd
-    torch.cuda.synchronize()
-    print("one-launch searches beside a matmul stream: gave up", gave_up, "of 6")
 
 
 def test_per_xcd_work_shares_never_change_the_result(cuda_device):
@@ -752,7 +679,7 @@ def test_per_xcd_work_shares_never_change_the_result(cuda_device):
         torch.cuda.synchronize()                       # (the stamps of this search have landed when the next one looks for them)
         assert torch.equal(i1, ref_i) and torch.equal(d1.view(torch.int32), ref_d.view(torch.int32))
     w, rounds = ix.xcd_weights()
-    assert rounds >= 1 and abs(sum(w) / 8 - 1.0) < 1e-6 and all(0.8 <= v <= 1.25 for v in w), (w, rounds)
+    assert rounds >= 1 and abs(sum(w) / 8 - 1.0) < 1e-6 and all(0.8 <= v <= 1.25 for v in w), (w, rounds, ix.xcd_stats())
     print("calibrated shares", [round(v, 4) for v in w], "after", rounds, "rounds")
     # a PHASED search on a long list (k = 90: pools; 2,600 pairs per workgroup): its phase cuts follow the shares (hb_finish_schedule)
     ix.set_xcd_weights(1)
@@ -775,7 +702,7 @@ def test_per_xcd_work_shares_never_change_the_result(cuda_device):
         assert torch.equal(i1, f32_i) and torch.equal(d1.view(torch.int32), f32_d.view(torch.int32))
         assert ix.last_fp16_fallbacks() < nq // 100
     w16, rounds16 = ix.xcd_weights(True)
-    assert rounds16 >= 1 and abs(sum(w16) / 8 - 1.0) < 1e-6 and all(0.8 <= v <= 1.25 for v in w16), (w16, rounds16)
+    assert rounds16 >= 1 and abs(sum(w16) / 8 - 1.0) < 1e-6 and all(0.8 <= v <= 1.25 for v in w16), (w16, rounds16, ix.xcd_stats(True))
     print("fp16 candidate kernel: calibrated shares", [round(v, 4) for v in w16], "after", rounds16, "rounds")
     ix.set_fp16(False)
     with pytest.raises(RuntimeError):

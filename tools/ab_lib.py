@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """A/B of two builds of libhbird_hip.so through the stable core of the C ABI only (create / reserve / add / search /
 timing): usage ab_lib.py rows dim nq k lib1.so lib2.so ...  -- kernel ms (HIP events) per library, interleaved rounds.
-AB_FP16=1 in the environment: use_fp16 searches (hb_index_set_fp16); AB_METRIC=1: L2 instead of inner product; AB_WALL=1: also whole-search ms by HIP events.
-A path that ends in "@onelaunch" loads the same file with phased searches as ONE launch (hb_index_set_one_launch(ix, 2, 0, 0))."""
+AB_FP16=1 in the environment: use_fp16 searches (hb_index_set_fp16); AB_METRIC=1: L2 instead of inner product; AB_WALL=1: also whole-search ms by HIP events."""
 import ctypes, os, sys
 import torch
 M, D, nq, k = (int(x) for x in sys.argv[1:5])
@@ -31,10 +30,6 @@ for path in libs:
         assert L.hb_index_add(h, ctypes.c_void_p(rows.data_ptr()), n, 1, 1) == 0, L.hb_last_error()
     torch.cuda.synchronize()
     L.hb_index_set_timing(h, 1)
-    # a library path may carry "@onelaunch": same file, but phased searches as ONE launch with grid barriers (hb_index_set_one_launch(ix, 2, 0, 0))
-    if path.endswith("@onelaunch"):
-        L.hb_index_set_one_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int]
-        assert L.hb_index_set_one_launch(h, 2, 0, 0) == 0
     if os.environ.get("AB_FP16"):
         L.hb_index_set_fp16.argtypes = [ctypes.c_void_p, ctypes.c_int]
         assert L.hb_index_set_fp16(h, 1) == 0
