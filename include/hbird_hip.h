@@ -196,6 +196,16 @@ int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_tiles);
 int hb_index_set_fp16(hb_index_t* ix, int enable);
 /* Number of queries of the last fp16-mode search that needed the exact fp32 re-search. */
 int hb_index_last_fp16_fallbacks(const hb_index_t* ix, int64_t* n);
+/* What happens to a query whose certificate fails.  mode 0 (default): ESCALATION -- the failing queries, compacted, get a second fp16 pass
+ * with k' = 256 candidates whose pools start from the floor (exact k-th best of the first pass - 1.001 E): every row that can still enter
+ * the top k scores above it in fp16, so the pass appends little, a list that does not fill up is complete by construction, and a full one
+ * is certified against a rank four times further down; only what fails again is searched by the fp32 kernel, from the exact k-th best
+ * found so far as its floor.  mode 1: straight to the fp32 kernel (round 5's behaviour; every started tile of 256 failing queries costs a
+ * whole-bank fp32 pass: 27 ms at 10 M x 768).  Same results either way: always the fp32 search's bits.
+ * hb_index_last_fp16_escalated: queries of the last use_fp16 search whose FIRST certificate failed (hb_index_last_fp16_fallbacks: those
+ * that reached the fp32 kernel). */
+int hb_index_set_fp16_escalation(hb_index_t* ix, int mode);
+int hb_index_last_fp16_escalated(const hb_index_t* ix, int64_t* n);
 /* kNN kernel variant, for A/B runs and tests (same results): 0 = default; 3 = the fp32 kernel with register-resident query fragments
  * wherever it applies (D padded to a multiple of 32: what the default does too); 4 = never that kernel (both operands staged through
  * LDS); 6 = small fp32 searches with k <= 32 on sorted LDS lists as until round 3 (the default runs them on phased candidate pools).

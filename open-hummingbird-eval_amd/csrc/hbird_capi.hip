@@ -85,7 +85,7 @@ extern "C" int hb_index_free(hb_index_t* ix) {
     (void)hipSetDevice(ix->device);
     (void)hipStreamSynchronize(ix->stream);
     void* ptrs[] = {ix->tiles, ix->binit, ix->bnorm, ix->labels, ix->q_tiles, ix->q_aux, ix->state, ix->sched_dev, ix->tmp,
-                    ix->tiles16, ix->q16, ix->cand, ix->bmax, ix->fb, ix->mtmp, ix->f16_flag, ix->labels16, ix->lab_flag, ix->rows32};
+                    ix->tiles16, ix->q16, ix->cand, ix->bmax, ix->fb, ix->fb1, ix->sched_esc_dev, ix->mtmp, ix->f16_flag, ix->labels16, ix->lab_flag, ix->rows32};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& c : ix->xcal) { if (c.stamp_host) (void)hipHostFree(c.stamp_host); if (c.stamp_ev) (void)hipEventDestroy(c.stamp_ev); }
     if (ix->ev0) (void)hipEventDestroy(ix->ev0);
@@ -126,9 +126,21 @@ extern "C" int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_til
 extern "C" int hb_index_set_fp16(hb_index_t* ix, int enable) {
     if (!ix) return hb_fail("hb_index_set_fp16: NULL index handle");
     ix->fp16 = enable == 2 ? 2 : (enable ? 1 : 0);   // 2: only where it pays (hb_launch_knn)
+    ix->f16_r1 = ix->f16_r12 = 0.0; ix->f16_searches = 0;
     return 0;
 }
 
+extern "C" int hb_index_set_fp16_escalation(hb_index_t* ix, int mode) {
+    if (!ix) return hb_fail("hb_index_set_fp16_escalation: NULL index handle");
+    if (mode < 0 || mode > 1) return hb_fail("hb_index_set_fp16_escalation: mode must be 0 (second fp16 pass before the fp32 kernel) or 1 (straight to the fp32 kernel)");
+    ix->fp16_escalation = mode;
+    return 0;
+}
+extern "C" int hb_index_last_fp16_escalated(const hb_index_t* ix, int64_t* n) {
+    if (!ix || !n) return hb_fail("hb_index_last_fp16_escalated: NULL pointer");
+    *n = ix->last_fp16_escalated;
+    return 0;
+}
 extern "C" int hb_index_last_fp16_fallbacks(const hb_index_t* ix, int64_t* n) {
     if (!ix || !n) return hb_fail("hb_index_last_fp16_fallbacks: NULL pointer");
     *n = ix->last_fp16_fallbacks;

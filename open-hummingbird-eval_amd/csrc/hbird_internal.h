@@ -95,8 +95,16 @@ struct hb_index {
     char* cand = nullptr; size_t cand_bytes = 0;
     float* bmax = nullptr;                               // device scalar: max bank-row norm
     char* mtmp = nullptr; size_t mtmp_bytes = 0;         // first-level lists of a two-level merge
-    char* fb = nullptr; size_t fb_bytes = 0;             // fallback workspace (uncertified queries)
-    int64_t last_fp16_fallbacks = 0;
+    char* fb = nullptr; size_t fb_bytes = 0;             // workspace of the uncertified queries (a caller's search) ...
+    char* fb1 = nullptr; size_t fb1_bytes = 0;           // ... and of their second fp16 pass
+    int64_t last_fp16_fallbacks = 0;                     // queries of the last use_fp16 search that the fp32 kernel had to answer ...
+    int64_t last_fp16_escalated = 0;                     // ... and queries whose first certificate failed (second fp16 pass, k' = 256, seeded floors)
+    int fp16_escalation = 0;                             // 0 = on (automatic), 1 = off: uncertified queries go straight to the fp32 kernel (round 5)
+    double f16_r1 = 0.0, f16_r12 = 0.0;                  // moving averages: share of queries failing the first certificate / reaching the fp32 kernel (adaptive use, mode 2)
+    int f16_searches = 0, f16_skipped = 0;
+    int esc_level = 0;                                   // inside hb_launch_knn: 0 = a caller's search, 1 = the second fp16 pass, 2 = the fp32 search of what is left
+    const float* seed_dev = nullptr;                     // per-query floors (scores) a nested search starts from
+    hb_schedule sched_esc; char* sched_esc_dev = nullptr; size_t sched_esc_bytes = 0;   // the nested searches' work list (the caller's stays cached)
     int score_output = 0;                                // 1: searches return ordering scores instead of distances
     int variant = 0;                                     // kernel selection for A/B runs and tests (hb_index_set_variant)
     int phases_on = 1;                                   // pool searches are launched in phases (hb_index_set_search_options)
@@ -134,11 +142,12 @@ int hb_launch_tiles_to_rows(const float* t32, int g8, float* rows, int rs, int64
 int hb_launch_rerank_rows(const float* rows, int rs, const float* binit, int d, const float* q, const float* qn2,
                           const int64_t* cand, const float* cand_score, const float* qnorm, const float* bmax,
                           unsigned char* certified, int kc, int64_t nq, int k, int64_t id_base, int metric, int out_metric,
-                          int64_t ntotal, int64_t* out_idx, float* out_dist, hipStream_t s);
+                          int64_t ntotal, int64_t* out_idx, float* out_dist, hipStream_t s, const float* seed_in = nullptr, float* kth_out = nullptr,
+                          float* floor_out = nullptr);
 int hb_launch_rerank(const float* tiles, const float* binit, int g8, int d, const float* q, const float* qn2,
                      const int64_t* cand, const float* cand_score, const float* qnorm, const float* bmax,
                      unsigned char* certified, int kc, int64_t nq, int k, int64_t id_base, int metric, int out_metric, int64_t ntotal, int64_t* out_idx,
-                     float* out_dist, hipStream_t s);
+                     float* out_dist, hipStream_t s, const float* seed_in = nullptr, float* kth_out = nullptr, float* floor_out = nullptr);
 int hb_launch_bnorm_max(const float* bnorm, int64_t n, float* bmax, hipStream_t s);
 int hb_launch_scatter_rows(const int64_t* rows, int64_t n, int k, const int64_t* src_idx, const float* src_dist,
                            int64_t* out_idx, float* out_dist, hipStream_t s);

@@ -289,7 +289,10 @@ __global__ __launch_bounds__(64) void knn_merge_kernel(const float* __restrict__
         for (int u = 0; u < HB_POOL_MAX / 64; ++u) {
             if (u * 64 >= valid) break;
             const int e = u * 64 + lane;
-            const bool keep = e < valid && (vv[u] >= tstar || tstar == -INFINITY);
+            // (sentinel entries -- the padding of a sorted list with fewer than k rows -- stay behind: a seeded second pass of few queries
+            // leaves 22 group lists of 256 entries with a hundred real candidates among them, and the ranking below is quadratic: 18 ms
+            // for two queries, profiles/r06/fp16_escalation_merge_before.csv)
+            const bool keep = e < valid && vi[u] != HB_ID_NONE && (vv[u] >= tstar || tstar == -INFINITY);
             const unsigned long long m = __ballot(keep);
             if (keep) { const int pos = n + __popcll(m & ((1ull << lane) - 1ull)); cs[pos] = vv[u]; ci[pos] = vi[u]; }
             n += __popcll(m);
@@ -482,6 +485,13 @@ __global__ __launch_bounds__(256) void seed_floors_kernel(const int64_t* __restr
     if (idx[q * kk + kk - 1] >= 0) atomicMax(gthr + q, pool_key(score[q * kk + kk - 1]));   // kk rows reach this score: a floor (ties pass)
 }
 
+__global__ __launch_bounds__(256) void seed_from_scores_kernel(const float* __restrict__ seed, int64_t nq, unsigned* __restrict__ gthr) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const float v = seed[q];
+    if (v > -INFINITY && v < INFINITY) atomicMax(gthr + q, pool_key(v));      // rows scoring >= v pass (floor_from_key admits ties); NaN / inf: no seed
+}
+
 // The same floor straight from the pools, without the merge: one wave per query gathers the scores of its slots' pools (those that
 // can matter: at or above the best threshold a full pool already has) into LDS and bisects for a score that at least kk of them
 // exceed -- 14 halvings between the smallest and the largest; any such score is a valid floor (cold_start_threshold,
@@ -659,10 +669,22 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // 384: 8 k 0.41 / 0.45, 16 k 0.65 / 0.47; 1,369 x 768: 4 k 0.30 / 0.23, 16 k 0.59 / 0.48; 12,544 x 384: 4 k 0.61 / 0.52, 50 k 3.9 / 1.5, 1 M
     // 69.3 / 10.6; 21,904 x 768: 4 k 1.43 / 1.09, 1 M 242.7 / 34.3; k = 90, 12,544 x 384: 16 k 1.74 / 2.04, 32 k 3.00 / 2.49, 1 M 70.4 / 13.8.
     // (Until round 4: at least 16,384 rows and rows x queries >= 2^27.)  Same results either way.
+    const int esc = ix->esc_level;      // 0: a caller's search; 1: the second fp16 pass over its uncertified queries; 2: the fp32 search of what is left
     const double kc_rel = std::min(256, std::max(64, (2 * k + 7) / 8 * 8)) / 64.0;
     bool f16 = ix->fp16 != 0 && k <= 128 &&
                (ix->fp16 == 1 || (ix->ntotal >= 4096 && (double)ix->ntotal * (double)nq * (double)ix->d >= 1.5e10 * kc_rel * kc_rel));
-    if (!f16) ix->last_fp16_fallbacks = 0;      // a plain fp32 search: nothing fell back (the counter is not left over from an earlier search)
+    // ADAPTIVE use (mode 2, round 6): on a bank whose neighbours sit closer together than fp16 can tell apart -- token worlds with little
+    // noise: profiles/r06/fp16_cliff_*.json -- most certificates fail, and passes that certify nothing are pure overhead.  The index keeps
+    // moving averages of the share of queries that failed the first certificate (r1) and of the share that reached the fp32 kernel (r12):
+    // r12 > 1/2 -> the fp32 kernel right away; r1 > 1/2 -> the first pass is skipped, ONE pass with k' = 256 serves all queries; every 16th
+    // search walks the whole chain again, so a bank (or a query stream) that changes is noticed.  Same bits on every path.
+    bool wide_first = false;
+    if (f16 && esc == 0 && ix->fp16 == 2 && ix->fp16_escalation == 0) {
+        const bool probe = (ix->f16_searches++ & 15) == 15;
+        if (!probe && ix->f16_r12 > 0.5) { f16 = false; ix->f16_skipped = 1; }
+        else if (!probe && ix->f16_r1 > 0.5) wide_first = true;
+    }
+    if (!f16 && esc == 0) { ix->last_fp16_fallbacks = ix->f16_skipped ? nq : 0; ix->last_fp16_escalated = 0; ix->f16_skipped = 0; }      // a plain fp32 search: nothing fell back (the counters are not left over from an earlier search)
     if (f16 && nq > 0 && ix->ntotal > 0) {
         // bring the fp16 copy of the bank fragment tiles up to date.  A finite value beyond the fp16 range (|x| > 65504) turns
         // into inf there and the scores into inf / NaN, which the exactness certificate cannot bound: such a bank stays on the
@@ -683,7 +705,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
             HB_HIP(hipMemcpyAsync(&ix->f16_overflow, ix->f16_flag, 4, hipMemcpyDeviceToHost, s0));
             HB_HIP(hipStreamSynchronize(s0));
         }
-        if (ix->f16_overflow) { f16 = false; ix->last_fp16_fallbacks = nq; }
+        if (ix->f16_overflow) { f16 = false; if (esc == 0) { ix->last_fp16_fallbacks = nq; ix->last_fp16_escalated = 0; } }
         // ... and the row-major fp32 copy for the re-rank (hbird_knn_f16.hip).  Automatic: by the bank's size (below; a 10 M x 768 bank:
         // 30.7 GB of tiles + 15.4 GB of fp16 tiles + 30.7 GB of rows, of 288)
         if (f16 && ix->rerank_copy != 2) {
@@ -719,7 +741,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // fp16 mode: the fused kernel collects kc >= 2k candidates, the fp32 chain arithmetic re-ranks them
     // k' = 2k, at least 64 (rounded up to 8, not to 64 as until round 4: the candidate kernel's time is linear in k' -- 300,000 x 768, 21,904
     // queries: k' = 64 / 128 / 192 / 256 -> 12.95 / 15.85 / 20.7 / 25.0 ms -- so k = 33 paid for 128 candidates where it needs 66)
-    const int kc = f16 ? std::min(256, std::max(64, (2 * k + 7) / 8 * 8)) : k;
+    const int kc = f16 ? (esc == 1 || wide_first ? 256 : std::min(256, std::max(64, (2 * k + 7) / 8 * 8))) : k;     // (the second pass: the widest list the re-rank takes)
     // Small searches (few stages per workgroup) on the kernel with register-resident query fragments run on POOLS even for k <= 32:
     // phased, with the bisection cold start and the scan epilogue (hbird_knn_bd.hip <WIDE, COLD>) a pool takes a tile's survivors in one
     // drain, a sorted LDS list one wave-cooperative insertion each.  Same box, kernel ms, lists / pools, k = 30: 50,176 x 384 x 12,544
@@ -788,7 +810,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     const int fam = f16 ? 1 : 0;
     const bool balance = G % 8 == 0 &&
                          (ix->xcd_balance == 2 || (ix->xcd_balance == 0 && (long long)nqt * nbt / std::max(1, G) * ix->g8 >= 30000));
-    if (balance && ix->xcd_balance == 0) hb_xcd_calibrate(ix, fam);
+    if (balance && ix->xcd_balance == 0 && esc == 0) hb_xcd_calibrate(ix, fam);     // (nested searches run on the shares in use and leave the calibration alone)
     static const double equal_shares[8] = {1, 1, 1, 1, 1, 1, 1, 1};
     // (shares divided by their mean: eight equal shares of any size are the equal list, which is cached as such)
     double shares_n[8];
@@ -802,9 +824,13 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         for (int g = 0; g < 8; ++g) { shares_n[g] = xc.w[ix->xcd_balance == 0 ? xc.perm[g] : g] / mean; uneven = uneven || std::fabs(shares_n[g] - 1.0) > 1e-9; }
         if (uneven) shares = shares_n;
     }
-    hb_schedule& sc = ix->sched;
+    hb_schedule& sc = esc == 0 ? ix->sched : ix->sched_esc;      // (the nested searches of uncertified queries keep a list of their own: the caller's stays cached)
+    char*& sched_dev = esc == 0 ? ix->sched_dev : ix->sched_esc_dev;
+    size_t& sched_bytes = esc == 0 ? ix->sched_bytes : ix->sched_esc_bytes;
     // phased searches (pools only: "Phased searches" above hb_launch_knn); hb_index_set_search_options(ix, 0, ...) turns them off (A/B, tests)
-    const bool phased = wide && ix->phases_on;
+    // (a nested search of uncertified queries starts from seeded floors: phases would only add boundaries -- and with one query tile over 256
+    // workgroups the floors between them go through the merge kernels: 70 ms for two queries)
+    const bool phased = wide && ix->phases_on && esc == 0;
     // XCD-level sharing of the query tiles (hb_build_clustered): automatic for the fp16 candidate kernel -- same box, 10 M x 768, 8 x 1
     // clusters: 302.7 -> 291.5 ms and 0.97 -> 0.52 TB of L2-miss traffic per search (L2 hit rate 0.60 -> 0.78); the fp32 kernel's 2 x 4
     // clusters lose 1.6 % with it (2298 -> 2334 ms: 1600 slots instead of 592, and its 768 KiB query tiles do not stay in L2 beside
@@ -821,15 +847,15 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     const size_t b_pb = sc.phase_bounds.size() * 4;
     const size_t o_wg = al(b_segs), o_qo = o_wg + al(b_wg), o_qs = o_qo + al(b_qo), o_wm = o_qs + al(b_qs), o_pb = o_wm + al(b_wm),
                  tot = o_pb + al(b_pb);
-    const bool need_upload = rebuilt || ix->sched_bytes < tot;
-    if (ensure_bytes(&ix->sched_dev, &ix->sched_bytes, tot)) return -1;
+    const bool need_upload = rebuilt || sched_bytes < tot;
+    if (ensure_bytes(&sched_dev, &sched_bytes, tot)) return -1;
     if (need_upload) {
-        HB_HIP(hipMemcpyAsync(ix->sched_dev, sc.segs.data(), b_segs, hipMemcpyHostToDevice, s));
-        HB_HIP(hipMemcpyAsync(ix->sched_dev + o_wg, sc.wg_off.data(), b_wg, hipMemcpyHostToDevice, s));
-        HB_HIP(hipMemcpyAsync(ix->sched_dev + o_qo, sc.qt_off.data(), b_qo, hipMemcpyHostToDevice, s));
-        HB_HIP(hipMemcpyAsync(ix->sched_dev + o_qs, sc.qt_slots.data(), b_qs, hipMemcpyHostToDevice, s));
-        HB_HIP(hipMemcpyAsync(ix->sched_dev + o_wm, sc.wg_member.data(), b_wm, hipMemcpyHostToDevice, s));
-        HB_HIP(hipMemcpyAsync(ix->sched_dev + o_pb, sc.phase_bounds.data(), b_pb, hipMemcpyHostToDevice, s));
+        HB_HIP(hipMemcpyAsync(sched_dev, sc.segs.data(), b_segs, hipMemcpyHostToDevice, s));
+        HB_HIP(hipMemcpyAsync(sched_dev + o_wg, sc.wg_off.data(), b_wg, hipMemcpyHostToDevice, s));
+        HB_HIP(hipMemcpyAsync(sched_dev + o_qo, sc.qt_off.data(), b_qo, hipMemcpyHostToDevice, s));
+        HB_HIP(hipMemcpyAsync(sched_dev + o_qs, sc.qt_slots.data(), b_qs, hipMemcpyHostToDevice, s));
+        HB_HIP(hipMemcpyAsync(sched_dev + o_wm, sc.wg_member.data(), b_wm, hipMemcpyHostToDevice, s));
+        HB_HIP(hipMemcpyAsync(sched_dev + o_pb, sc.phase_bounds.data(), b_pb, hipMemcpyHostToDevice, s));
         HB_HIP(hipStreamSynchronize(s));   // host vectors may be rebuilt by the next call
     }
     const size_t state_half = (size_t)sc.n_slots * HB_QT * klw * 4;
@@ -844,14 +870,14 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     ix->wg_stamp_dev = a.wg_stamp; ix->wg_stamp_blocks = sc.G;
     if (a.wg_stamp) HB_HIP(hipMemsetAsync(a.wg_stamp, 0, stamp_bytes, s));   // a block that never stamps reads 0 / 0 (hb_stamps_summarise)
     a.bank_tiles = ix->tiles; a.binit = ix->binit; a.q_tiles = ix->q_tiles;
-    a.segs = reinterpret_cast<const hb_seg*>(ix->sched_dev);
-    a.wg_off = reinterpret_cast<const int*>(ix->sched_dev + o_wg);
+    a.segs = reinterpret_cast<const hb_seg*>(sched_dev);
+    a.wg_off = reinterpret_cast<const int*>(sched_dev + o_wg);
     a.wg_end = a.wg_off + 1;
     // this launch's share of every block's segments: [phase_begin(p)[b], phase_end(p)[b]) of the block's list
     const int n_phases = (int)sc.phase_clock.size() + 1;   // 1: a single launch (lists; pools with too little work per workgroup)
-    const int* pb = reinterpret_cast<const int*>(ix->sched_dev + o_pb);
-    auto phase_begin = [&](int p) { return p == 0 ? reinterpret_cast<const int*>(ix->sched_dev + o_wg) : pb + (size_t)(p - 1) * sc.G; };
-    auto phase_end = [&](int p) { return p == n_phases - 1 ? reinterpret_cast<const int*>(ix->sched_dev + o_wg) + 1 : pb + (size_t)p * sc.G; };
+    const int* pb = reinterpret_cast<const int*>(sched_dev + o_pb);
+    auto phase_begin = [&](int p) { return p == 0 ? reinterpret_cast<const int*>(sched_dev + o_wg) : pb + (size_t)(p - 1) * sc.G; };
+    auto phase_end = [&](int p) { return p == n_phases - 1 ? reinterpret_cast<const int*>(sched_dev + o_wg) + 1 : pb + (size_t)p * sc.G; };
     a.state_s = reinterpret_cast<float*>(ix->state);
     a.state_i = reinterpret_cast<unsigned*>(ix->state + state_half);
     a.g8 = ix->g8; a.k = k; a.klw = klw;
@@ -865,7 +891,13 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // their threshold.  Without it a slot's first tile appended all 256 tied rows for each of them and compacted their pools on the spot
     // (50,176 x 384 x 21,904 queries, 112 padding queries, pools: 943 us for a one-tile phase that takes 136 us with 21,760 queries)
     if (nq < (int64_t)nqt * HB_QT) HB_HIP(hipMemsetD32Async((hipDeviceptr_t)(a.gthr + nq), 0xFF800000u, (size_t)((int64_t)nqt * HB_QT - nq), s));
-    a.wg_member = reinterpret_cast<const int*>(ix->sched_dev + o_wm);
+    // a nested search of uncertified queries starts from what the pass before it found out (hb_rerank_seeds): per query a score that the
+    // rows which can still matter reach
+    if (esc != 0 && ix->seed_dev) {
+        seed_from_scores_kernel<<<dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s>>>(ix->seed_dev, nq, a.gthr);
+        HB_HIP(hipGetLastError());
+    }
+    a.wg_member = reinterpret_cast<const int*>(sched_dev + o_wm);
     a.prog = reinterpret_cast<int*>(ix->state + 2 * state_half + 2 * state_aux + floor_bytes);
     a.cl = sc.cq * sc.cb;
     // soft-sync lag in stages: the members stay inside the L2's reach (4 MiB per XCD: tens of fp32 k8 stages); 0 disables
@@ -877,8 +909,8 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // between two phases of a pool search: the kk-th best of all rows seen so far becomes every slot's floor -- straight from the pools
     // where a query tile's pools fit the floor kernel's LDS, else through the merge (few queries against a big bank: many slots)
     auto seed_floors = [&](int kk, int64_t* scratch_idx, float* scratch_dist) -> int {
-        const int* qo = reinterpret_cast<const int*>(ix->sched_dev + o_qo);
-        const int* qs = reinterpret_cast<const int*>(ix->sched_dev + o_qs);
+        const int* qo = reinterpret_cast<const int*>(sched_dev + o_qo);
+        const int* qs = reinterpret_cast<const int*>(sched_dev + o_qs);
         const size_t per_wave = (size_t)sc.max_slots_per_qt * klw;
         // (up to 144 KiB of the CU's 160: 32 slots per query tile x pools of 256, 16 x 512 -- the merge path below costs a phase boundary
         // ten times as much: 10 M x 768, k = 90 with 16 slots per query tile: 2.9 -> 44.7 ms per search, profiles/r04/cluster_tail_rows_ab.txt)
@@ -923,57 +955,82 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
             }
         }
         if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
-        if (balance && ix->xcd_balance == 0 && hb_xcd_collect(ix, 1, a.wg_stamp, sc, shares, n_phases, nqt, nbt, kc, s)) return -1;
-        if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, pool_cnt ? a.state_thr : nullptr, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
-                         reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, kc, klw, 0, 0, nullptr,
+        if (balance && ix->xcd_balance == 0 && esc == 0 && hb_xcd_collect(ix, 1, a.wg_stamp, sc, shares, n_phases, nqt, nbt, kc, s)) return -1;
+        if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, pool_cnt ? a.state_thr : nullptr, reinterpret_cast<const int*>(sched_dev + o_qo),
+                         reinterpret_cast<const int*>(sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, kc, klw, 0, 0, nullptr,
                          cand_idx, cand_dist, s)) return -1;
-        if (ensure_bytes(&ix->fb, &ix->fb_bytes, (size_t)nq + 64)) return -1;
-        unsigned char* cert = reinterpret_cast<unsigned char*>(ix->fb);
+        // workspace of this level: [certificates nq + 64][exact k-th scores nq][floors for a second pass nq] and, once the failures are
+        // known, [their rows][queries][aux][floors][ids][distances]
+        char*& fbuf = esc == 0 ? ix->fb : ix->fb1;
+        size_t& fbuf_bytes = esc == 0 ? ix->fb_bytes : ix->fb1_bytes;
+        auto al2 = [](size_t x) { return (x + 255) / 256 * 256; };
+        const size_t o_kth = al2((size_t)nq + 64), o_flo = o_kth + al2((size_t)nq * 4), o_rows = o_flo + al2((size_t)nq * 4);
+        if (ensure_bytes(&fbuf, &fbuf_bytes, o_rows)) return -1;
+        unsigned char* cert = reinterpret_cast<unsigned char*>(fbuf);
+        float* kth = reinterpret_cast<float*>(fbuf + o_kth);
+        float* flo = reinterpret_cast<float*>(fbuf + o_flo);
+        HB_HIP(hipMemsetD32Async((hipDeviceptr_t)kth, 0xFF800000u, (o_rows - o_kth) / 4, s));    // -inf: no seed (a query with fewer than k candidates)
+        const float* seed_in = esc == 1 ? ix->seed_dev : nullptr;
         if (ix->rows32 && ix->rerank_copy != 2 && ix->rows32_rows >= ix->ntotal) {
             if (hb_launch_rerank_rows(ix->rows32, ix->rows32_rs, ix->binit, ix->d, q_dev, ix->q_aux, cand_idx, cand_dist, ix->q_aux + nq, ix->bmax,
-                                      cert, kc, nq, k, id_base, ix->metric, out_metric, ix->ntotal, out_idx, out_dist, s)) return -1;
+                                      cert, kc, nq, k, id_base, ix->metric, out_metric, ix->ntotal, out_idx, out_dist, s, seed_in, kth, flo)) return -1;
         } else if (hb_launch_rerank(ix->tiles, ix->binit, ix->g8, ix->d, q_dev, ix->q_aux, cand_idx, cand_dist, ix->q_aux + nq, ix->bmax,
-                                    cert, kc, nq, k, id_base, ix->metric, out_metric, ix->ntotal, out_idx, out_dist, s)) return -1;
+                                    cert, kc, nq, k, id_base, ix->metric, out_metric, ix->ntotal, out_idx, out_dist, s, seed_in, kth, flo)) return -1;
         if (ix->time_kernels) {
             HB_HIP(hipEventSynchronize(ix->ev1));
             float ms = 0.f;
             HB_HIP(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
             ix->last_knn_ms = ms;
         }
-        // queries whose certificate failed are searched again with the exact fp32 kernel
+        // Queries whose certificate failed are searched again.  ESCALATION (round 6): first by a second fp16 pass with k' = 256 candidates
+        // (the certificate compares the exact k-th best with the fp16 score of rank k': four times the ranks apart) whose pools start from
+        // the floor `kth - 1.001 E` -- every row that can still matter scores above it in fp16, few others do, so the pass appends little and
+        // a list that does not fill up is complete by construction; only what fails again goes to the exact fp32 kernel, which starts from
+        // the exact k-th best found so far as its floor.  A failing query used to cost a share of a whole-bank fp32 search (10 M x 768: 27 ms
+        // per started tile of 256 queries; 5 % failing queries = +45 % on the step): the second pass costs a twentieth of that per query.
         std::vector<unsigned char> hc((size_t)nq);
         HB_HIP(hipMemcpyAsync(hc.data(), cert, (size_t)nq, hipMemcpyDeviceToHost, s));
         HB_HIP(hipStreamSynchronize(s));
         std::vector<int64_t> bad;
         for (int64_t i = 0; i < nq; ++i) if (!hc[i]) bad.push_back(i);
-        ix->last_fp16_fallbacks = (int64_t)bad.size();
-        if (!bad.empty()) {
-            const int64_t nf = (int64_t)bad.size();
-            auto al2 = [](size_t x) { return (x + 255) / 256 * 256; };
-            const size_t o_rows = al2((size_t)nq + 64), o_q = o_rows + al2((size_t)nf * 8), o_aux = o_q + al2((size_t)nf * ix->d * 4),
-                         o_idx = o_aux + al2((size_t)nf * 8), o_dist = o_idx + al2((size_t)nf * k * 8), tot2 = o_dist + al2((size_t)nf * k * 4);
-            if (ix->fb_bytes < tot2) {
+        const int64_t nf = (int64_t)bad.size();
+        if (esc == 0) { ix->last_fp16_escalated = 0; ix->last_fp16_fallbacks = 0; }
+        if (esc == 0 && !wide_first) ix->f16_r1 = 0.5 * ix->f16_r1 + 0.5 * (double)nf / (double)nq;
+        if (esc == 0 && nf == 0) ix->f16_r12 *= 0.5;
+        if (nf > 0) {
+            // the second pass needs k' = 256 > the first one's, a bank worth a candidate pass, and is not repeated
+            const bool again16 = esc == 0 && ix->fp16_escalation == 0 && kc < 256 && ix->ntotal >= 4096;
+            const size_t o_q = o_rows + al2((size_t)nf * 8), o_aux = o_q + al2((size_t)nf * ix->d * 4), o_seed = o_aux + al2((size_t)nf * 8),
+                         o_idx = o_seed + al2((size_t)nf * 4), o_dist = o_idx + al2((size_t)nf * k * 8), tot2 = o_dist + al2((size_t)nf * k * 4);
+            if (fbuf_bytes < tot2) {
                 char* nb = nullptr;
-                HB_HIP(hipMalloc((void**)&nb, tot2));
-                HB_HIP(hipFree(ix->fb));
-                ix->fb = nb; ix->fb_bytes = tot2;
+                HB_HIP(hipMalloc((void**)&nb, tot2 + tot2 / 4));
+                HB_HIP(hipMemcpyAsync(nb, fbuf, o_rows, hipMemcpyDeviceToDevice, s));      // (the seeds of this level)
+                HB_HIP(hipStreamSynchronize(s));
+                HB_HIP(hipFree(fbuf));
+                fbuf = nb; fbuf_bytes = tot2 + tot2 / 4;
+                kth = reinterpret_cast<float*>(fbuf + o_kth); flo = reinterpret_cast<float*>(fbuf + o_flo);
             }
-            int64_t* d_rows = reinterpret_cast<int64_t*>(ix->fb + o_rows);
-            float* d_q = reinterpret_cast<float*>(ix->fb + o_q);
-            float* d_aux = reinterpret_cast<float*>(ix->fb + o_aux);
-            int64_t* d_fi = reinterpret_cast<int64_t*>(ix->fb + o_idx);
-            float* d_fd = reinterpret_cast<float*>(ix->fb + o_dist);
+            int64_t* d_rows = reinterpret_cast<int64_t*>(fbuf + o_rows);
+            float* d_q = reinterpret_cast<float*>(fbuf + o_q);
+            float* d_aux = reinterpret_cast<float*>(fbuf + o_aux);
+            float* d_seed = reinterpret_cast<float*>(fbuf + o_seed);
+            int64_t* d_fi = reinterpret_cast<int64_t*>(fbuf + o_idx);
+            float* d_fd = reinterpret_cast<float*>(fbuf + o_dist);
             HB_HIP(hipMemcpyAsync(d_rows, bad.data(), (size_t)nf * 8, hipMemcpyHostToDevice, s));
             if (hb_launch_gather_rows(q_dev, nq, ix->d, d_rows, nf, d_q, s)) return -1;
+            if (hb_launch_gather_rows(again16 ? flo : kth, nq, 1, d_rows, nf, d_seed, s)) return -1;
             if (hb_launch_rows_to_tiles(d_q, nf, ix->d, ix->dp, 0, ix->q_tiles, nullptr, nullptr, ix->metric, 0, 0, s)) return -1;
             float* saved_aux = ix->q_aux;
             ix->q_aux = d_aux;                       // chain ||q||^2 of the re-searched queries (L2 distances)
             int rc = hb_launch_query_aux(d_q, nf, ix->d, d_aux, d_aux + nf, s);
-            const int saved = ix->fp16, saved_t = ix->time_kernels;
-            ix->fp16 = 0; ix->time_kernels = 0;
+            const int saved = ix->fp16, saved_t = ix->time_kernels, saved_esc = ix->esc_level;
+            const float* saved_seed = ix->seed_dev;
+            ix->fp16 = again16 ? 1 : 0; ix->time_kernels = 0; ix->esc_level = again16 ? 1 : 2; ix->seed_dev = d_seed;
+            if (!again16) ix->last_fp16_fallbacks = nf;
             if (!rc) rc = hb_launch_knn(ix, d_q, nf, k, id_base, d_fi, d_fd);
-            ix->fp16 = saved; ix->time_kernels = saved_t; ix->q_aux = saved_aux;
-            ix->last_fp16_fallbacks = nf;           // (the nested fp32 search cleared it)
+            ix->fp16 = saved; ix->time_kernels = saved_t; ix->q_aux = saved_aux; ix->esc_level = saved_esc; ix->seed_dev = saved_seed;
+            if (esc == 0) { ix->last_fp16_escalated = nf; ix->f16_r12 = 0.5 * ix->f16_r12 + 0.5 * (double)ix->last_fp16_fallbacks / (double)nq; }
             if (rc) return -1;
             if (hb_launch_scatter_rows(d_rows, nf, k, d_fi, d_fd, out_idx, out_dist, s)) return -1;
             HB_HIP(hipStreamSynchronize(s));         // `bad` and the workspace are reused by the next call
@@ -1022,10 +1079,10 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         }
     }
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
-    if (balance && ix->xcd_balance == 0 && hb_xcd_collect(ix, 0, a.wg_stamp, sc, shares, n_phases, nqt, nbt, k, s)) return -1;
+    if (balance && ix->xcd_balance == 0 && esc == 0 && hb_xcd_collect(ix, 0, a.wg_stamp, sc, shares, n_phases, nqt, nbt, k, s)) return -1;
     const float* qn2 = ix->q_aux;   // [nq] chain ||q||^2 (valid for L2)
-    if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, pool_cnt ? a.state_thr : nullptr, reinterpret_cast<const int*>(ix->sched_dev + o_qo),
-                     reinterpret_cast<const int*>(ix->sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, k, klw, id_base, out_metric,
+    if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, pool_cnt ? a.state_thr : nullptr, reinterpret_cast<const int*>(sched_dev + o_qo),
+                     reinterpret_cast<const int*>(sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, k, klw, id_base, out_metric,
                      qn2, out_idx, out_dist, s)) return -1;
     if (ix->time_kernels) {
         HB_HIP(hipEventSynchronize(ix->ev1));

@@ -265,6 +265,27 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_f16v2_kernel(knn16_args a) 
     wg_stamp<knn16_args>(1);
 }
 
+// What the re-rank leaves for an ESCALATION of the queries whose certificate fails (hb_launch_knn), and what it takes from the pass before:
+//   seed_in  [query] (second pass only): the fp16-score floor this pass ran under -- every row with an fp16 score >= it was offered to the
+//            pools, so a candidate list that is NOT full holds every such row: the rows outside score below the floor in fp16, hence below
+//            floor + E exactly, and the answer is exact when its k-th best exceeds that;
+//   kth_out  [query]: the exact k-th best score among this pass's candidates -- a lower bound of the true k-th best: the floor of an fp32
+//            search of this query (ties pass: floor_from_key);
+//   floor_out[query]: kth - 1.001 E, a hair lower: every row that can still enter the top k has an exact score >= kth, hence an fp16 score
+//            above this -- the floor of a second, wider fp16 pass (0.001 E is twenty times the rounding of these few operations).
+struct hb_rerank_seeds { const float* seed_in; float* kth_out; float* floor_out; };
+__device__ __forceinline__ bool hb_rerank_finish(const hb_rerank_seeds& sd, int64_t qi, bool ok, bool list_not_full, bool have_kth, float s, float E) {
+    if (sd.seed_in && list_not_full && have_kth && !ok) ok = s > sd.seed_in[qi] + E;
+    if (sd.kth_out) {
+        const bool fin = have_kth && E < INFINITY && fabsf(s) < INFINITY;      // (false for NaN as well)
+        float f = s - 1.001f * E;
+        f = f - fabsf(f) * 2.4e-7f - 1e-37f;
+        sd.kth_out[qi] = fin ? s : -INFINITY;
+        sd.floor_out[qi] = fin ? f : -INFINITY;
+    }
+    return ok;
+}
+
 // Exact re-rank: one wave per query; lane j scores candidates j, j+64, ... with the fp32 chain arithmetic of the fp32
 // kernel (acc = row init; acc = fmaf(q_k, b_k, acc) for k ascending over the fp32 fragment tiles), then the wave
 // ranks them by (score desc, id asc) and writes the best k.
@@ -274,7 +295,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ t
                                                      const float* __restrict__ qnorm, const float* __restrict__ bmax,
                                                      unsigned char* __restrict__ certified, int kc, int64_t nq, int k,
                                                      int64_t id_base, int metric, int out_metric, int64_t ntotal,
-                                                     int64_t* __restrict__ out_idx, float* __restrict__ out_dist) {
+                                                     int64_t* __restrict__ out_idx, float* __restrict__ out_dist, hb_rerank_seeds sd) {
     __shared__ float s_sc[4][256];
     __shared__ int64_t s_id[4][256];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -338,6 +359,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ t
             if (last >= 0 && id >= 0 && finite_q) {
                 ok = s > cand_score[qi * (int64_t)kc + kc - 1] + E;
             }
+            ok = hb_rerank_finish(sd, qi, ok, last < 0, id >= 0 && finite_q, s, E);
             certified[qi] = ok ? 1 : 0;
         }
         if (rank < k) {
@@ -355,11 +377,12 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ t
 int hb_launch_rerank(const float* tiles, const float* binit, int g8, int d, const float* q, const float* qn2,
                      const int64_t* cand, const float* cand_score, const float* qnorm, const float* bmax,
                      unsigned char* certified, int kc, int64_t nq, int k, int64_t id_base, int metric, int out_metric,
-                     int64_t ntotal, int64_t* out_idx, float* out_dist, hipStream_t s) {
+                     int64_t ntotal, int64_t* out_idx, float* out_dist, hipStream_t s, const float* seed_in, float* kth_out, float* floor_out) {
     if (nq == 0) return 0;
     if (kc > 256) return hb_fail("hb_index_search: too many candidates for the re-rank kernel");
     rerank_kernel<<<dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s>>>(tiles, binit, g8, d, q, qn2, cand, cand_score, qnorm, bmax,
-                                                                     certified, kc, nq, k, id_base, metric, out_metric, ntotal, out_idx, out_dist);
+                                                                     certified, kc, nq, k, id_base, metric, out_metric, ntotal, out_idx, out_dist,
+                                                                     hb_rerank_seeds{seed_in, kth_out, floor_out});
     HB_HIP(hipGetLastError());
     return 0;
 }
@@ -405,7 +428,7 @@ __global__ __launch_bounds__(256) void rerank_rows_kernel(const float* __restric
                                                           const float* __restrict__ qnorm, const float* __restrict__ bmax,
                                                           unsigned char* __restrict__ certified, int kc, int64_t nq, int k,
                                                           int64_t id_base, int metric, int out_metric, int64_t ntotal,
-                                                          int64_t* __restrict__ out_idx, float* __restrict__ out_dist) {
+                                                          int64_t* __restrict__ out_idx, float* __restrict__ out_dist, hb_rerank_seeds sd) {
     __shared__ float s_sc[4][256];
     __shared__ unsigned s_id[4][256];                    // bank rows (below 2^32); RRW_NONE: no candidate
     __shared__ int s_act[4][256];
@@ -510,6 +533,7 @@ __global__ __launch_bounds__(256) void rerank_rows_kernel(const float* __restric
             const bool finite_q = qnorm[qi] <= 65504.0f;
             bool ok = last < 0 && ntotal < kc && finite_q;
             if (last >= 0 && id >= 0 && finite_q) ok = s > cand_score[qi * (int64_t)kc + kc - 1] + E;
+            ok = hb_rerank_finish(sd, qi, ok, last < 0, id >= 0 && finite_q, s, E);
             certified[qi] = ok ? 1 : 0;
         }
         if (rank < k) {
@@ -527,11 +551,12 @@ __global__ __launch_bounds__(256) void rerank_rows_kernel(const float* __restric
 int hb_launch_rerank_rows(const float* rows, int rs, const float* binit, int d, const float* q, const float* qn2,
                           const int64_t* cand, const float* cand_score, const float* qnorm, const float* bmax,
                           unsigned char* certified, int kc, int64_t nq, int k, int64_t id_base, int metric, int out_metric,
-                          int64_t ntotal, int64_t* out_idx, float* out_dist, hipStream_t s) {
+                          int64_t ntotal, int64_t* out_idx, float* out_dist, hipStream_t s, const float* seed_in, float* kth_out, float* floor_out) {
     if (nq == 0) return 0;
     if (kc > 256) return hb_fail("hb_index_search: too many candidates for the re-rank kernel");
     rerank_rows_kernel<<<dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s>>>(rows, rs, binit, d, q, qn2, cand, cand_score, qnorm, bmax,
-                                                                          certified, kc, nq, k, id_base, metric, out_metric, ntotal, out_idx, out_dist);
+                                                                          certified, kc, nq, k, id_base, metric, out_metric, ntotal, out_idx, out_dist,
+                                                                          hb_rerank_seeds{seed_in, kth_out, floor_out});
     HB_HIP(hipGetLastError());
     return 0;
 }

@@ -70,6 +70,8 @@ SIGNATURES = {
     "hb_index_set_tuning": (c_int, [c_void_p, c_int, c_int]),
     "hb_index_set_fp16": (c_int, [c_void_p, c_int]),
     "hb_index_last_fp16_fallbacks": (c_int, [c_void_p, POINTER(c_int64)]),
+    "hb_index_set_fp16_escalation": (c_int, [c_void_p, c_int]),
+    "hb_index_last_fp16_escalated": (c_int, [c_void_p, POINTER(c_int64)]),
     "hb_schedule_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, POINTER(c_int64)]),
     "hb_schedule_plan_phased": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, POINTER(c_int64),
                                         c_void_p, c_int, POINTER(c_int), c_void_p]),

@@ -271,6 +271,17 @@ class HipFlatIndex:
         _lib.check(_lib.lib().hb_index_last_fp16_fallbacks(self._h, ctypes.byref(n)))
         return int(n.value)
 
+    def last_fp16_escalated(self) -> int:
+        """Queries of the last use_fp16 search whose first certificate failed (they got the second, wider fp16 pass; last_fp16_fallbacks():
+        those that reached the fp32 kernel)."""
+        n = ctypes.c_int64(0)
+        _lib.check(_lib.lib().hb_index_last_fp16_escalated(self._h, ctypes.byref(n)))
+        return int(n.value)
+
+    def set_fp16_escalation(self, on: bool = True):
+        """use_fp16: uncertified queries get a second fp16 pass (k' = 256, seeded floors) before the fp32 kernel (default), or go straight to it."""
+        _lib.check(_lib.lib().hb_index_set_fp16_escalation(self._h, 0 if on else 1))
+
     def set_variant(self, variant: int):
         _lib.check(_lib.lib().hb_index_set_variant(self._h, int(variant)))
 

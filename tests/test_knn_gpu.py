@@ -564,6 +564,53 @@ def test_use_fp16_certificate_and_exact_fallback(cuda_device):
     _check_exact(i32, d32, q, bank, k, "dot_product")
 
 
+@pytest.mark.parametrize("metric", ["dot_product", "l2"])
+def test_use_fp16_escalation_second_pass_then_fp32(cuda_device, metric):
+    """What happens to a query whose first certificate fails (hb_index_set_fp16_escalation): a second fp16 pass with k' = 256 candidates,
+    seeded with the floor (exact k-th best - 1.001 E), and only then the fp32 kernel, seeded with the exact k-th best found so far.
+    Planted near-duplicate clusters force both: 150 rows within 1e-4 of one direction are wider than the first pass's k' = 64 but fit the
+    second pass's list (certified there: the list does not fill up); 400 such rows are wider than k' = 256 too and reach the fp32 kernel.
+    Always the fp32 search's bits -- with the escalation on, off, and against the oracle; ordinary queries never leave the first pass."""
+    M, D, k = 60_000, 128, 30
+    rng = np.random.default_rng(11)
+    bank = gi.unit_bank(M, D, seed=13)
+    c1, c2 = bank[7].copy(), bank[8].copy()
+    for r in range(1000, 1150):
+        v = c1 + 1e-4 * rng.standard_normal(D).astype(np.float32); bank[r] = v / np.linalg.norm(v)
+    for r in range(30_000, 30_400):
+        v = c2 + 1e-4 * rng.standard_normal(D).astype(np.float32); bank[r] = v / np.linalg.norm(v)
+    bank[40_000:40_003] = bank[1000]                     # exact duplicates: ties by id across the passes
+    q = gi.vit_like_queries(700, D, seed=14)
+    q[:60] = 4.0 * c1 + 1e-3 * rng.standard_normal((60, D)).astype(np.float32)
+    q[60:100] = 4.0 * c2 + 1e-3 * rng.standard_normal((40, D)).astype(np.float32)
+    qd = torch.from_numpy(q).cuda()
+    ix = HipFlatIndex(D, 0 if metric == "dot_product" else 1, 0)
+    ix.add(torch.from_numpy(bank).cuda())
+    ref_i, ref_d = ix.search(qd, k)                      # the fp32 kernel
+    _check_exact(ref_i, ref_d, q, bank, k, metric)
+    ix.set_fp16(True)
+    for rerank_copy in (1, 2):
+        ix.set_rerank_copy(rerank_copy)
+        ix.set_fp16_escalation(True)
+        i1, d1 = ix.search(qd, k)
+        esc, fb = ix.last_fp16_escalated(), ix.last_fp16_fallbacks()
+        assert torch.equal(i1, ref_i) and torch.equal(d1.view(torch.int32), ref_d.view(torch.int32))
+        assert 100 <= esc < 200 and 40 <= fb <= esc - 55, (esc, fb)      # both clusters escalate; the narrow one is settled by the second pass
+        ix.set_fp16_escalation(False)
+        i2, d2 = ix.search(qd, k)
+        assert torch.equal(i2, ref_i) and torch.equal(d2.view(torch.int32), ref_d.view(torch.int32))
+        assert ix.last_fp16_escalated() == ix.last_fp16_fallbacks() == esc, (ix.last_fp16_escalated(), ix.last_fp16_fallbacks(), esc)
+    ix.set_fp16_escalation(True)
+    i3, d3 = ix.search(qd[100:], k)                      # ordinary queries only
+    assert torch.equal(i3, ref_i[100:]) and torch.equal(d3.view(torch.int32), ref_d[100:].view(torch.int32))
+    assert ix.last_fp16_escalated() <= 6 and ix.last_fp16_fallbacks() <= ix.last_fp16_escalated()
+    i4, d4 = ix.search(qd[:100], 90)                     # k' = 184 first, then 256
+    ix.set_fp16(False)
+    r4i, r4d = ix.search(qd[:100], 90)
+    assert torch.equal(i4, r4i) and torch.equal(d4.view(torch.int32), r4d.view(torch.int32))
+
+
+
 @pytest.mark.parametrize("k,fp16", [(30, False), (32, False), (90, False), (256, False), (30, True), (100, True)])
 def test_few_queries_against_a_big_bank_two_level_merge(cuda_device, k, fp16):
     """One query tile against many bank tiles: every workgroup holds a partial list of the same queries (up to 256
