@@ -574,7 +574,7 @@ def flatten_into_roofline(res):
     r["fp16_frac_of_fp16_peak"] = get(f, "candidate_kernel_frac_of_fp16_mfma_peak")
     r["fp16_clock_ghz_unprofiled"] = get(f, "clock_ghz_unprofiled")
     r["fp16_clock_ghz_counters"] = get(f, "clock_ghz"); r["fp16_mfma_busy"] = get(f, "mfma_busy")
-    r["fp16_fallback_queries"] = get(f, "fallback_queries")
+    r["fp16_fallback_queries"] = get(f, "fallback_queries"); r["fp16_first_certificate_failed"] = get(f, "first_certificate_failed")
     r["fp16_guard_locked"] = get(f, "calibration", "locked")
     e = res.get("e2e")
     r["e2e_fp32_images_per_s"] = get(e, "fp32", "images_per_s_steady_state"); r["e2e_fp16_images_per_s"] = get(e, "use_fp16", "images_per_s_steady_state")

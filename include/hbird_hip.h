@@ -54,6 +54,10 @@ int hb_index_add_labels(hb_index_t* ix, const float* labels, int64_t n, int c, i
  * 0 (default) = fp32 storage. */
 int hb_index_set_label_denominator(hb_index_t* ix, int P);
 int hb_index_label_denominator(const hb_index_t* ix, int* P);
+/* The stored counts back to fp32 rows, in place and in one pass (the value (float)j / (float)P of every count; denominator 0 afterwards):
+ * for a bank whose training batches come in more than one input size -- the reference recomputes patch_size per batch (hbird_eval.py:313-314),
+ * and a table of counts holds ONE denominator.  A no-op on an fp32 table. */
+int hb_index_labels_to_fp32(hb_index_t* ix);
 int64_t hb_index_ntotal(const hb_index_t* ix);
 int64_t hb_index_nlabels(const hb_index_t* ix);
 /* Drop all rows and labels (keeps allocations). */

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void gather_label_counts_kernel(const unsigned
                                                                   const int64_t* __restrict__ ids, int64_t n, float* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n * c) return;
-    const int64_t i = t / c, r = ids[i];
+    const int64_t i = t / c, r = ids ? ids[i] : i;      // (ids == nullptr: the rows in order -- hb_index_labels_to_fp32)
     out[t] = (r >= 0 && r < src_rows) ? (float)src[r * src_stride + (t % c)] / (float)P : 0.0f;
 }
 

@@ -393,6 +393,24 @@ extern "C" int hb_index_set_label_denominator(hb_index_t* ix, int P) {
     ix->label_P = P;
     return 0;
 }
+extern "C" int hb_index_labels_to_fp32(hb_index_t* ix) {
+    if (!ix) return hb_fail("hb_index_labels_to_fp32: NULL index handle");
+    if (ix->label_P == 0) return 0;
+    HB_HIP(hipSetDevice(ix->device));
+    if (hb_labels_checked(ix)) return -1;
+    float* nl = nullptr;
+    const int64_t cap = std::max<int64_t>(ix->nlabels, ix->lab_cap);
+    if (ix->nlabels > 0) {
+        HB_HIP(hipMalloc((void**)&nl, (size_t)cap * ix->c * 4));
+        // one pass: count j of the value j / P -> (float)j / (float)P, the fp32 value K2 produced (hbird_eval.py:319-320)
+        if (hb_launch_gather_label_counts(ix->labels16, ix->nlabels, ix->c, ix->lab_stride(), ix->label_P, nullptr, ix->nlabels, nl, ix->stream)) { (void)hipFree(nl); return -1; }
+    }
+    HB_HIP(hipStreamSynchronize(ix->stream));
+    if (ix->labels16) HB_HIP(hipFree(ix->labels16));
+    if (ix->labels) HB_HIP(hipFree(ix->labels));
+    ix->labels16 = nullptr; ix->labels = nl; ix->label_P = 0; ix->lab_cap = nl ? cap : 0; ix->lab_checked = 0;
+    return 0;
+}
 extern "C" int hb_index_label_denominator(const hb_index_t* ix, int* P) {
     if (!ix || !P) return hb_fail("hb_index_label_denominator: NULL pointer");
     *P = ix->label_P;

@@ -79,6 +79,7 @@ SIGNATURES = {
     "hb_index_set_cluster": (c_int, [c_void_p, c_int, c_int, c_int]),
     "hb_index_set_cluster_sharing": (c_int, [c_void_p, c_int]),
     "hb_index_set_label_denominator": (c_int, [c_void_p, c_int]),
+    "hb_index_labels_to_fp32": (c_int, [c_void_p]),
     "hb_index_label_denominator": (c_int, [c_void_p, POINTER(c_int)]),
     "hb_index_copy_label_counts": (c_int, [c_void_p, c_void_p, c_int]),
     "hb_index_set_label_count_table": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64]),

@@ -230,68 +230,93 @@ class HbirdEvaluation:
             own_lo, own_hi = 0, float("inf")
         if self.memory_size is not None:
             self.index.reserve(max(1, self._planned_rows // max(1, self.world if self.sharded else 1)))
-        presized = self.memory_size is not None
+        state = {"presized": self.memory_size is not None}
         # Which batches this rank must actually LOAD.  Unbounded sharded build: only its own (hdist.rank_batches fetches just those
         # index batches from a DataLoader: rank r of N decodes 1 / N of the images).  Bounded memory: every batch, because the
         # reference's one random stream (500) is consumed for every batch by an amount that depends on its masks -- all ranks
         # replay it -- and the masks only come with their images.
         need_all = self.memory_size is not None or not self.sharded
         self.batches_loaded = 0
+        self._mixed_patch_sizes = False
+        failure = None
         with torch.no_grad():
             for ep in tqdm(range(self.augmentation_epoch), desc="Augmentation loop"):
                 base = ep * (n_batches or 0)
                 batches = enumerate(train_loader) if need_all else hdist.rank_batches(train_loader, lambda i, b=base: own_lo <= b + i < own_hi)
-                for bi, (x, y) in tqdm(batches, desc="Memory Creation loop"):
-                    flat = base + bi if n_batches is not None else self.batches_loaded
-                    mine = own_lo <= flat < own_hi
-                    self.batches_loaded += 1
-                    y = y.to(self.gpu_device)
-                    y = (y * 255).long()                                   # hbird_eval.py:309
-                    bs = y.shape[0]
-                    input_size = x.shape[-1]
-                    patch_size = input_size // S                          # 313-314
-                    if self.index.ntotal == 0:
-                        self._set_label_denominator(patch_size * patch_size)
-                    elif self.index.label_denominator not in (0, patch_size * patch_size):
-                        # the reference recomputes patch_size per batch (313-314); the compressed table holds counts of ONE denominator
-                        raise ValueError(f"training batches of different input sizes (patch {patch_size} x {patch_size} after a bank "
-                                         f"with label denominator {self.index.label_denominator}): the compressed label table needs one "
-                                         "patch size -- pass nn_params={'compress_labels': False} to keep fp32 label rows")
-                    # K2: `y[y == 255] = 0` (310) + patchify (317) + one-hot mean (319-320)
-                    label = ops.patch_label_hist(y, patch_size, num_classes, map255=True)   # [bs,S,S,C]
-                    if self.memory_size is None:
-                        if not presized and total_flat is not None:
-                            # the unbounded bank's size is known up front (batches x images x patches; a short last
-                            # batch only over-reserves): one allocation instead of geometric growth copies
-                            own_batches = (min(own_hi, total_flat) - own_lo) if self.sharded else total_flat
-                            self.index.reserve(max(1, int(own_batches) * bs * S * S))
-                            presized = True
-                        feats = self._tokens(x)                            # [bs, S*S, D] on the GPU
-                        self.index.use_current_stream()
-                        self.index.add(feats.reshape(-1, feats.shape[-1]), normalize=True)   # K1 (324-329)
-                        self.index.add_labels(label.reshape(-1, num_classes))
-                    else:
-                        K = int(self.num_sampled_features)
-                        lab = label.reshape(bs, S * S, num_classes)
-                        scores, nonempty, nz = ops.patch_scores(lab)       # K3a (471-493)
-                        nz_host = nz.cpu().tolist()                        # 497 (.tolist() sync in the reference too)
-                        total_nz = sum(nz_host)
-                        # the CPU generator is consumed for EVERY batch, in loader order, so that all ranks
-                        # stay aligned with the single-process stream of the reference (500)
-                        r = torch.rand(total_nz) if total_nz > 0 else torch.zeros(0)
-                        if not mine:
-                            continue
-                        r_off = torch.tensor([0] + nz_host[:-1], dtype=torch.int64).cumsum(0)
-                        sidx = ops.patch_select(scores, nonempty, r.to(self.gpu_device), r_off.to(self.gpu_device), K)
-                        feats = self._tokens(x)
-                        D = feats.shape[-1]
-                        rows = (sidx + torch.arange(bs, device=sidx.device)[:, None] * (S * S)).reshape(-1)
-                        sampled = ops.gather_rows(feats.reshape(-1, D), rows)                  # 515
-                        self.index.use_current_stream()
-                        self.index.add(sampled, normalize=True)                                # 335, 352-353
-                        self.index.add_labels(ops.gather_rows(lab.reshape(-1, num_classes), rows))   # 344-354
+                try:
+                    self._create_memory_epoch(batches, base, n_batches, own_lo, own_hi, total_flat, num_classes, S, state)
+                except Exception as e:          # noqa: BLE001 -- re-raised below, on every rank
+                    failure = e
+                # Sharded build: a rank that raised must not leave its peers waiting in the next collective (_finalize_shards, or the
+                # bounded build's aligned random stream): one all-reduce per epoch end, and all ranks go on or none
+                if self.sharded:
+                    flag = torch.tensor([0 if failure is None else 1], device=self.gpu_device)
+                    torch.distributed.all_reduce(flag)
+                    if int(flag.item()) != 0:
+                        if failure is not None:
+                            raise failure
+                        raise RuntimeError(f"the bank build failed on another rank (epoch {ep}); this rank stops with it")
+                elif failure is not None:
+                    raise failure
         self.id_base = 0          # a sharded build learns its id base from the ranks' row counts (_finalize_shards)
         return self.index.ntotal
+
+    def _create_memory_epoch(self, batches, base, n_batches, own_lo, own_hi, total_flat, num_classes, S, state) -> None:
+        """One pass over the training batches (the body of the reference's inner loop, hbird_eval.py:306-355)."""
+        presized = state["presized"]
+        for bi, (x, y) in tqdm(batches, desc="Memory Creation loop"):
+            flat = base + bi if n_batches is not None else self.batches_loaded
+            mine = own_lo <= flat < own_hi
+            self.batches_loaded += 1
+            y = y.to(self.gpu_device)
+            y = (y * 255).long()                                   # hbird_eval.py:309
+            bs = y.shape[0]
+            input_size = x.shape[-1]
+            patch_size = input_size // S                          # 313-314
+            if self.index.ntotal == 0 and not self._mixed_patch_sizes:
+                self._set_label_denominator(patch_size * patch_size)
+            elif self.index.label_denominator not in (0, patch_size * patch_size):
+                # the reference recomputes patch_size per batch (313-314) and its fp32 label rows do not care; the compressed table
+                # holds counts of ONE denominator: on a second one the rows stored so far go back to fp32 (one pass) and the build
+                # goes on as the reference's does
+                logger.warning("training batches of a second input size (patch %d x %d after label denominator %d): the label "
+                               "table continues as fp32 rows", patch_size, patch_size, self.index.label_denominator)
+                self.index.labels_to_fp32()
+                self._mixed_patch_sizes = True
+            # K2: `y[y == 255] = 0` (310) + patchify (317) + one-hot mean (319-320)
+            label = ops.patch_label_hist(y, patch_size, num_classes, map255=True)   # [bs,S,S,C]
+            if self.memory_size is None:
+                if not presized and total_flat is not None:
+                    # the unbounded bank's size is known up front (batches x images x patches; a short last
+                    # batch only over-reserves): one allocation instead of geometric growth copies
+                    own_batches = (min(own_hi, total_flat) - own_lo) if self.sharded else total_flat
+                    self.index.reserve(max(1, int(own_batches) * bs * S * S))
+                    presized = True
+                feats = self._tokens(x)                            # [bs, S*S, D] on the GPU
+                self.index.use_current_stream()
+                self.index.add(feats.reshape(-1, feats.shape[-1]), normalize=True)   # K1 (324-329)
+                self.index.add_labels(label.reshape(-1, num_classes))
+            else:
+                K = int(self.num_sampled_features)
+                lab = label.reshape(bs, S * S, num_classes)
+                scores, nonempty, nz = ops.patch_scores(lab)       # K3a (471-493)
+                nz_host = nz.cpu().tolist()                        # 497 (.tolist() sync in the reference too)
+                total_nz = sum(nz_host)
+                # the CPU generator is consumed for EVERY batch, in loader order, so that all ranks
+                # stay aligned with the single-process stream of the reference (500)
+                r = torch.rand(total_nz) if total_nz > 0 else torch.zeros(0)
+                if not mine:
+                    continue
+                r_off = torch.tensor([0] + nz_host[:-1], dtype=torch.int64).cumsum(0)
+                sidx = ops.patch_select(scores, nonempty, r.to(self.gpu_device), r_off.to(self.gpu_device), K)
+                feats = self._tokens(x)
+                D = feats.shape[-1]
+                rows = (sidx + torch.arange(bs, device=sidx.device)[:, None] * (S * S)).reshape(-1)
+                sampled = ops.gather_rows(feats.reshape(-1, D), rows)                  # 515
+                self.index.use_current_stream()
+                self.index.add(sampled, normalize=True)                                # 335, 352-353
+                self.index.add_labels(ops.gather_rows(lab.reshape(-1, num_classes), rows))   # 344-354
+        state["presized"] = presized
 
     def _set_label_denominator(self, P: int) -> None:
         """Every soft label is j / P, P = patch_size ** 2 (the mean of a one-hot over a patch's P pixels, hbird_eval.py:319-320): the

@@ -213,6 +213,10 @@ class HipFlatIndex:
         index then stores the uint16 counts j -- half the table -- and hands back the same fp32 values.  Before the first label row."""
         _lib.check(_lib.lib().hb_index_set_label_denominator(self._h, int(P)))
 
+    def labels_to_fp32(self):
+        """The stored counts back to fp32 rows, in place (hb_index_labels_to_fp32): a bank whose batches come in a second patch size."""
+        _lib.check(_lib.lib().hb_index_labels_to_fp32(self._h))
+
     @property
     def label_denominator(self) -> int:
         P = ctypes.c_int(0)
@@ -558,6 +562,12 @@ class HipMultiIndex:
         if (int(P) == 0) != (self._label_P == 0):
             self._labels = None         # fp32 values <-> int16 counts: a table kept by reset() has the other form's dtype
         self._label_P = int(P)
+
+    def labels_to_fp32(self):
+        """As HipFlatIndex.labels_to_fp32: int16 counts j -> fp32 values j / P (float32 division: the quotient K2 computed), denominator 0."""
+        if self._label_P and self._labels is not None:
+            self._labels = self._labels.to(torch.float32) / torch.tensor(float(self._label_P), device=self._labels.device)
+        self._label_P = 0
 
     @property
     def label_denominator(self) -> int:

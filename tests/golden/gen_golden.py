@@ -284,6 +284,31 @@ def main():
     g["trainable_after_regex_freeze"] = np.array(sorted(n for n, p_ in vit.named_parameters() if p_.requires_grad))
     np.savez_compressed(os.path.join(out, "g9_feature_extractor.npz"), **g)
 
+    # ---- G10 _create_memory over training batches of TWO input sizes (hbird_eval.py:313-314 recomputes patch_size per batch) ------------
+    # Same eval_spatial_resolution S = 4, inputs of 32 px (patch 8 x 8: labels j / 64) and 64 px (patch 16 x 16: labels j / 256), unbounded
+    # bank; then an evaluation on 32-px validation batches.
+    g = {}
+    C, D, S, B, k = 5, 16, 4, 3, 5
+    wa, wb = gi.SegWorld(C, D, 32, 8, seed=91), gi.SegWorld(C, D, 64, 16, seed=92)
+    wb.centroids = wa.centroids.copy()                       # one world, two resolutions
+    train = [wa.batch(B, True), wb.batch(B, True), wa.batch(B, True), wb.batch(B, True)]
+    val = wa.loader(2, B, with_255=True)
+    tr_tok = [gi.patch_mean_tokens(x, x.shape[-1] // S) for x, _ in train]
+    va_tok = [gi.patch_mean_tokens(x, 8) for x, _ in val]
+    ext = ReplayExtractor(tr_tok + va_tok, S, D)
+    tl = [(torch.from_numpy(x), torch.from_numpy(y)) for x, y in train]
+    vl = [(torch.from_numpy(x), torch.from_numpy(y)) for x, y in val]
+    torch.manual_seed(4321)
+    ev = HE(ext, tl, num_classes=C, n_neighbours=k, augmentation_epoch=1, device="cpu", nn_method="faiss", nn_params={}, memory_size=None)
+    jac = ev.evaluate(vl, eval_spatial_resolution=S, ignore_index=255)
+    g.update({"cfg": np.array([C, D, S, B, k]), "feature_memory": ev.feature_memory.numpy(), "label_memory": ev.label_memory.numpy(),
+              "jac": np.float64(jac)})
+    for i, (x, y) in enumerate(train):
+        g[f"train_y_{i}"] = y; g[f"train_tok_{i}"] = tr_tok[i]
+    for i, (x, y) in enumerate(val):
+        g[f"val_y_{i}"] = y; g[f"val_tok_{i}"] = va_tok[i]
+    np.savez_compressed(os.path.join(out, "g10_mixed_patch_sizes.npz"), **g)
+
     # (y/255)*255 round trip that hbird_eval.py:219,309 rely on
     c = np.arange(256, dtype=np.float32)
     rt = (torch.from_numpy(c / np.float32(255.0)) * 255).long().numpy()

@@ -298,7 +298,7 @@ def test_c_abi_rejects_a_null_handle_without_a_gpu():
         "hb_index_set_score_output": (None, 1), "hb_index_distances_from_scores": (None, None, 1, 1, None),
         "hb_index_set_timing": (None, 1), "hb_index_last_knn_ms": (None, ctypes.byref(ms)),
         "hb_index_set_tuning": (None, 0, 0), "hb_index_last_fp16_fallbacks": (None, ctypes.byref(n64)), "hb_index_set_fp16_escalation": (None, 0), "hb_index_last_fp16_escalated": (None, ctypes.byref(n64)),
-        "hb_index_set_variant": (None, 0), "hb_index_set_search_options": (None, 1, 0), "hb_index_set_rerank_copy": (None, 0), "hb_index_kernel_clock": (None, (ctypes.c_double * 4)()), "hb_index_xcd_stats": (None, 0, (ctypes.c_double * 12)()), "hb_index_wg_stamps": (None, info, 8, ctypes.byref(ctypes.c_int(0))), "hb_index_set_xcd_weights": (None, 1, None), "hb_index_xcd_weights": (None, 0, (ctypes.c_double * 8)(), None), "hb_index_rerank_copy_bytes": (None, ctypes.byref(n64)), "hb_index_schedule_info": (None, info), "hb_index_set_cluster": (None, 2, 2, 16), "hb_index_set_cluster_sharing": (None, 2), "hb_index_set_label_denominator": (None, 196),
+        "hb_index_set_variant": (None, 0), "hb_index_set_search_options": (None, 1, 0), "hb_index_set_rerank_copy": (None, 0), "hb_index_kernel_clock": (None, (ctypes.c_double * 4)()), "hb_index_xcd_stats": (None, 0, (ctypes.c_double * 12)()), "hb_index_wg_stamps": (None, info, 8, ctypes.byref(ctypes.c_int(0))), "hb_index_set_xcd_weights": (None, 1, None), "hb_index_xcd_weights": (None, 0, (ctypes.c_double * 8)(), None), "hb_index_rerank_copy_bytes": (None, ctypes.byref(n64)), "hb_index_schedule_info": (None, info), "hb_index_set_cluster": (None, 2, 2, 16), "hb_index_set_cluster_sharing": (None, 2), "hb_index_set_label_denominator": (None, 196), "hb_index_labels_to_fp32": (None,),
         "hb_index_label_denominator": (None, ctypes.byref(ctypes.c_int(0))), "hb_index_copy_label_counts": (None, None, 1),
         "hb_index_set_label_count_table": (None, None, None, 0, 0, 0, 0),
         "hb_index_cluster_stats": (None, info),

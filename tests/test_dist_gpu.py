@@ -402,3 +402,68 @@ def test_saved_bank_is_reused_by_two_ranks(cuda_device, golden_dir, tmp_path):
         assert l[2] == b[2] and l[3] == b[3] == g["feature_memory_unb"].shape[0] and np.array_equal(l[4], b[4])
     one = ret[(1, True, 0)]
     assert one[0] is True and one[1] == 0 and abs(one[2] - float(g["jac_unb"])) < 1e-4
+
+
+def _worker_mixed(rank, world, port, golden_dir, fail_rank, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "open-hummingbird-eval_amd"), os.path.join(root, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from helpers import IndexedReplayExtractor
+    from hbird_mi.hbird_eval import HbirdEvaluation
+    g = np.load(f"{golden_dir}/g10_mixed_patch_sizes.npz")
+    C, D, S, B, k = g["cfg"].tolist()
+    train, val, tok = [], [], {}
+    for i in range(4):
+        H = g[f"train_y_{i}"].shape[-1]
+        x = torch.zeros((B, 3, H, H)); x[0, 0, 0, 0] = float(i); tok[i] = g[f"train_tok_{i}"]
+        train.append((x, torch.from_numpy(g[f"train_y_{i}"])))
+    for i in range(2):
+        x = torch.zeros((B, 3, 32, 32)); x[0, 0, 0, 0] = float(1000 + i); tok[1000 + i] = g[f"val_tok_{i}"]
+        val.append((x, torch.from_numpy(g[f"val_y_{i}"])))
+    ext = IndexedReplayExtractor(tok, S, D)
+    if fail_rank is not None:
+        # one rank's extractor fails on a batch it owns: its peer must not be left waiting in the next collective
+        if rank == fail_rank:
+            del ext.tokens[2 * fail_rank]
+        try:
+            HbirdEvaluation(ext, train, num_classes=C, n_neighbours=k, device="cuda:0", nn_method="hip", nn_params={"idx_shard": True})
+            ret[rank] = "built"
+        except KeyError:
+            ret[rank] = "own failure"
+        except RuntimeError as e:
+            ret[rank] = "peer failure" if "another rank" in str(e) else repr(e)
+        td.destroy_process_group()
+        return
+    ev = HbirdEvaluation(ext, train, num_classes=C, n_neighbours=k, device="cuda:0", nn_method="hip", nn_params={"idx_shard": True})
+    fm = ev.feature_memory.numpy()
+    ok = np.array_equal(ev.label_memory.numpy(), g["label_memory"][ev.id_base: ev.id_base + fm.shape[0]])
+    ok = ok and np.abs(fm - g["feature_memory"][ev.id_base: ev.id_base + fm.shape[0]]).max() <= 2.5e-7
+    jac = ev.evaluate(val, S, ignore_index=255)
+    ret[rank] = (bool(ok), float(jac), abs(jac - float(g["jac"])) < 1e-4, ev.index.label_denominator)
+    td.destroy_process_group()
+
+
+def test_two_rank_build_over_two_input_sizes(cuda_device, golden_dir):
+    """Fixture G10 (training batches of 32 px and 64 px, hbird_eval.py:313-314) in a row-sharded two-rank build: rank 0 owns a 32-px and a
+    64-px batch and converts its label table to fp32 rows on the way, rank 1 likewise; the replicated table is fp32; bank and mIoU are
+    the reference's."""
+    world, port = 2, _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_mixed, args=(world, port, golden_dir, None, ret), nprocs=world, join=True)
+    assert ret[0][0] and ret[1][0] and ret[0][2] and ret[1][2], dict(ret)
+    assert ret[0][1] == ret[1][1]
+
+
+@pytest.mark.parametrize("fail_rank", [0, 1])
+def test_a_failing_rank_stops_the_sharded_build_on_every_rank(cuda_device, golden_dir, fail_rank):
+    """A rank that raises inside its share of the bank build used to leave its peers waiting in the next collective (_finalize_shards).
+    Now the ranks agree at every epoch's end (one all-reduce): the failing rank re-raises its own exception, the others raise a
+    RuntimeError naming the cause, and the job ends (the spawn below would otherwise hang until the test's timeout)."""
+    world, port = 2, _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_mixed, args=(world, port, golden_dir, fail_rank, ret), nprocs=world, join=True)
+    assert ret[fail_rank] == "own failure" and ret[1 - fail_rank] == "peer failure", dict(ret)

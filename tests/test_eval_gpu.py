@@ -39,6 +39,32 @@ def test_create_memory_and_evaluate_match_reference(cuda_device, golden_dir, nam
     assert np.abs(det["knns"].numpy().sum(-1) - g[f"knns_rowsum_{name}"])[same].max() < 1e-4
 
 
+def _g10_case(golden_dir):
+    g = np.load(f"{golden_dir}/g10_mixed_patch_sizes.npz")
+    C, D, S, B, k = g["cfg"].tolist()
+    train = [(torch.zeros((B, 3, g[f"train_y_{i}"].shape[-1], g[f"train_y_{i}"].shape[-1])), torch.from_numpy(g[f"train_y_{i}"])) for i in range(4)]
+    val = [(torch.zeros((B, 3, 32, 32)), torch.from_numpy(g[f"val_y_{i}"])) for i in range(2)]
+    return g, C, D, S, B, k, train, val
+
+
+@pytest.mark.parametrize("compress", [True, False])
+def test_create_memory_with_two_input_sizes_follows_the_reference(cuda_device, golden_dir, compress, caplog):
+    """The reference recomputes patch_size for every training batch (hbird_eval.py:313-314): a loader that mixes 32-px and 64-px batches
+    builds a bank whose label rows are j / 64 and j / 256.  The compressed label table (uint16 counts of ONE denominator, the default)
+    converts itself to fp32 rows at the first batch of a second size and the build goes on -- the reference's bank (fixture G10) and mIoU."""
+    g, C, D, S, B, k, train, val = _g10_case(golden_dir)
+    ext = ReplayExtractor([g[f"train_tok_{i}"] for i in range(4)] + [g[f"val_tok_{i}"] for i in range(2)], S, D)
+    import logging
+    with caplog.at_level(logging.WARNING):
+        ev = HbirdEvaluation(ext, train, num_classes=C, n_neighbours=k, device="cuda", nn_method="hip", nn_params={"compress_labels": compress})
+    assert ev.index.label_denominator == 0                    # fp32 rows now (from the start with compress_labels=False)
+    assert ("second input size" in caplog.text) == compress
+    assert np.array_equal(ev.label_memory.numpy(), g["label_memory"])
+    assert np.abs(ev.feature_memory.numpy() - g["feature_memory"]).max() <= 2.5e-7
+    jac = ev.evaluate(val, S, ignore_index=255)
+    assert abs(jac - float(g["jac"])) < 1e-4, (jac, float(g["jac"]))
+
+
 def test_evaluate_fused_path_equals_detail_path(cuda_device, golden_dir):
     g = np.load(f"{golden_dir}/g67_memory_evaluate.npz")
     c = golden_case(g, "ade")

@@ -201,19 +201,46 @@ def test_plugin_errors(cuda_device):
         nn.find_nearest_neighbors(fm[:2], k=257)
 
 
-def test_mid_size_vs_float64_definition(cuda_device):
-    """300k x 128 bank: fp32 chain result equals the float64 definition except at near-ties."""
+@pytest.mark.parametrize("metric", ["dot_product", "l2"])
+def test_mid_size_vs_float64_definition(cuda_device, metric):
+    """300k x 128 bank, both metrics: fp32 chain result equals the float64 definition except at near-ties."""
     M, D, nq, k = 300_000, 128, 512, 30
     bank = gi.unit_bank(M, D, seed=21)
+    if metric == "l2":
+        bank = bank * (1.0 + 0.5 * np.random.default_rng(23).random((M, 1), dtype=np.float32))      # rows of unequal norm: L2 is not a re-ordered IP
     q = gi.vit_like_queries(nq, D, seed=22)
-    ix = HipFlatIndex(D, 0, 0)
+    ix = HipFlatIndex(D, 0 if metric == "dot_product" else 1, 0)
     ix.add(torch.from_numpy(bank).cuda())
     idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
     idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
-    _check_exact(idx, dist, q, bank, k, "dot_product")
-    i64, d64 = oracle.knn_f64(q, bank, k)
-    rep = oracle.near_tie_report(idx, i64, d64)
+    _check_exact(idx, dist, q, bank, k, metric)
+    i64, d64 = oracle.knn_f64(q, bank, k, metric)
+    rep = oracle.near_tie_report(idx, i64, -d64 if metric == "l2" else d64)
     assert rep["excused_rate"] == 1.0 and rep["set_rate"] > 0.98, rep
+
+
+@pytest.mark.parametrize("metric,fp16", [("dot_product", False), ("l2", False), ("dot_product", True)])
+def test_exact_ties_against_an_independent_float64_definition(cuda_device, metric, fp16):
+    """Small-integer rows with ~170 exact copies each: every score is exact in fp32 and float64, so the kernel's neighbours must equal
+    torch-float64 scores ordered by (score, id ascending) -- computed here without oracle/ -- id for id, also across tile, slot and pass
+    boundaries (the copies are scattered over 10,000 rows; use_fp16: such ties defeat the certificate and walk the whole escalation)."""
+    rng = np.random.default_rng(19)
+    M, D, nq, k = 10_000, 64, 300, 30
+    base = rng.integers(-3, 4, size=(60, D)).astype(np.float32)
+    bank = base[rng.integers(0, 60, size=M)]
+    q = rng.integers(-2, 3, size=(nq, D)).astype(np.float32)
+    b64, q64 = torch.from_numpy(bank).double(), torch.from_numpy(q).double()
+    if metric == "dot_product":
+        sc = (q64 @ b64.T).numpy(); key = -sc
+    else:
+        sc = torch.stack([((qq[None, :] - b64) ** 2).sum(-1) for qq in q64]).numpy(); key = sc
+    ids = np.arange(M)
+    want = np.stack([np.lexsort((ids, key[r]))[:k] for r in range(nq)])
+    ix = HipFlatIndex(D, 0 if metric == "dot_product" else 1, 0)
+    ix.add(torch.from_numpy(bank).cuda()); ix.set_fp16(fp16)
+    idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
+    assert np.array_equal(idx.cpu().numpy(), want)
+    assert np.array_equal(dist.cpu().numpy().astype(np.float64), np.take_along_axis(sc, want, axis=1))
 
 
 @pytest.mark.parametrize("M,D,nq", [(2_074_072, 384, 12_544), (1_000_000, 768, 21_904)])
