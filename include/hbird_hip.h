@@ -26,7 +26,10 @@ typedef struct hb_index hb_index_t;
 
 #define HB_METRIC_IP 0 /* faiss.GpuIndexFlatIP, search_faiss.py:43-44 ("dot_product")        */
 #define HB_METRIC_L2 1 /* faiss.GpuIndexFlatL2, search_faiss.py:45-46 ("l2" / "euclidean")   */
-#define HB_MAX_K 256   /* neighbours per query (reference default 30; k <= 32 keeps the lists in LDS) */
+#define HB_MAX_K 2048  /* neighbours per query of a search -- faiss-gpu's own limit (the reference forwards any k, search_faiss.py:84-85; its default
+                        * is 30).  k <= 32 keeps the lists in LDS, k <= 256 is one pass over candidate pools, beyond that ceil(k / 256) passes,
+                        * each behind the last neighbour of the one before: a search of k = 1024 costs four searches of k = 256. */
+#define HB_MAX_K_AGGREGATE 256   /* ... of the fused search + label aggregation (K5 keeps a query's k weights in LDS) and of sharded merges */
 
 const char* hb_last_error(void);
 /* faiss.get_num_gpus(), search_faiss.py:14 */

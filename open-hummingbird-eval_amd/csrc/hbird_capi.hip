@@ -85,7 +85,7 @@ extern "C" int hb_index_free(hb_index_t* ix) {
     (void)hipSetDevice(ix->device);
     (void)hipStreamSynchronize(ix->stream);
     void* ptrs[] = {ix->tiles, ix->binit, ix->bnorm, ix->labels, ix->q_tiles, ix->q_aux, ix->state, ix->sched_dev, ix->tmp,
-                    ix->tiles16, ix->q16, ix->cand, ix->bmax, ix->fb, ix->fb1, ix->sched_esc_dev, ix->mtmp, ix->f16_flag, ix->labels16, ix->lab_flag, ix->rows32};
+                    ix->tiles16, ix->q16, ix->cand, ix->bmax, ix->fb, ix->fb1, ix->sched_esc_dev, ix->bigk, ix->mtmp, ix->f16_flag, ix->labels16, ix->lab_flag, ix->rows32};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& c : ix->xcal) { if (c.stamp_host) (void)hipHostFree(c.stamp_host); if (c.stamp_ev) (void)hipEventDestroy(c.stamp_ev); }
     if (ix->ev0) (void)hipEventDestroy(ix->ev0);
@@ -482,7 +482,9 @@ static inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 static int search_impl(hb_index* ix, const float* q, int64_t nq, int k, int64_t id_base, float beta, float* out_lab,
                        int64_t* out_idx, float* out_dist, int io_on_device, bool aggregate) {
     if (nq < 0) return hb_fail("hb_index_search: negative query count");
-    if (k < 1 || k > HB_MAX_K) return hb_fail("hb_index_search: k must be in [1, " + std::to_string(HB_MAX_K) + "]");
+    if (k < 1 || k > HB_MAX_K) return hb_fail("hb_index_search: k must be in [1, " + std::to_string(HB_MAX_K) + "] (faiss-gpu's own limit)");
+    if (aggregate && k > HB_MAX_K_AGGREGATE)
+        return hb_fail("hb_index_search_aggregate: k must be in [1, " + std::to_string(HB_MAX_K_AGGREGATE) + "] (plain searches take k up to " + std::to_string(HB_MAX_K) + ")");
     if (nq == 0) return 0;
     if (!q) return hb_fail("hb_index_search: q is NULL");
     hb_range range(aggregate ? "hbird:search_aggregate" : "hbird:search");

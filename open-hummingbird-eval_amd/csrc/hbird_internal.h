@@ -102,6 +102,8 @@ struct hb_index {
     int fp16_escalation = 0;                             // 0 = on (automatic), 1 = off: uncertified queries go straight to the fp32 kernel (round 5)
     double f16_r1 = 0.0, f16_r12 = 0.0;                  // moving averages: share of queries failing the first certificate / reaching the fp32 kernel (adaptive use, mode 2)
     int f16_searches = 0, f16_skipped = 0;
+    const float* ceil_s_dev = nullptr; const unsigned* ceil_i_dev = nullptr;    // a later pass of a search with k > 256 (hb_launch_knn_bigk)
+    char* bigk = nullptr; size_t bigk_bytes = 0;         // its workspace: one pass's lists and the ceilings
     int esc_level = 0;                                   // inside hb_launch_knn: 0 = a caller's search, 1 = the second fp16 pass, 2 = the fp32 search of what is left
     const float* seed_dev = nullptr;                     // per-query floors (scores) a nested search starts from
     hb_schedule sched_esc; char* sched_esc_dev = nullptr; size_t sched_esc_bytes = 0;   // the nested searches' work list (the caller's stays cached)

@@ -16,6 +16,7 @@
 // value (0 for IP, -0.5*||b||^2 for L2, -inf for padding rows) -- bit-exact against
 // oracle/hbird_oracle.c:orc_knn_chain_f32.  Ordering key: (score descending, row id ascending).
 #include "hbird_internal.h"
+#include "../../include/hbird_hip.h"
 #include <algorithm>
 #include <array>
 #include <mutex>
@@ -37,7 +38,9 @@
 // spilled SGPRs inside the stage loop of the pool (WIDE) instantiation (k = 90: +12 % kernel time).
 // (The timing-only ablation instantiations of rounds 1-3 -- no copies / no fragment reads / no barrier / no epilogue -- and the
 // in-kernel counters of the small-search work are gone from the product: their numbers are in profiles/LABBOOK.md and profiles/r01 - r03.)
-template <bool COLD, bool WIDE, bool CL = false>
+// CEIL (pools only): a later pass of a search with k > 256 (hb_launch_knn_bigk) -- every score at or ahead of the query's ceiling key (the last
+// neighbour already delivered) is turned into -inf before the tile's epilogue sees it
+template <bool COLD, bool WIDE, bool CL = false, bool CEIL = false>
 __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -77,6 +80,9 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
             thr = lst_s[myq * HB_KL + (k - 1)];
         }
         thr = fmaxf(thr, floor_load(a.gthr, seg.q_tile * HB_QT + myq));
+        [[maybe_unused]] float c_s = INFINITY;
+        [[maybe_unused]] unsigned c_i = 0u;
+        if constexpr (CEIL) { c_s = a.ceil_s[seg.q_tile * HB_QT + myq]; c_i = a.ceil_i[seg.q_tile * HB_QT + myq]; }
         const float* qsrc = a.q_tiles + ((size_t)(seg.q_tile * 8 + w) * g8) * HB_BLK + lane * 4;
         const int total = seg.n_tiles * g8;
         f32x16 acc[8];
@@ -177,6 +183,19 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
             KN_FENCE
             slot_c = slot_n;
             if (++ks == g8) {
+                if constexpr (CEIL) {
+                    // acc[t][4 q + r] of this lane is bank row bt * 256 + 32 t + 8 q + 4 (lane >> 5) + r for query lane & 31 (tile_epilogue)
+                    const unsigned rbase = (unsigned)bt * HB_BT + 4u * (unsigned)(lane >> 5);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const unsigned row = rbase + 32u * t + 8u * (r >> 2) + (r & 3);
+                            const float v = acc[t][r];
+                            acc[t][r] = (v < c_s || (v == c_s && row > c_i)) ? v : -INFINITY;
+                            if ((r & 3) == 3) KN_FENCE      // (four values at a time: left to itself the scheduler opens all 128 chains at once and spills)
+                        }
+                }
                 if constexpr (WIDE) {
                     // the slot's pool pointers are derived HERE (from one scalar, laundered so that the compiler cannot
                     // hoist them): kept live through the stage loop they crowd out the copy loop's own pointers, which
@@ -658,9 +677,72 @@ static int hb_xcd_collect(hb_index* ix, int fam, const unsigned* stamps_dev, con
     return 0;
 }
 
+// ---- k beyond the pools' 256 (the reference forwards any k to Faiss, search_faiss.py:84-85; faiss-gpu takes up to 2048) ------------------------
+// The best k = the best 256, then the best 256 of the rows BEHIND those in the ordering (score descending, id ascending), and so on: passes of
+// the pool search, each with a per-query ceiling key = the last neighbour delivered so far.  A pass costs a whole search (k = 1024: four), which
+// is what an exact flat search of that width costs here; ids and distance bits are those of one search with a list of k.
+__global__ __launch_bounds__(256) void bigk_place_kernel(const int64_t* __restrict__ tmp_idx, const float* __restrict__ tmp_sc, int64_t nq, int kp, int k,
+                                                         int col0, int64_t id_base, int out_metric, const float* __restrict__ qn2,
+                                                         int64_t* __restrict__ out_idx, float* __restrict__ out_dist, float* __restrict__ ceil_s,
+                                                         unsigned* __restrict__ ceil_i) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nq * kp) return;
+    const int64_t q = t / kp;
+    const int j = (int)(t % kp);
+    const int64_t id = tmp_idx[t];
+    const float s = tmp_sc[t];
+    const int64_t o = q * (int64_t)k + col0 + j;
+    if (id < 0) { out_idx[o] = -1; out_dist[o] = out_metric == 1 ? INFINITY : -INFINITY; }
+    else {
+        out_idx[o] = id + id_base;
+        if (out_metric == 1) { const float d2 = fmaf(-2.0f, s, qn2[q]); out_dist[o] = d2 > 0.0f ? d2 : 0.0f; }
+        else out_dist[o] = s;
+    }
+    if (j == kp - 1) {      // the next pass starts behind this entry; a list that ran out of rows closes the search (nothing is behind -inf)
+        ceil_s[q] = id < 0 ? -INFINITY : s;
+        ceil_i[q] = id < 0 ? 0xFFFFFFFFu : (unsigned)id;
+    }
+}
+
+int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t id_base, int64_t* out_idx, float* out_dist);
+static int hb_launch_knn_bigk(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t id_base, int64_t* out_idx, float* out_dist) {
+    if (nq == 0) return 0;
+    hipStream_t s = ix->stream;
+    const int64_t nqp = (nq + HB_QT - 1) / HB_QT * HB_QT;
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t o_sc = al((size_t)nq * 256 * 8), o_cs = o_sc + al((size_t)nq * 256 * 4), o_ci = o_cs + al((size_t)nqp * 4), tot = o_ci + al((size_t)nqp * 4);
+    if (ensure_bytes(&ix->bigk, &ix->bigk_bytes, tot)) return -1;
+    int64_t* tmp_idx = reinterpret_cast<int64_t*>(ix->bigk);
+    float* tmp_sc = reinterpret_cast<float*>(ix->bigk + o_sc);
+    float* ceil_s = reinterpret_cast<float*>(ix->bigk + o_cs);
+    unsigned* ceil_i = reinterpret_cast<unsigned*>(ix->bigk + o_ci);
+    HB_HIP(hipMemsetD32Async((hipDeviceptr_t)ceil_s, 0xFF800000u, (size_t)nqp, s));      // (padding queries: nothing behind -inf)
+    HB_HIP(hipMemsetD32Async((hipDeviceptr_t)ceil_i, 0xFFFFFFFFu, (size_t)nqp, s));
+    const int out_metric = ix->score_output ? 0 : ix->metric;
+    const int saved_so = ix->score_output, saved_t = ix->time_kernels;
+    double knn_ms = 0.0;
+    int rc = 0;
+    for (int col0 = 0; col0 < k && !rc; col0 += 256) {
+        const int kp = std::min(256, k - col0);
+        ix->score_output = 1;                                // ordering scores: what the next pass's ceiling compares with
+        ix->ceil_s_dev = col0 ? ceil_s : nullptr; ix->ceil_i_dev = col0 ? ceil_i : nullptr;
+        rc = hb_launch_knn(ix, q_dev, nq, kp, 0, tmp_idx, tmp_sc);
+        ix->score_output = saved_so; ix->ceil_s_dev = nullptr; ix->ceil_i_dev = nullptr;
+        if (rc) break;
+        if (saved_t) knn_ms += ix->last_knn_ms;
+        bigk_place_kernel<<<dim3((unsigned)((nq * kp + 255) / 256)), dim3(256), 0, s>>>(tmp_idx, tmp_sc, nq, kp, k, col0, id_base, out_metric, ix->q_aux,
+                                                                                         out_idx, out_dist, ceil_s, ceil_i);
+        HB_HIP(hipGetLastError());
+    }
+    if (saved_t) ix->last_knn_ms = knn_ms;
+    return rc;
+}
+
 // q_tiles / q_aux must already be prepared by the caller (hb_index_search).
 int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t id_base, int64_t* out_idx, float* out_dist) {
-    if (k < 1 || k > 256) return hb_fail("hb_index_search: k must be in [1, 256]");
+    if (k < 1 || k > HB_MAX_K) return hb_fail("hb_index_search: k must be in [1, " + std::to_string(HB_MAX_K) + "] (faiss-gpu's limit, search_faiss.py:84-85)");
+    if (k > 256) return hb_launch_knn_bigk(ix, q_dev, nq, k, id_base, out_idx, out_dist);
+    const bool ceil = ix->ceil_s_dev != nullptr;      // a later pass of a search with k > 256: pools, the LDS-staged kernel's CEIL instantiation
     // fp16 mode 2 (what the plugin's use_fp16=True selects): the candidate pass only where it pays.  Its fixed costs are per query
     // (fp16 query tiles, re-rank of k' = 2k candidates, a second merge) and per search (the phases' launches and floor kernels), what it
     // saves is proportional to the matrix work rows x queries x D: the pass runs from rows x queries x D >= 1.5e10 x (k' / 64)^2 on, and
@@ -719,14 +801,17 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
                 size_t free_b = 0, total_b = 0;
                 HB_HIP(hipMemGetInfo(&free_b, &total_b));
                 ix->rows32_declined_cap = ix->cap_rows;     // (cleared below when the copy is made)
-                // automatic: by the BANK's size against the device's memory, not by what happens to be free at the first search (round 4's rule:
-                // the same index then behaved differently beside other allocations) -- the three copies (fp32 tiles, fp16 tiles, fp32 rows =
-                // 2.5 x the bank) may take up to 55 % of the device: 10 M x 768 (77 of 288 GB) gets the copy, 20 M x 1024 (207 GB) does not; an
-                // allocation that fails all the same just means no copy
+                // automatic (round 6, by measurement: profiles/r06/fp16_residency_*.json): what the copy saves is a few ms of re-rank per search
+                // (about 4 ms for 21,904 queries x 64 candidates), whatever the bank's size, and what it costs is the bank once more.  At 300,000
+                // x 768 that is 17 % of a search for 0.9 GB; at 10 M x 768 1.5 % for 30.7 GB, at 20 M x 1024 and 27.7 M x 768 0.4 % for 83-85 GB.
+                // So only banks of up to 4e9 values (16 GB of fp32: 5.2 M x 768) get it -- a use_fp16 index of a bigger bank holds 1.5 x the bank
+                // (fp32 tiles for the exact re-rank and the fp32 searches, fp16 tiles for the candidate pass), not 2.5 x -- and, as before, only
+                // where the three copies stay within 55 % of the device with room to spare: the search's own workspace is allocated after the
+                // copy, and a device shared with a model or another rank must not be filled to the brim by an optional copy.  An allocation that
+                // fails all the same just means no copy.
                 const size_t bank_b = (size_t)ix->cap_rows * ix->dp * 4;
-                // (and with room to spare: the search's own workspace -- candidate lists, pools, the work list -- is allocated after the copy,
-                // and a device shared with a model or another rank must not be filled to the brim by an optional copy)
-                if (ix->rerank_copy == 1 || (bank_b + bank_b / 2 + need <= total_b / 100 * 55 && free_b > need + std::max<size_t>(total_b / 16, (size_t)2 << 30))) {
+                if (ix->rerank_copy == 1 || (bank_b <= (size_t)16e9 && bank_b + bank_b / 2 + need <= total_b / 100 * 55 &&
+                                             free_b > need + std::max<size_t>(total_b / 16, (size_t)2 << 30))) {
                     if (hipMalloc((void**)&ix->rows32, need) == hipSuccess) { ix->rows32_cap_rows = ix->cap_rows; ix->rows32_rs = rs; ix->rows32_rows = 0; ix->rows32_declined_cap = -1; }
                     else { (void)hipGetLastError(); ix->rows32 = nullptr; if (ix->rerank_copy == 1) return hb_fail("hb_index_search: no memory for the re-rank copy of the bank"); }
                 }
@@ -755,8 +840,8 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     const long long pairs0 = (long long)((nq + HB_QT - 1) / HB_QT) * ((ix->ntotal + HB_BT - 1) / HB_BT);
     const bool small_shape = pairs0 / std::max<long long>(1, std::min<long long>(G0, pairs0)) * ix->g8 < std::min<long long>(small_limit, 120000);   // no gain beyond (1.25 M x 768: 157 k stages)
     const bool bd_shape = ix->g8 % 4 == 0 && ix->variant != 4;
-    const bool small_pools = !f16 && k >= 8 && k <= HB_KL && small_shape && bd_shape && (ix->variant == 0 || ix->variant == 3) && ix->force_cq <= 1;
-    const bool wide = f16 || k > HB_KL || small_pools;
+    const bool small_pools = !f16 && !ceil && k >= 8 && k <= HB_KL && small_shape && bd_shape && (ix->variant == 0 || ix->variant == 3) && ix->force_cq <= 1;
+    const bool wide = f16 || k > HB_KL || small_pools || ceil;
     // pools (k > HB_KL): capacity >= 2 kc so that a compaction is paid for by >= kc cheap appends
     // (smaller / larger pools measure the same on the fp16 candidate kernel: kc + 64, kc + 192)
     const int klw = wide ? std::min(HB_POOL_MAX, (std::max(2 * kc, kc + 128) + 63) / 64 * 64) : HB_KL;
@@ -783,7 +868,8 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // profiles/LABBOOK.md, profiles/r02), so what they buy is traffic, and time only for the fp16 kernel (-8 %).  The 4-wave variant
     // does not know strided segments.
     int cq = 1, cb = 1;
-    if (ix->force_cq > 0 && ix->force_cb > 0) { cq = ix->force_cq; cb = ix->force_cb; }
+    if (ceil) { cq = 1; cb = 1; }
+    else if (ix->force_cq > 0 && ix->force_cb > 0) { cq = ix->force_cq; cb = ix->force_cb; }
     // fp16 candidate kernel: from 70 k stages per workgroup up (round 4: with the lean stage loop and the XCD-level query sharing the
     // clusters pay much earlier than the 400 k of round 3).  Same box, kernel ms (phased), none vs automatic: 10 M x 768 321 / 284,
     // 2.5 M x 768 (157 k stages) 83.0 / 77.5, 5 M x 384 (157 k) 85.3 / 80.3, 1.25 M x 768 (79 k) 43.7 / 41.8, 5 M x 768 x 12,544 queries
@@ -870,6 +956,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     ix->wg_stamp_dev = a.wg_stamp; ix->wg_stamp_blocks = sc.G;
     if (a.wg_stamp) HB_HIP(hipMemsetAsync(a.wg_stamp, 0, stamp_bytes, s));   // a block that never stamps reads 0 / 0 (hb_stamps_summarise)
     a.bank_tiles = ix->tiles; a.binit = ix->binit; a.q_tiles = ix->q_tiles;
+    a.ceil_s = ix->ceil_s_dev; a.ceil_i = ix->ceil_i_dev;
     a.segs = reinterpret_cast<const hb_seg*>(sched_dev);
     a.wg_off = reinterpret_cast<const int*>(sched_dev + o_wg);
     a.wg_end = a.wg_off + 1;
@@ -1059,7 +1146,8 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // The query fragments straight into registers (hbird_knn_bd.hip): -3.8 % kernel time at 10 M x 768 (0.895 -> 0.93 of the
     // fp32 MFMA peak), same bits.  Default for the big LDS-list searches whose stage count per tile is a multiple of four
     // (D = 384, 768, 1024, ...); variant 3 forces it wherever it applies (tests), variant 4 keeps the LDS-staged kernel.
-    if (bd_shape && (ix->variant == 0 || ix->variant == 3 || ix->variant == 6)) {
+    if (ceil) { fn = (knn_fn)knn_fused_kernel<false, true, false, true>; lds_bytes = KN_LDS_TOTAL; }
+    else if (bd_shape && (ix->variant == 0 || ix->variant == 3 || ix->variant == 6)) {
         fn = hb_knn_bd_kernel(wide, a.cl > 1, small);
         lds_bytes = hb_knn_bd_lds_bytes(small && !wide);
     }

@@ -31,6 +31,8 @@ struct knn_args {
     int* cl_stats;          // {checks, spins, timeouts} of the launch
     unsigned* qfl;          // [query][16]: quota floors of small searches (monotone keys; columns 0-6 / 8-14 per slot of the query tile, 7 the plain floor)
     unsigned* wg_stamp;     // diagnostics (hb_index_set_timing) and share calibration: [block][2][4], see wg_stamp(); nullptr: off
+    const float* ceil_s;    // k > 256 (hb_launch_knn_bigk): per query the ordering key (score, row) of the last neighbour the passes before
+    const unsigned* ceil_i; // have delivered -- only rows strictly behind it take part in this pass (knn_fused_kernel<.., CEIL>); nullptr: off
 };
 
 // A kernel argument read again from the kernarg segment at the point of use (through a laundered pointer, so that the

@@ -123,7 +123,8 @@ extern "C" int hb_multi_add(hb_multi_t* m, const float* x, int64_t n, int normal
 extern "C" int hb_multi_search(hb_multi_t* m, const float* q, int64_t nq, int k, int64_t* out_idx, float* out_dist) {
     if (!m) return hb_fail("hb_multi_search: NULL handle");
     if (nq < 0) return hb_fail("hb_multi_search: negative query count");
-    if (k < 1 || k > HB_MAX_K) return hb_fail("hb_multi_search: k must be in [1, " + std::to_string(HB_MAX_K) + "]");
+    if (k < 1 || k > HB_MAX_K_AGGREGATE)
+        return hb_fail("hb_multi_search: k must be in [1, " + std::to_string(HB_MAX_K_AGGREGATE) + "] (the merge of the GPUs' lists; a single-GPU index takes k up to " + std::to_string(HB_MAX_K) + ")");
     if (nq == 0) return 0;
     if (!q || !out_idx || !out_dist) return hb_fail("hb_multi_search: NULL pointer");
     const int ng = (int)m->ix.size();

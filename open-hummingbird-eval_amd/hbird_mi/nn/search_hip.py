@@ -19,7 +19,8 @@ from hbird_mi import _lib
 from hbird_mi.nn.search_base import NearestNeighborSearchBase
 
 _METRICS = {"dot_product": 0, "l2": 1, "euclidean": 1}
-MAX_K = 256
+MAX_K = 256          # of the fused search + label aggregation (HbirdEvaluation) and of sharded searches: HB_MAX_K_AGGREGATE
+MAX_K_SEARCH = 2048  # of a plain search on one GPU -- faiss-gpu's own limit (the reference forwards any k, search_faiss.py:84-85): HB_MAX_K
 
 
 def _ptr(t):
@@ -852,8 +853,12 @@ class NearestNeighborSearchHIP(NearestNeighborSearchBase):
     def find_nearest_neighbors(self, q, k=None):
         if k is None:
             k = self.n_neighbors
-        if not 1 <= k <= MAX_K:
-            raise ValueError(f"k={k} outside the supported range [1, {MAX_K}]")
+        sharded = (self.idx_shard and self.world > 1) or self.multi is not None
+        top = MAX_K if sharded else MAX_K_SEARCH
+        if not 1 <= k <= top:
+            # faiss-gpu raises for k > 2048 (its k-select limit); here one GPU takes the same 2048 (beyond 256 in ceil(k / 256) passes),
+            # a sharded or multi-GPU index 256 (the merge of the shards' lists)
+            raise ValueError(f"k={k} outside the supported range [1, {top}]" + (" of a sharded index (one GPU: up to 2048, faiss-gpu's own limit)" if sharded else " (faiss-gpu's own limit)"))
         if isinstance(q, torch.Tensor) and q.is_cuda:
             idx, dist = self._search_device(q, k)
             return idx, dist

@@ -198,7 +198,7 @@ def test_plugin_errors(cuda_device):
         NearestNeighborSearchHIP(fm, gpu_ids=[99])                       # search_faiss.py:25
     nn = NearestNeighborSearchHIP(fm, n_neighbors=5, some_unknown_kwarg=1)   # **kwargs swallowed
     with pytest.raises(ValueError):
-        nn.find_nearest_neighbors(fm[:2], k=257)
+        nn.find_nearest_neighbors(fm[:2], k=2049)                        # beyond faiss-gpu's own limit of 2048
 
 
 @pytest.mark.parametrize("metric", ["dot_product", "l2"])
