@@ -166,7 +166,7 @@ class HbirdEvaluation:
         import time as _time
         t0 = _time.perf_counter()
         with torch.cuda.device(self.gpu_device):
-            if reuse_memory and self._memory_files_exist():
+            if reuse_memory and self._reusable_memory():
                 # the saved bank of an earlier run: every rank takes its row range of the one file pair
                 self.batches_loaded = 0
                 self.bank_loaded = self.load_memory()
@@ -461,6 +461,42 @@ class HbirdEvaluation:
     def _memory_files_exist(self) -> bool:
         return (self.f_mem_p is not None and self.l_mem_p is not None and os.path.isfile(self.f_mem_p)
                 and os.path.isfile(self.l_mem_p))
+
+    def _reusable_memory(self) -> bool:
+        """May the file pair f_mem_p / l_mem_p stand in for a bank build?  (The reference always rebuilds and overwrites, hbird_eval.py:175;
+        re-use is this engine's addition.)  The files must exist AND fit this run -- feature width, class count, equal row counts, and with
+        memory_size set no more rows than it allows -- otherwise the bank is rebuilt with a warning.  Under torch.distributed RANK 0 decides
+        and broadcasts: ranks that looked for themselves could disagree (a file system that is not shared, a half-written file) and would
+        then meet in different collectives -- load_memory's and _create_memory's -- and hang."""
+        ok = 0
+        if self.rank == 0:
+            ok = 1 if self._memory_files_exist() else 0
+            if ok:
+                try:
+                    fm = torch.load(self.f_mem_p, mmap=True); lm = torch.load(self.l_mem_p, mmap=True)
+                    why = None
+                    if fm.dim() != 2 or lm.dim() != 2 or fm.shape[0] != lm.shape[0]:
+                        why = f"shapes {tuple(fm.shape)} / {tuple(lm.shape)} are not [M, D] / [M, C]"
+                    elif fm.shape[1] != self.feature_extractor.d_model:
+                        why = f"feature width {fm.shape[1]} != the extractor's {self.feature_extractor.d_model}"
+                    elif lm.shape[1] != self.num_classes:
+                        why = f"{lm.shape[1]} label columns != num_classes {self.num_classes}"
+                    elif self.memory_size is not None and fm.shape[0] > self.memory_size:
+                        why = f"{fm.shape[0]} rows > memory_size {self.memory_size}"
+                    if why is not None:
+                        logger.warning("saved bank %s / %s does not fit this run (%s): rebuilding", self.f_mem_p, self.l_mem_p, why)
+                        ok = 0
+                except Exception as e:          # noqa: BLE001 -- an unreadable file is a reason to rebuild, not to fail
+                    logger.warning("saved bank %s / %s cannot be read (%r): rebuilding", self.f_mem_p, self.l_mem_p, e)
+                    ok = 0
+        if self.world > 1:
+            t = torch.tensor([ok], device=self.gpu_device)
+            torch.distributed.broadcast(t, 0)
+            ok = int(t.item())
+            if ok and not self._memory_files_exist():
+                raise RuntimeError(f"rank 0 decided to re-use the saved bank {self.f_mem_p} / {self.l_mem_p}, which rank {self.rank} cannot see: "
+                                   "the bank files must be on a file system all ranks share")
+        return bool(ok)
 
     def load_memory(self) -> bool:
         """Load a bank saved by `_save_memory` (or by the reference) and rebuild the index from it; under a

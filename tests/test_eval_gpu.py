@@ -388,6 +388,30 @@ def test_saved_bank_is_reused_by_a_new_process(cuda_device, golden_dir, tmp_path
     assert abs(loaded[3] - float(g["jac_unb"])) < 1e-4
 
 
+def test_a_saved_bank_that_does_not_fit_is_rebuilt(cuda_device, golden_dir, tmp_path, caplog):
+    """The files exist but belong to another run (other class count / feature width / unreadable): the bank is rebuilt with a warning, as the
+    reference -- which always rebuilds and overwrites (hbird_eval.py:175) -- would, and the files then hold the new bank."""
+    import logging
+    g = np.load(f"{golden_dir}/g67_memory_evaluate.npz")
+    c = golden_case(g, "unb")
+    fp, lp = str(tmp_path / "f.pt"), str(tmp_path / "l.pt")
+    for bad_f, bad_l, why in ((torch.zeros(10, c["D"]), torch.zeros(10, c["C"] + 3), "label columns"),
+                              (torch.zeros(10, c["D"] + 1), torch.zeros(10, c["C"]), "feature width"),
+                              (None, None, "cannot be read")):
+        if bad_f is None:
+            open(fp, "wb").write(b"not a tensor"); open(lp, "wb").write(b"not a tensor")
+        else:
+            torch.save(bad_f, fp); torch.save(bad_l, lp)
+        caplog.clear()
+        with caplog.at_level(logging.WARNING):
+            ev = HbirdEvaluation(ReplayExtractor(c["tr_tok"] + c["va_tok"], c["S"], c["D"]), c["train"], num_classes=c["C"], n_neighbours=c["k"],
+                                 device="cuda", nn_method="hip", f_mem_p=fp, l_mem_p=lp, reuse_memory=True)
+        assert why in caplog.text and "rebuilding" in caplog.text
+        assert ev.bank_loaded is False and ev.batches_loaded == c["nb"]
+        assert tuple(torch.load(fp).shape) == g["feature_memory_unb"].shape and tuple(torch.load(lp).shape) == g["label_memory_unb"].shape
+        assert abs(ev.evaluate(c["val"], c["S"], ignore_index=c["ign"]) - float(g["jac_unb"])) < 1e-4
+
+
 def test_cli_reuses_the_saved_bank(cuda_device, tmp_path):
     """eval.py --f-mem-p / --l-mem-p: the second invocation reports bank_loaded and the same mIoU."""
     import importlib.util, json, os
