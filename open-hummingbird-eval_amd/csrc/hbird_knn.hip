@@ -38,8 +38,8 @@
 // spilled SGPRs inside the stage loop of the pool (WIDE) instantiation (k = 90: +12 % kernel time).
 // (The timing-only ablation instantiations of rounds 1-3 -- no copies / no fragment reads / no barrier / no epilogue -- and the
 // in-kernel counters of the small-search work are gone from the product: their numbers are in profiles/LABBOOK.md and profiles/r01 - r03.)
-// CEIL (pools only): a later pass of a search with k > 256 (hb_launch_knn_bigk) -- every score at or ahead of the query's ceiling key (the last
-// neighbour already delivered) is turned into -inf before the tile's epilogue sees it
+// CEIL (pools only): a later pass of a search with k > 256 (hb_launch_knn_bigk) -- the tile's epilogue only queues rows strictly behind the
+// query's ceiling key (the last neighbour already delivered): tile_epilogue<.., CEIL>
 template <bool COLD, bool WIDE, bool CL = false, bool CEIL = false>
 __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -80,9 +80,6 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
             thr = lst_s[myq * HB_KL + (k - 1)];
         }
         thr = fmaxf(thr, floor_load(a.gthr, seg.q_tile * HB_QT + myq));
-        [[maybe_unused]] float c_s = INFINITY;
-        [[maybe_unused]] unsigned c_i = 0u;
-        if constexpr (CEIL) { c_s = a.ceil_s[seg.q_tile * HB_QT + myq]; c_i = a.ceil_i[seg.q_tile * HB_QT + myq]; }
         const float* qsrc = a.q_tiles + ((size_t)(seg.q_tile * 8 + w) * g8) * HB_BLK + lane * 4;
         const int total = seg.n_tiles * g8;
         f32x16 acc[8];
@@ -183,19 +180,6 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
             KN_FENCE
             slot_c = slot_n;
             if (++ks == g8) {
-                if constexpr (CEIL) {
-                    // acc[t][4 q + r] of this lane is bank row bt * 256 + 32 t + 8 q + 4 (lane >> 5) + r for query lane & 31 (tile_epilogue)
-                    const unsigned rbase = (unsigned)bt * HB_BT + 4u * (unsigned)(lane >> 5);
-#pragma unroll
-                    for (int t = 0; t < 8; ++t)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const unsigned row = rbase + 32u * t + 8u * (r >> 2) + (r & 3);
-                            const float v = acc[t][r];
-                            acc[t][r] = (v < c_s || (v == c_s && row > c_i)) ? v : -INFINITY;
-                            if ((r & 3) == 3) KN_FENCE      // (four values at a time: left to itself the scheduler opens all 128 chains at once and spills)
-                        }
-                }
                 if constexpr (WIDE) {
                     // the slot's pool pointers are derived HERE (from one scalar, laundered so that the compiler cannot
                     // hoist them): kept live through the stage loop they crowd out the copy loop's own pointers, which
@@ -204,7 +188,12 @@ __global__ __launch_bounds__(HB_THREADS, 2) void knn_fused_kernel(knn_args a) {
                     asm volatile("" : "+s"(slot_));
                     float* ps = a.state_s + (size_t)slot_ * HB_QT * klw;
                     unsigned* pi = a.state_i + (size_t)slot_ * HB_QT * klw;
-                    tile_epilogue<true, true>(acc, thr, ps, pi, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
+                    if constexpr (CEIL) {
+                        // (the ceiling is read HERE, once per tile, not kept in registers through the stage loop)
+                        const float c_s = a.ceil_s[seg.q_tile * HB_QT + myq];
+                        const unsigned c_i = a.ceil_i[seg.q_tile * HB_QT + myq];
+                        tile_epilogue<true, true, HB_POOL_MAX / 64, true>(acc, thr, ps, pi, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt, c_s, c_i);
+                    } else tile_epilogue<true, true>(acc, thr, ps, pi, sc, w * 32, lane, k, (unsigned)bt, klw, pcnt);
                 } else if constexpr (COLD) {
                     // small searches: cold start of a slot's first tile (separate instantiation, see launcher)
                     if (seg.first && bt == seg.b_tile0 && cold_start_needed(thr)) thr = fmaxf(thr, cold_start_threshold(acc, k));

@@ -389,9 +389,14 @@ __device__ __forceinline__ void pool_drain(int np, float q0v, float q1v, float q
 // qb = first of the 32 queries (of the workgroup's 256) that `acc` holds.
 // WIDE = false: lst_s / lst_i are the sorted LDS lists.  WIDE = true: they are the slot's pools in global memory
 // (row stride klw = capacity) and `cnt` holds the fill counts of the workgroup's 256 queries in LDS.
-template <bool SLOW = true, bool WIDE = false, int EMAX = HB_POOL_MAX / 64>
+// CEIL (pools only; a later pass of a search with k > 256, hb_launch_knn_bigk): only rows strictly BEHIND the query's ceiling key (c_s, c_i) in
+// the ordering (score descending, row ascending) take part -- tested where a survivor is queued, four compares per flagged quarter.  (The
+// rows ahead of the ceiling flag their quarters for nothing: at most k quarters per query over the whole search.  Masking the 128
+// accumulators ahead of the epilogue instead cost 56 spilled registers inside the stage loop: a pass 2.8 x as long.)
+template <bool SLOW = true, bool WIDE = false, int EMAX = HB_POOL_MAX / 64, bool CEIL = false>
 __device__ __forceinline__ int tile_epilogue(f32x16 (&acc)[8], float& thr, float* lst_s, unsigned* lst_i, float* sc,
-                                              int qb, int lane, int k, unsigned bt, int klw = HB_KL, int* cnt = nullptr) {
+                                              int qb, int lane, int k, unsigned bt, int klw = HB_KL, int* cnt = nullptr,
+                                              float c_s = INFINITY, unsigned c_i = 0u) {
     unsigned qmask = 0;   // bit 4t+q: quarter q (8 bank rows) of row tile t holds a score above its query's threshold
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -417,18 +422,25 @@ __device__ __forceinline__ int tile_epilogue(f32x16 (&acc)[8], float& thr, float
             }
             float q0v = 0.f, q1v = 0.f, q2v = 0.f, q3v = 0.f;
             int np = 0;
-            if (r0 > thr) { q0v = r0; np = 1; }
-            if (r1 > thr) { q3v = q2v; q2v = q1v; q1v = q0v; q0v = r1; ++np; }
-            if (r2 > thr) { q3v = q2v; q2v = q1v; q1v = q0v; q0v = r2; ++np; }
-            if (r3 > thr) { q3v = q2v; q2v = q1v; q1v = q0v; q0v = r3; ++np; }
+            const unsigned row0 = bt * HB_BT + (bit >> 2) * 32 + (bit & 3) * 8 + 4u * (unsigned)(lane >> 5);
+            bool p0 = r0 > thr, p1 = r1 > thr, p2 = r2 > thr, p3 = r3 > thr;
+            if constexpr (CEIL) {
+                p0 = p0 && (r0 < c_s || (r0 == c_s && row0 > c_i));
+                p1 = p1 && (r1 < c_s || (r1 == c_s && row0 + 1u > c_i));
+                p2 = p2 && (r2 < c_s || (r2 == c_s && row0 + 2u > c_i));
+                p3 = p3 && (r3 < c_s || (r3 == c_s && row0 + 3u > c_i));
+            }
+            if (p0) { q0v = r0; np = 1; }
+            if (p1) { q3v = q2v; q2v = q1v; q1v = q0v; q0v = r1; ++np; }
+            if (p2) { q3v = q2v; q2v = q1v; q1v = q0v; q0v = r2; ++np; }
+            if (p3) { q3v = q2v; q2v = q1v; q1v = q0v; q0v = r3; ++np; }
             // the row codes follow from which registers passed: entry i (newest first) is the i-th highest set bit
-            const int pm = (r0 > thr ? 1 : 0) | (r1 > thr ? 2 : 0) | (r2 > thr ? 4 : 0) | (r3 > thr ? 8 : 0);
+            const int pm = (p0 ? 1 : 0) | (p1 ? 2 : 0) | (p2 ? 4 : 0) | (p3 ? 8 : 0);
             int m = pm;
             const int q0c = m ? 31 - __builtin_clz(m) : 0; m &= ~(1 << q0c);
             const int q1c = m ? 31 - __builtin_clz(m) : 0; m &= ~(1 << q1c);
             const int q2c = m ? 31 - __builtin_clz(m) : 0; m &= ~(1 << q2c);
             const int q3c = m ? 31 - __builtin_clz(m) : 0;
-            const unsigned row0 = bt * HB_BT + (bit >> 2) * 32 + (bit & 3) * 8 + 4u * (unsigned)(lane >> 5);
             pool_drain<EMAX>(np, q0v, q1v, q2v, q3v, q0c, q1c, q2c, q3c, thr, lst_s, lst_i, qb, lane, k, row0, klw, cnt);
         }
         return flagged;

@@ -337,8 +337,8 @@ class HipFlatIndex:
         return d
 
     def set_rerank_copy(self, mode: int = 0):
-        """use_fp16 searches: a second, row-major fp32 copy of the bank for the exact re-rank (speed only; 0 automatic -- made when
-        2.5 x the bank stays within 55 % of the device's memory --, 1 always, 2 never)."""
+        """use_fp16 searches: a second, row-major fp32 copy of the bank for the exact re-rank (speed only; 0 automatic -- made for banks of up
+        to 16 GB when 2.5 x the bank stays within 55 % of the device's memory: beyond that it buys under 2 % --, 1 always, 2 never)."""
         _lib.check(_lib.lib().hb_index_set_rerank_copy(self._h, int(mode)))
 
     def rerank_copy_bytes(self) -> int:
