@@ -549,8 +549,8 @@ def use_fp16_leg(index, q, k, device, flops, nq, n=3, warm=8):
                 "clock_ghz_unprofiled": float(np.median(ghz)),
                 "xcd_shares": [round(v, 4) for v in index.xcd_weights(True)[0]], "calibration": index.xcd_stats(True),
                 "note": "certified-exact fast mode, same outputs as the fp32 search; synthetic N(0,1) rows (gap rank 30 -> 64 about 8 E).  Clustered "
-                        "banks (token worlds, profiles/r06/fp16_cliff_10Mx768.json, same shape): 2.3 % first-pass failures 75.6 k q-p/s, 51 % "
-                        "51.3 k, 99.9 % 72.8 k (one k' = 256 pass), banks fp16 cannot certify at all 9.64 k = the fp32 search"}
+                        "banks (token worlds, profiles/r06/final/fp16_cliff_10Mx768.json, same shape): 2.3 % first-pass failures 76.0 k q-p/s, 51 % "
+                        "51.8 k, 99.9 % 71.4 k (one k' = 256 pass), banks fp16 cannot certify at all 9.7 k = the fp32 search"}
     finally:
         index.set_fp16(False)
 

@@ -261,7 +261,7 @@ int hb_index_xcd_stats(const hb_index_t* ix, int fp16_kernel, double out[12]);
  * 512 B apart, so that pass pulls eight times the bytes it uses; a second, row-major fp32 copy of the bank lets it read whole lines (a
  * use_fp16 search at 300,000 x 768: 8.0 -> 6.6 ms, k = 90: 18.0 -> 12.4; results identical).  What it saves is a few ms of re-rank per search whatever
  * the bank's size, what it costs is the bank once more: 17 % of a search for 0.9 GB at 300,000 x 768, 1.5 % for 30.7 GB at 10 M x 768, 0.4 % for
- * 83 GB at 20 M x 1024 (profiles/r06/fp16_residency_*.json).  mode 0 = automatic: the copy is made at the first use_fp16 search for banks of up
+ * 83 GB at 20 M x 1024 (profiles/r06/final/fp16_residency.json).  mode 0 = automatic: the copy is made at the first use_fp16 search for banks of up
  * to 16 GB (5.2 M x 768) when fp32 tiles + fp16 tiles + this copy stay within 55 % of the device's memory with room to spare -- a bigger bank's
  * use_fp16 index holds 1.5 x the bank, not 2.5 x (the whole ADE20K bank, 27.7 M x 768: 130 GB) --; 1 = always (an error if the allocation fails);
  * 2 = never (an existing copy is released).  hb_index_rerank_copy_bytes: what the copy occupies now (0 = none). */

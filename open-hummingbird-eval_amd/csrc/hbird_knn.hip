@@ -745,7 +745,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     bool f16 = ix->fp16 != 0 && k <= 128 &&
                (ix->fp16 == 1 || (ix->ntotal >= 4096 && (double)ix->ntotal * (double)nq * (double)ix->d >= 1.5e10 * kc_rel * kc_rel));
     // ADAPTIVE use (mode 2, round 6): on a bank whose neighbours sit closer together than fp16 can tell apart -- token worlds with little
-    // noise: profiles/r06/fp16_cliff_*.json -- most certificates fail, and passes that certify nothing are pure overhead.  The index keeps
+    // noise: profiles/r06/final/fp16_cliff_*.json -- most certificates fail, and passes that certify nothing are pure overhead.  The index keeps
     // moving averages of the share of queries that failed the first certificate (r1) and of the share that reached the fp32 kernel (r12):
     // r12 > 1/2 -> the fp32 kernel right away; r1 > 1/2 -> the first pass is skipped, ONE pass with k' = 256 serves all queries; every 16th
     // search walks the whole chain again, so a bank (or a query stream) that changes is noticed.  Same bits on every path.
@@ -790,7 +790,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
                 size_t free_b = 0, total_b = 0;
                 HB_HIP(hipMemGetInfo(&free_b, &total_b));
                 ix->rows32_declined_cap = ix->cap_rows;     // (cleared below when the copy is made)
-                // automatic (round 6, by measurement: profiles/r06/fp16_residency_*.json): what the copy saves is a few ms of re-rank per search
+                // automatic (round 6, by measurement: profiles/r06/final/fp16_residency.json): what the copy saves is a few ms of re-rank per search
                 // (about 4 ms for 21,904 queries x 64 candidates), whatever the bank's size, and what it costs is the bank once more.  At 300,000
                 // x 768 that is 17 % of a search for 0.9 GB; at 10 M x 768 1.5 % for 30.7 GB, at 20 M x 1024 and 27.7 M x 768 0.4 % for 83-85 GB.
                 // So only banks of up to 4e9 values (16 GB of fp32: 5.2 M x 768) get it -- a use_fp16 index of a bigger bank holds 1.5 x the bank
