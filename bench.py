@@ -74,6 +74,8 @@ def parse():
     ap.add_argument("--cpu-full-bank", choices=["auto", "never"], default="auto", help="CPU baseline at the full bank size (the bench's own rows fetched to "
                     "the host) when the host has the memory; never = the bounded sample only")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # one untimed step under rocprofv3 --pmc
+    ap.add_argument("--cluster-shape", type=int, nargs=2, default=[0, 0], metavar=("Q", "B"), help="L2-sharing cluster shape of the fp32 searches "
+                    "(0 0 = automatic: kept where they measure faster; 1 1 = none; the counter passes repeat the timed steps' form)")
     return ap.parse_args()
 
 
@@ -249,6 +251,8 @@ def main():
         index.set_variant(a.variant)
     if a.fp16:
         index.set_fp16(True)
+    if a.cluster_shape[0] > 0:
+        index.set_cluster(a.cluster_shape[0], a.cluster_shape[1], 0 if tuple(a.cluster_shape) == (1, 1) else -1)
     index.set_label_denominator(LABEL_P)       # label rows j / 196 as uint16 counts: what HbirdEvaluation does by default (half the table)
     t_build = time.time()
     build_bank(index, lo, hi, D, C, device)
@@ -503,11 +507,15 @@ def main():
         if single and not a.fp16 and not a.no_ab:
             res["xcd_shares_ab"] = safe("equal_shares_leg", legs.equal_shares_leg, index, q, k, device)
         if single and not a.fp16:
-            res["without_clusters"] = safe("without_clusters_leg", legs.without_clusters_leg, index, q, k, device, flops, peak)
+            ab = safe("clusters_ab_leg", legs.clusters_ab_leg, index, q, k, device, flops, peak)
+            if "failed" not in ab:        # the timed steps' own number fills the slot of the form they ran
+                ab["clustered_kernel_ms" if ab["clustered_kernel_ms"] is None else "unclustered_kernel_ms"] = kms
+            res["clusters_ab"] = ab
             res["use_fp16_mode"] = safe("use_fp16_leg", legs.use_fp16_leg, index, q, k, device, flops, nq)
         if single and not a.no_e2e:
             res["e2e"] = safe("e2e_leg", legs.e2e_leg, index, D, C, k, nq, device, max(1, a.e2e_batches))
     if world == 1 and not dist_on:
+        a.cluster_q, a.cluster_b = res["config"]["schedule"].get("cluster") or (1, 1)      # the fp32 counter passes repeat the timed steps' form
         # the CPU baseline at the full bank size wants the bench's own rows on the host: fetched before the index goes
         bank_host, fetch_note, q_host = None, None, None
         if not a.no_cpu_baseline and a.cpu_full_bank == "auto":
@@ -566,8 +574,9 @@ def flatten_into_roofline(res):
     r["equal_shares_kernel_ms"] = get(ab, "equal_shares_kernel_ms")
     r["calibrated_shares_kernel_ms"] = get(ab, "calibrated_shares_kernel_ms")
     r["calibrated_over_equal"] = get(ab, "calibrated_over_equal")
-    r["without_clusters_kernel_ms"] = get(res, "without_clusters", "avg_kernel_ms")
-    r["without_clusters_frac"] = get(res, "without_clusters", "frac")
+    r["clustered_kernel_ms"] = get(res, "clusters_ab", "clustered_kernel_ms"); r["unclustered_kernel_ms"] = get(res, "clusters_ab", "unclustered_kernel_ms")
+    r["clusters_kept_by_measurement"] = get(res, "clusters_ab", "clusters_kept")
+    r["cluster_shape_in_timed_steps"] = "x".join(str(v) for v in (get(res, "clusters_ab", "cluster_in_timed_steps") or [])) or None
     f = res.get("use_fp16_mode")
     r["fp16_value"] = get(f, "value"); r["fp16_ms_per_step"] = get(f, "ms_per_step")
     r["fp16_candidate_kernel_ms"] = get(f, "candidate_kernel_ms")

@@ -259,7 +259,8 @@ def pmc_pass(a, kernel, counters, fp16):
     import csv
     env = dict(os.environ); env["TMPDIR"] = "/tmp"
     args = ["--rows", str(a.rows), "--dim", str(a.dim), "--classes", str(a.classes), "--nq", str(a.nq), "--k", str(a.k),
-            "--workgroups", str(a.workgroups), "--panel", str(a.panel), "--variant", str(a.variant)] + (["--fp16"] if fp16 else [])
+            "--workgroups", str(a.workgroups), "--panel", str(a.panel), "--variant", str(a.variant),
+            ] + (["--fp16"] if fp16 else ["--cluster-shape", str(getattr(a, "cluster_q", 0)), str(getattr(a, "cluster_b", 0))])
     out = tempfile.mkdtemp(prefix="hbird_pmc_", dir="/tmp")
     try:
         cmd = [exe, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", out, "--",
@@ -309,7 +310,8 @@ def measure_traffic(a, kernel):
     import csv
     env = dict(os.environ); env["TMPDIR"] = "/tmp"
     args = ["--rows", str(a.rows), "--dim", str(a.dim), "--classes", str(a.classes), "--nq", str(a.nq), "--k", str(a.k),
-            "--workgroups", str(a.workgroups), "--panel", str(a.panel), "--variant", str(a.variant)] + (["--fp16"] if a.fp16 else [])
+            "--workgroups", str(a.workgroups), "--panel", str(a.panel), "--variant", str(a.variant),
+            ] + (["--fp16"] if a.fp16 else ["--cluster-shape", str(getattr(a, "cluster_q", 0)), str(getattr(a, "cluster_b", 0))])
     vals = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="hbird_pmc_", dir="/tmp")
@@ -519,20 +521,28 @@ def equal_shares_leg(index, q, k, device, fp16=False, n=3):
             "steps_each": n, "verdict": "calibrated shares faster" if c < e else "equal shares not slower on this box (the guard drops shares that measure slower)"}
 
 
-def without_clusters_leg(index, q, k, device, flops, peak, n=3):
-    """The timed steps ran with the automatic L2-sharing clusters (the biggest searches: -60 % fabric reads for under 1 % of kernel time);
-    the same step without them, so that the price is on the line."""
-    cl_auto = tuple(index.schedule_info().get("cluster", (1, 1)))
-    if cl_auto == (1, 1):
-        return {"skipped": "this search runs without clusters anyway"}
-    index.set_cluster(1, 1, 0)
+def clusters_ab_leg(index, q, k, device, flops, peak, n=3):
+    """The biggest fp32 searches can run in L2-sharing clusters (2 x 4 workgroups of one XCD on a common clock: -60 % L2-miss traffic for some
+    cycles).  The index keeps them only where they MEASURE faster on this box (two calibrated launches with, two without, during the first
+    five searches: hb_index_xcd_stats [10]); this leg times the OTHER form, so that both numbers and the decision are on the line."""
+    cur = tuple(index.schedule_info().get("cluster", (1, 1)))
+    st = index.xcd_stats(False)
+    other = (1, 1, 0) if cur != (1, 1) else (2, 4, -1)
+    index.set_cluster(*other)
     try:
         kms, ghz, _ = timed_searches(index, q, k, n, device)
+        other_shape = tuple(index.schedule_info().get("cluster", (1, 1)))
     finally:
         index.set_cluster(0, 0, -1)
     m = float(np.mean(kms))
-    return {"cluster_in_timed_steps": list(cl_auto), "avg_kernel_ms": m, "frac": flops / (m * 1e-3) / 1e12 / peak, "clock_ghz_unprofiled": float(np.median(ghz)),
-            "note": "hb_index_set_cluster(ix, 1, 1, 0); same outputs; roofline.traffic is of the timed (clustered) kernel"}
+    res = {"cluster_in_timed_steps": list(cur), "other_form": list(other_shape), "other_form_kernel_ms": m, "other_form_frac": flops / (m * 1e-3) / 1e12 / peak,
+           "other_form_clock_ghz_unprofiled": float(np.median(ghz)),
+           "decision": {1: "clusters kept (measured faster on this box)", 0: "clusters dropped (measured slower on this box)", -1: "still measuring"}.get(st.get("clusters_kept", -1)),
+           "clusters_kept": st.get("clusters_kept", -1), "clustered_minus_unclustered_ms_at_decision": st.get("clustered_minus_unclustered_ms"),
+           "note": "same outputs either way; roofline.traffic is of the form the timed steps ran"}
+    res["clustered_kernel_ms"] = m if cur == (1, 1) else None            # (the timed steps' own number fills the other slot: bench.py)
+    res["unclustered_kernel_ms"] = m if cur != (1, 1) else None
+    return res
 
 
 def use_fp16_leg(index, q, k, device, flops, nq, n=3, warm=8):

@@ -255,7 +255,10 @@ int hb_index_kernel_clock(hb_index_t* ix, double out[4]);
  * [2] = reverts by the guard, [3] = stamp sets read, [4] = stamp sets rejected (a workgroup that did not stamp, blocks equal mod 8 that did not
  * share an XCD, a time far from the others'), [5] / [6] = shortest launch in ms with the best / the current share set, [7] = work lists built
  * for this index so far (a re-plan costs host time: 8 ms at 10 M x 768), [8] = moves of the group -> XCD map, [9] = the XCD block 0 was last
- * seen on.  In calibrated mode the shares (hb_index_xcd_weights) belong to the PHYSICAL XCDs 0-7 as HW_REG_XCC_ID numbers them. */
+ * seen on, [10] (fp32 family) = the measured decision about the automatic L2-sharing clusters of the biggest fp32 searches: -1 still
+ * measuring, 1 kept, 0 dropped (two calibrated launches with, two without, the faster form stays: hb_index_set_cluster), [11] = shortest
+ * launch with minus without clusters in ms.  In calibrated mode the shares (hb_index_xcd_weights) belong to the PHYSICAL XCDs 0-7 as
+ * HW_REG_XCC_ID numbers them. */
 int hb_index_xcd_stats(const hb_index_t* ix, int fp16_kernel, double out[12]);
 /* use_fp16 searches re-rank their candidates in exact fp32 arithmetic.  In the fragment tiles a bank row is 2 x D/8 sixteen-byte pieces
  * 512 B apart, so that pass pulls eight times the bytes it uses; a second, row-major fp32 copy of the bank lets it read whole lines (a

@@ -201,6 +201,7 @@ extern "C" int hb_index_set_xcd_weights(hb_index_t* ix, int mode, const double* 
     }
     ix->xcd_balance = mode;
     for (auto& c : ix->xcal) { c.stamp_pending = 0; c.rounds = mode == 0 ? 0 : 1; c.locked = 0; c.cur_n = 0; c.best_span = 0.0; c.perm_moves = 0; }
+    // (the clusters' own decision -- xcal[0].cl_* -- is a property of the box: it survives a change of the share mode)
     ix->sched = hb_schedule();
     return 0;
 }
@@ -257,7 +258,8 @@ extern "C" int hb_index_xcd_stats(const hb_index_t* ix, int fp16_kernel, double 
     const hb_index::xcd_cal& c = ix->xcal[fp16_kernel ? 1 : 0];
     out[0] = c.rounds; out[1] = c.locked; out[2] = c.reverts; out[3] = c.samples; out[4] = c.rejected;
     out[5] = c.best_span * 1e-5; out[6] = c.cur_span * 1e-5; out[7] = (double)ix->sched_builds;
-    out[8] = c.perm_moves; out[9] = c.perm[0]; out[10] = out[11] = 0.0;
+    out[8] = c.perm_moves; out[9] = c.perm[0];
+    out[10] = c.cl_state == 2 ? c.cl_choice : -1; out[11] = (c.cl_span_on - c.cl_span_off) * 1e-5;
     return 0;
 }
 extern "C" int hb_index_set_rerank_copy(hb_index_t* ix, int mode) {

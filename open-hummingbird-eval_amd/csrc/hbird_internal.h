@@ -79,6 +79,13 @@ struct hb_index {
         int cur_n = 0, locked = 0, reverts = 0;          // locked: 1 = by the guard, 2 = the group -> XCD map kept moving (equal shares)
         int perm[8] = {0, 1, 2, 3, 4, 5, 6, 7};          // XCD that group g (blocks equal to g mod 8) was last seen on; the shares w[] are per physical XCD
         int perm_moves = 0;
+        // fp32 family only: the automatic L2-sharing clusters of the biggest searches are kept only where they measure faster (hb_launch_knn)
+        int cl_state = 0;                                // 0 = measuring with clusters, 1 = measuring without, 2 = decided
+        int cl_choice = 1;                               // decided: 1 = clusters, 0 = none
+        int cl_n_on = 0, cl_n_off = 0;
+        std::array<int, 3> cl_shape{{0, 0, 0}};            // (query tiles, bank tiles, k) of the launches being compared
+        double cl_span_on = 0.0, cl_span_off = 0.0;      // shortest qualifying launch with / without clusters (100 MHz ticks)
+        int stamp_auto_cluster = 0;                      // the pending stamps are of a search whose cluster shape was the automatic choice
     } xcal[2];
     int64_t sched_builds = 0;                            // work lists built for this index (a re-plan costs host time: 8 ms at 10 M x 768)
     int xcd_balance = 0;                                 // 0 = automatic (big fp32 searches calibrate the shares from their own workgroups' durations), 1 = equal shares, 2 = as set

@@ -530,6 +530,7 @@ __global__ __launch_bounds__(256) void pool_floor_kernel(const float* __restrict
 // the same shares made it SLOWER (281 -> 288-297 ms).  Shares are remembered per device and family for indexes created later.
 static std::mutex g_xcd_mu;
 static std::map<std::pair<int, int>, std::array<double, 8>> g_xcd_known;     // (device, kernel family) -> last calibrated shares
+static std::map<int, int> g_cl_known;                                        // device -> decided: fp32 clusters on (1) / off (0)
 // A launch's stamps, read on the host: per block, at its start and at its end, {100 MHz real-time counter (low word), XCC id, shader-cycle
 // counter lo, hi} (wg_stamp, hbird_knn_dev.h).  -> false when the sample cannot be trusted (the region is zeroed
 // before a stamping launch: a block that never stamped reads 0 / 0; blocks equal mod 8 that did NOT share an XCD, or two such groups on one
@@ -588,6 +589,8 @@ static void hb_xcd_calibrate(hb_index* ix, int fam) {
             if (differs) ix->sched = hb_schedule();
             c.rounds = 1;
         }
+        auto cl = g_cl_known.find(ix->device);
+        if (fam == 0 && cl != g_cl_known.end() && c.cl_state != 2) { c.cl_state = 2; c.cl_choice = cl->second; ix->sched = hb_schedule(); }
     }
     if (!c.stamp_pending || !c.stamp_ev || !c.stamp_host || hipEventQuery(c.stamp_ev) != hipSuccess) { (void)hipGetLastError(); return; }
     const int G = c.stamp_pending;
@@ -604,6 +607,28 @@ static void hb_xcd_calibrate(hb_index* ix, int fam) {
         std::copy(sm.xcc, sm.xcc + 8, c.perm);
         ix->sched = hb_schedule();
         if (++c.perm_moves >= 3) { for (int x = 0; x < 8; ++x) c.w[x] = 1.0; c.locked = 2; }
+    }
+    // The fp32 kernel's automatic L2-sharing clusters (2 x 4 for the biggest searches) cut the L2-miss traffic by 60 % and cost cycles (the
+    // soft sync, more slots, shorter segments).  Whether that pays is a property of the BOX: round 5's driver box -- held at 2.31 GHz by its
+    // power budget -- ran 2.5 % FASTER with them (2314 vs 2374 ms), every box of rounds 5 and 6 that held 2.38-2.39 GHz ran 0.2-0.7 % slower at
+    // the same clock.  So it is measured: launches with calibrated shares are timed with clusters (two), then without (two), by their
+    // spans; the faster form stays for this index and is remembered for the device.  Five searches in all, then nothing changes any more.
+    const std::array<int, 3> shape_now{{c.stamp_key[0], c.stamp_key[1], c.stamp_key[4]}};      // (query tiles, bank tiles, k: spans of one shape only)
+    if (fam == 0 && c.stamp_auto_cluster && c.cl_state < 2 && c.rounds >= 1 && (c.cl_n_on + c.cl_n_off == 0 || shape_now == c.cl_shape)) {
+        const bool clustered = c.stamp_key[5] != 17;      // (cluster shape q * 16 + b; 1 x 1 = 17)
+        c.cl_shape = shape_now;
+        if (c.cl_state == 0 && clustered) {
+            c.cl_span_on = c.cl_n_on ? std::min(c.cl_span_on, sm.span_ticks) : sm.span_ticks;
+            if (++c.cl_n_on >= 2) { c.cl_state = 1; ix->sched = hb_schedule(); }
+        } else if (c.cl_state == 1 && !clustered) {
+            c.cl_span_off = c.cl_n_off ? std::min(c.cl_span_off, sm.span_ticks) : sm.span_ticks;
+            if (++c.cl_n_off >= 2) {
+                c.cl_state = 2; c.cl_choice = c.cl_span_on < c.cl_span_off ? 1 : 0;
+                ix->sched = hb_schedule();
+                std::lock_guard<std::mutex> lock(g_xcd_mu);
+                g_cl_known[ix->device] = c.cl_choice;
+            }
+        }
     }
     if (c.locked == 2) return;
     // The GUARD: shares are kept only while they measure faster.  Launches of one shape (the key) are compared by their span (first start to
@@ -639,7 +664,7 @@ static void hb_xcd_calibrate(hb_index* ix, int fam) {
         change = std::max(change, std::fabs(w[x] / c.w[x] - 1.0));
     }
     // ... and a new work list (10 M x 768: 8 ms of host time) only for a change that is worth it
-    const double worth = fam ? (c.rounds < 2 ? 0.003 : c.rounds < 4 ? 0.006 : 0.012) : (c.rounds < 2 ? 0.0015 : 0.003);   // (fp16: 0.5 % / 0.8 % kept the shares moving: slower)
+    const double worth = fam ? (c.rounds < 2 ? 0.003 : c.rounds < 4 ? 0.006 : 0.012) : (c.rounds < 2 ? 0.0015 : c.rounds < 6 ? 0.003 : 0.006);   // (fp16: 0.5 % / 0.8 % kept the shares moving: slower; fp32, round 6: 0.3 % for ever re-planned four times in twenty steps)
     if (change > worth) {
         for (int x = 0; x < 8; ++x) c.w[x] = w[x];
         ix->sched = hb_schedule();                            // rebuilt with the new shares by the caller
@@ -649,7 +674,7 @@ static void hb_xcd_calibrate(hb_index* ix, int fam) {
 }
 // behind a calibrating launch: its per-block stamps -> pinned host memory, read by the next big search of the family if the copy has completed by then
 static int hb_xcd_collect(hb_index* ix, int fam, const unsigned* stamps_dev, const hb_schedule& sc, const double* shares, int n_phases, int nqt, int nbt,
-                          int k, hipStream_t s) {
+                          int k, hipStream_t s, bool auto_cluster = false) {
     hb_index::xcd_cal& c = ix->xcal[fam];
     if (!stamps_dev || sc.G > 1024 || c.stamp_pending) return 0;
     if (!c.stamp_ev) HB_HIP(hipEventCreateWithFlags(&c.stamp_ev, hipEventDisableTiming));
@@ -659,6 +684,7 @@ static int hb_xcd_collect(hb_index* ix, int fam, const unsigned* stamps_dev, con
     c.stamp_pending = sc.G;
     for (int x = 0; x < 8; ++x) c.stamp_w[x] = shares[x];
     c.stamp_key = {nqt, nbt, sc.G, n_phases, k, sc.cq * 16 + sc.cb};
+    c.stamp_auto_cluster = auto_cluster ? 1 : 0;
     // a phased search stamps its last launch.  Cuts that follow the shares (long lists, hb_finish_schedule) make it a fair sample; with
     // common cuts a group's extra share is all in that launch -- its part of the work
     const double per_wg = (double)nqt * (double)nbt / std::max(1, sc.G);
@@ -851,12 +877,20 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     }
     const int G = ix->force_G > 0 ? ix->force_G : ix->num_cu;
     const size_t tile_bytes = (size_t)HB_BT * ix->dp * 4;
+    // per-XCD work shares (hb_xcd_calibrate above; read BEFORE the cluster shape is chosen: the calibration also decides whether the fp32 clusters stay): calibrated for fp32 searches from 30,000 stages per workgroup (30-60 ms of kernel; from 150,000 until late in
+    // round 5: cfg-2's 2 M x 384 bank went without, 135.3 -> 134.7 ms with; phased searches gain in their last phase only);
+    // shares given by the caller (mode 2) apply to searches of any size, both kernel families (tests/fuzz_small.py FUZZ_XCD=1)
+    const int fam = f16 ? 1 : 0;
+    const bool balance = G % 8 == 0 &&
+                         (ix->xcd_balance == 2 || (ix->xcd_balance == 0 && (long long)nqt * nbt / std::max(1, G) * ix->g8 >= 30000));
+    if (balance && ix->xcd_balance == 0 && esc == 0) hb_xcd_calibrate(ix, fam);     // (nested searches run on the shares in use and leave the calibration alone)
     // L2-sharing clusters (hb_index_set_cluster; automatic shapes below): q x b workgroups of one XCD walk the same bank /
     // query tiles within `lag` stages of each other, so one L2 fill serves several.  Neither kernel is bound by the fabric
     // (the fp32 one by the matrix pipe, the fp16 candidate kernel by its LDS-DMA copies and the power the chip grants it:
     // profiles/LABBOOK.md, profiles/r02), so what they buy is traffic, and time only for the fp16 kernel (-8 %).  The 4-wave variant
     // does not know strided segments.
     int cq = 1, cb = 1;
+    bool auto_cluster = false;      // fp32: the cluster shape of this search is the automatic choice (kept only where it measures faster)
     if (ceil) { cq = 1; cb = 1; }
     else if (ix->force_cq > 0 && ix->force_cb > 0) { cq = ix->force_cq; cb = ix->force_cb; }
     // fp16 candidate kernel: from 70 k stages per workgroup up (round 4: with the lean stage loop and the XCD-level query sharing the
@@ -873,19 +907,18 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // (same box, kernel ms, none vs 2 x 4): 10 M x 768 2280 vs 2298 (+0.8 %), 5 M x 1024 1528 vs 1531 (+0.2 %), but
     // 1.25 M x 768 289.3 vs 293.9 (+1.6 %), 2 M x 384 142.3 vs 146.4 (+2.9 %): more slots, shorter segments.  Automatic from
     // one million stages per workgroup up (8 M rows at D = 768); hb_index_set_cluster(ix, 1, 1, 0) turns them off, (ix, 2, 4, -1) forces them.
+    // Round 6: ... and only where they MEASURE faster on this box (hb_xcd_calibrate: two calibrated launches with, two without, the faster
+    // form stays); without the calibration's stamps (equal or given shares) they stay on.
     else if (!f16 && !wide && ix->variant == 0 && ix->force_cq == 0 && ix->g8 % 4 == 0 &&
-             (long long)nqt * nbt / std::max(1, G) * ix->g8 >= 1000000)
-        hb_default_cluster(nqt, nbt, G, true, &cq, &cb);
+             (long long)nqt * nbt / std::max(1, G) * ix->g8 >= 1000000) {
+        auto_cluster = true;
+        const hb_index::xcd_cal& c0 = ix->xcal[0];
+        const bool measured = ix->xcd_balance == 0 && G % 8 == 0;
+        if (!measured || c0.cl_state == 0 || (c0.cl_state == 2 && c0.cl_choice)) hb_default_cluster(nqt, nbt, G, true, &cq, &cb);
+    }
     if ((long long)nqt * nbt < G || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
     const int panel = ix->force_panel > 0 ? ix->force_panel
                                           : hb_default_panel(nqt, std::min<long long>(G, (long long)nqt * nbt), tile_bytes, cq, cb);
-    // per-XCD work shares (hb_xcd_calibrate above): calibrated for fp32 searches from 30,000 stages per workgroup (30-60 ms of kernel; from 150,000 until late in
-    // round 5: cfg-2's 2 M x 384 bank went without, 135.3 -> 134.7 ms with; phased searches gain in their last phase only);
-    // shares given by the caller (mode 2) apply to searches of any size, both kernel families (tests/fuzz_small.py FUZZ_XCD=1)
-    const int fam = f16 ? 1 : 0;
-    const bool balance = G % 8 == 0 &&
-                         (ix->xcd_balance == 2 || (ix->xcd_balance == 0 && (long long)nqt * nbt / std::max(1, G) * ix->g8 >= 30000));
-    if (balance && ix->xcd_balance == 0 && esc == 0) hb_xcd_calibrate(ix, fam);     // (nested searches run on the shares in use and leave the calibration alone)
     static const double equal_shares[8] = {1, 1, 1, 1, 1, 1, 1, 1};
     // (shares divided by their mean: eight equal shares of any size are the equal list, which is cached as such)
     double shares_n[8];
@@ -1156,7 +1189,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         }
     }
     if (ix->time_kernels) HB_HIP(hipEventRecord(ix->ev1, s));
-    if (balance && ix->xcd_balance == 0 && esc == 0 && hb_xcd_collect(ix, 0, a.wg_stamp, sc, shares, n_phases, nqt, nbt, k, s)) return -1;
+    if (balance && ix->xcd_balance == 0 && esc == 0 && hb_xcd_collect(ix, 0, a.wg_stamp, sc, shares, n_phases, nqt, nbt, k, s, auto_cluster)) return -1;
     const float* qn2 = ix->q_aux;   // [nq] chain ||q||^2 (valid for L2)
     if (launch_merge(ix, a.state_s, a.state_i, pool_cnt, pool_cnt ? a.state_thr : nullptr, reinterpret_cast<const int*>(sched_dev + o_qo),
                      reinterpret_cast<const int*>(sched_dev + o_qs), sc.max_slots_per_qt, nqt, nq, k, klw, id_base, out_metric,

@@ -333,7 +333,7 @@ class HipFlatIndex:
         keys = ["rounds", "locked", "reverts", "samples", "rejected"]
         d = {k: int(out[i]) for i, k in enumerate(keys)}
         d.update({"best_span_ms": float(out[5]), "cur_span_ms": float(out[6]), "work_lists_built": int(out[7]), "xcd_map_moves": int(out[8]),
-                  "xcd_of_block0": int(out[9])})
+                  "xcd_of_block0": int(out[9]), "clusters_kept": int(out[10]), "clustered_minus_unclustered_ms": float(out[11])})
         return d
 
     def set_rerank_copy(self, mode: int = 0):

@@ -40,14 +40,14 @@ def test_scaling_model_is_the_table_in_design_md():
 def test_flat_scalars_reach_roofline():
     bench = _bench()
     res = {"roofline": {}, "xcd_shares_ab": {"equal_shares_kernel_ms": 2300.0, "calibrated_shares_kernel_ms": 2280.0, "calibrated_over_equal": 0.9913},
-           "without_clusters": {"avg_kernel_ms": 2290.0, "frac": 0.93},
+           "clusters_ab": {"clustered_kernel_ms": 2290.0, "unclustered_kernel_ms": 2280.0, "clusters_kept": 0, "cluster_in_timed_steps": [1, 1]},
            "use_fp16_mode": {"value": 8e4, "ms_per_step": 280.0, "candidate_kernel_ms": 270.0, "candidate_kernel_frac_of_fp16_mfma_peak": 0.47,
                              "clock_ghz_unprofiled": 1.6, "fallback_queries": 0, "calibration": {"locked": 0}},
            "e2e": {"failed": "x"}, "miou_parity": {"max_abs_miou_delta_vs_reference": 0.0}}
     bench.flatten_into_roofline(res)
     r = res["roofline"]
     assert r["equal_shares_kernel_ms"] == 2300.0 and r["fp16_value"] == 8e4 and r["fp16_fallback_queries"] == 0 and r["fp16_guard_locked"] == 0
-    assert r["e2e_fp32_images_per_s"] is None and r["miou_max_abs_delta_vs_reference"] == 0.0 and r["without_clusters_frac"] == 0.93
+    assert r["e2e_fp32_images_per_s"] is None and r["miou_max_abs_delta_vs_reference"] == 0.0 and r["unclustered_kernel_ms"] == 2280.0 and r["cluster_shape_in_timed_steps"] == "1x1"
     assert all(not isinstance(v, (dict, list)) for v in r.values())      # flat: the driver's record keeps scalars only
 
 

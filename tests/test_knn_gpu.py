@@ -467,10 +467,16 @@ def test_headline_size_10m_x_768(cuda_device):
     ix.set_fp16(False)
     # the chain oracle at full size: the bank comes back in 1 M-row chunks, each searched by the oracle with its id base, merged on the host
     from helpers import chain_oracle_topk_chunked
-    assert tuple(ix.schedule_info()["cluster"]) != (1, 1), "the headline search is expected to run on the clustered instantiation"
+    # both forms of the big fp32 search -- in 2 x 4 L2-sharing clusters and without (the index keeps whichever measures faster on the box)
+    for shape in ((2, 4, -1), (1, 1, 0)):
+        ix.set_cluster(*shape)
+        ic, dc = ix.search(q, k)
+        assert tuple(ix.schedule_info()["cluster"]) == shape[:2]
+        assert torch.equal(ic, idx) and torch.equal(dc, dist), shape
+    ix.set_cluster(0, 0, -1)
     sel32 = torch.linspace(0, nq - 1, 512, device=dev).long()      # (512 queries, 2.3 % of the batch: the bank chunks' trip to the host is most of what the check costs)
     ci, cd = chain_oracle_topk_chunked(ix, q[sel32], M, k)
-    for name, (gi_, gd_) in (("fp32 clustered", (idx, dist)), ("use_fp16", (idx16, dist16))):
+    for name, (gi_, gd_) in (("fp32", (idx, dist)), ("use_fp16", (idx16, dist16))):
         assert np.array_equal(gi_[sel32].cpu().numpy(), ci), f"{name}: indices differ from the chain oracle at 10 M x 768"
         assert np.array_equal(gd_[sel32].cpu().numpy().view(np.uint32), cd.view(np.uint32)), f"{name}: distance bits differ"
     # float64 scores of 16 queries against every bank row (chunked reconstruct), exact top-k by (score, id)

@@ -25,4 +25,4 @@ for i in range(n):
         print("per-XCD durations (us) min/median/max:", [(round(float(d[x::8].min()) / 100, 1), round(float(np.median(d[x::8])) / 100, 1), round(float(d[x::8].max()) / 100, 1)) for x in range(8)],
               "xcc ok", bool((t[:, 2] == np.arange(len(t)) % 8).all()), flush=True)
     print(json.dumps({"search": i, "knn_ms": round(ix.last_knn_ms(), 3), "clock": {a: round(b, 4) for a, b in ix.kernel_clock().items()},
-                      "shares": [round(v, 4) for v in ix.xcd_weights(fp16)[0]], "stats": ix.xcd_stats(fp16)}), flush=True)
+                      "cluster": ix.schedule_info()["cluster"], "shares": [round(v, 4) for v in ix.xcd_weights(fp16)[0]], "stats": ix.xcd_stats(fp16)}), flush=True)
