@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--e2e-batches", type=int, default=3, help="validation batches of the end-to-end leg in fp32 mode (use_fp16 mode: twice as many)")
     ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 --pmc pass behind clock_ghz / mfma_busy")
     ap.add_argument("--no-ab", action="store_true", help="N = 1: skip the equal-XCD-shares A/B leg")
+    ap.add_argument("--timed-only", action="store_true", help="N = 1: warm-up + timed steps and nothing else (no A/B legs, use_fp16, end to end, counter passes, CPU "
+                    "baseline): what tools/gpu_profile.sh runs under rocprofv3, so that the kernel statistics are those of the timed kernel")
     ap.add_argument("--cpu-full-bank", choices=["auto", "never"], default="auto", help="CPU baseline at the full bank size (the bench's own rows fetched to "
                     "the host) when the host has the memory; never = the bounded sample only")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # one untimed step under rocprofv3 --pmc
@@ -202,6 +204,8 @@ def emit(res):
 
 def main():
     a = parse()
+    if a.timed_only:
+        a.no_ab = a.no_e2e = a.no_counters = a.no_traffic = a.no_cpu_baseline = True
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None:
         if a.gpus is not None and a.gpus > 1:
@@ -506,7 +510,7 @@ def main():
         single = world == 1 and not dist_on
         if single and not a.fp16 and not a.no_ab:
             res["xcd_shares_ab"] = safe("equal_shares_leg", legs.equal_shares_leg, index, q, k, device)
-        if single and not a.fp16:
+        if single and not a.fp16 and not a.timed_only:
             ab = safe("clusters_ab_leg", legs.clusters_ab_leg, index, q, k, device, flops, peak)
             if "failed" not in ab:        # the timed steps' own number fills the slot of the form they ran
                 ab["clustered_kernel_ms" if ab["clustered_kernel_ms"] is None else "unclustered_kernel_ms"] = kms
@@ -551,7 +555,7 @@ def main():
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = safe("cpu_baseline", legs.cpu_baseline, D, k, M, bank_host, q_host, fetch_note)
         del bank_host
-        res["miou_parity"] = safe("miou_parity", legs.miou_parity, device)
+        res["miou_parity"] = None if a.timed_only else safe("miou_parity", legs.miou_parity, device)
         flatten_into_roofline(res)
     if dist_on:
         td.destroy_process_group()

@@ -7,8 +7,13 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_${1:-r3}
 mkdir -p $OUT
 cd /tmp
-B="python3 $ROOT/bench.py --no-cpu-baseline --no-traffic --no-e2e"
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_trace -- $B --steps 3 --warmup 1 > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+B="python3 $ROOT/bench.py --timed-only"
+# the driver's warm-up (5: the share calibration and the cluster decision settle in it) and 5 timed steps, nothing else: the statistics of the
+# kernel the timed steps ran are those of the timed steps (+ the last warm-up searches in the same form)
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_trace -- $B --steps 5 --warmup 5 > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+# the counter passes run ONE search of a fresh index: in the form the timed steps ran (clusters kept or dropped by measurement)
+CS=$(python3 -c "import json; d = json.load(open('$OUT/bench_under_rocprof.json')); print(*d['config']['schedule']['cluster'])")
+B="$B --cluster-shape $CS"
 find /tmp/p_trace -name "*kernel_stats.csv" -exec cp {} $OUT/knn_10Mx768_kernel_stats.csv \;
 find /tmp/p_trace -name "*kernel_trace.csv" -exec sh -c 'head -1 "$1" > "$2"; grep -E "knn_|aggregate_kernel|query_aux|rerank|rows_to_tiles_kernel<false, false>|tiles_to_f16" "$1" | tail -60 >> "$2"' _ {} $OUT/knn_10Mx768_kernel_trace_hot.csv \;
 pass() {  # name, counters...
