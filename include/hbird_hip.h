@@ -277,8 +277,9 @@ int hb_index_schedule_info(const hb_index_t* ix, int64_t out[8]);
  * of one XCD walk (cluster_q query tiles) x (cluster_b interleaved bank tiles) in lockstep, so that one L2 fill serves
  * several workgroups.  0 x 0 = automatic (the fp16 candidate kernel of big searches: 8 x 1, or 4 x 2 / 2 x 2 when that
  * idles fewer pairs; the fp32 kernel: 2 x 4 or 2 x 2, only from one million k8 stages per workgroup up -- it is bound by
- * the matrix pipe, clusters cut its fabric reads by 60 % for under 1 % of time there and cost more on smaller searches,
- * DESIGN.md), 1 x 1 = off, q x b with q * b <= 8 otherwise.  sync_lag: stages a member may run ahead of the slowest one before it waits (-1 = 16, 0 = never). */
+ * the matrix pipe, clusters cut its fabric reads by 60 % and cost cycles: a box held below its nominal clock by its power budget ran 2.5 %
+ * faster with them, boxes at 2.38-2.39 GHz 0.2-0.8 % slower, so the calibration times both forms during an index's first five big searches and
+ * keeps the faster one: hb_index_xcd_stats [10]), 1 x 1 = off, q x b with q * b <= 8 otherwise.  sync_lag: stages a member may run ahead of the slowest one before it waits (-1 = 16, 0 = never). */
 int hb_index_set_cluster(hb_index_t* ix, int cluster_q, int cluster_b, int sync_lag);
 /* How a clustered work list is dealt (speed only): 2 = every run of one query group is split over ALL clusters of an XCD, so that
  * the XCD's workgroups keep re-reading the same cluster_q query tiles -- they stay in its L2 instead of being streamed through the

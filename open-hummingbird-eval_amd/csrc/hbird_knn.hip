@@ -914,7 +914,8 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         auto_cluster = true;
         const hb_index::xcd_cal& c0 = ix->xcal[0];
         const bool measured = ix->xcd_balance == 0 && G % 8 == 0;
-        if (!measured || c0.cl_state == 0 || (c0.cl_state == 2 && c0.cl_choice)) hb_default_cluster(nqt, nbt, G, true, &cq, &cb);
+        // (a decision, once made, holds whatever the share mode; before it: on while measuring with, off while measuring without)
+        if (c0.cl_state == 2 ? c0.cl_choice != 0 : (!measured || c0.cl_state == 0)) hb_default_cluster(nqt, nbt, G, true, &cq, &cb);
     }
     if ((long long)nqt * nbt < G || cq * cb > HB_CLUSTER_MAX || G % (8 * cq * cb) != 0) { cq = 1; cb = 1; }
     const int panel = ix->force_panel > 0 ? ix->force_panel
