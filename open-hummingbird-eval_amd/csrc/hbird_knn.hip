@@ -768,7 +768,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // (Until round 4: at least 16,384 rows and rows x queries >= 2^27.)  Same results either way.
     const int esc = ix->esc_level;      // 0: a caller's search; 1: the second fp16 pass over its uncertified queries; 2: the fp32 search of what is left
     const double kc_rel = std::min(256, std::max(64, (2 * k + 7) / 8 * 8)) / 64.0;
-    bool f16 = ix->fp16 != 0 && k <= 128 &&
+    bool f16 = ix->fp16 != 0 && k <= 128 && !ceil &&      // (a later pass of a search with k > 256 runs behind a ceiling, which only the fp32 pool kernel knows)
                (ix->fp16 == 1 || (ix->ntotal >= 4096 && (double)ix->ntotal * (double)nq * (double)ix->d >= 1.5e10 * kc_rel * kc_rel));
     // ADAPTIVE use (mode 2, round 6): on a bank whose neighbours sit closer together than fp16 can tell apart -- token worlds with little
     // noise: profiles/r06/final/fp16_cliff_*.json -- most certificates fail, and passes that certify nothing are pure overhead.  The index keeps

@@ -257,6 +257,20 @@ def test_k_beyond_256_in_passes_behind_a_ceiling(cuda_device, k, metric):
     _check_exact(i2, d2, q[:64], bank, k, metric)
 
 
+@pytest.mark.parametrize("k", [300, 384, 600])
+def test_k_beyond_256_with_use_fp16_set(cuda_device, k):
+    """use_fp16 applies up to k = 128; a search with k > 256 whose LAST pass is that narrow (k = 300: 256 + 44) must still run it behind the
+    ceiling on the fp32 kernel -- the flag is accepted, the bits are the fp32 search's."""
+    M, D, nq = 30_000, 128, 200
+    bank = gi.unit_bank(M, D, seed=101); q = gi.vit_like_queries(nq, D, seed=102)
+    ix = HipFlatIndex(D, 0, 0); ix.add(torch.from_numpy(bank).cuda())
+    for mode in (1, 2):
+        ix.set_fp16(mode)
+        idx, dist = ix.search(torch.from_numpy(q).cuda(), k)
+        _check_exact(idx, dist, q, bank, k, "dot_product")
+        assert ix.last_fp16_fallbacks() == 0 and ix.last_fp16_escalated() == 0
+
+
 def test_k_beyond_256_on_a_bank_with_fewer_rows(cuda_device):
     """k = 700 over 600 rows, three of them NaN: 597 neighbours, then id -1 / -inf -- the list closes in the pass where the rows run out
     and later passes deliver nothing."""
