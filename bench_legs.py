@@ -418,7 +418,10 @@ def e2e_leg(index, D, C, k, nq, device, n_batches):
                      "images_per_s_steady_state": B / (gpu_ms * 1e-3) if gpu_ms > 0 else None,
                      "bound_by": max(on_stream, key=on_stream.get) if on_stream else None,
                      "h2d_and_loader": "overlapped: the next batch is fetched and copied on a side stream during the current search",
-                     "miou_of_random_weights": float(jac)}
+                     "miou_of_random_weights": float(jac),
+                     # use_fp16: what the LAST batch's search did about its certificates (hb_index_last_fp16_escalated / _fallbacks)
+                     "last_batch_first_certificate_failed": index.last_fp16_escalated() if fp16 else None,
+                     "last_batch_reached_fp32": index.last_fp16_fallbacks() if fp16 else None}
     index.set_fp16(False)
     del ev, ext, vit
     torch.cuda.empty_cache()
