@@ -250,7 +250,8 @@ int hb_index_wg_stamps(hb_index_t* ix, uint32_t* out, int max_blocks, int* workg
  * Zeros when the last launch did not stamp (hb_index_set_timing off and no share calibration).  One stream synchronisation. */
 int hb_index_kernel_clock(hb_index_t* ix, double out[4]);
 /* State of the share calibration of one kernel family (fp16_kernel as above): out[0] = calibration rounds, [1] = 1 when the GUARD has locked
- * the shares -- a share set whose launches (same shape, shortest of at least two) measured 0.15 % slower than the best set seen is dropped, the
+ * the shares -- a share set whose launches (same shape, shortest of at least two) measured 0.15 % slower than the best set seen (the fp16
+ * candidate kernel, whose launches scatter by 0.5 %: three launches, 0.8 %) is dropped, the
  * best set returns and this index stops calibrating --, 2 when the map from block groups to XCDs kept moving (equal shares from then on),
  * [2] = reverts by the guard, [3] = stamp sets read, [4] = stamp sets rejected (a workgroup that did not stamp, blocks equal mod 8 that did not
  * share an XCD, a time far from the others'), [5] / [6] = shortest launch in ms with the best / the current share set, [7] = work lists built
