@@ -261,6 +261,18 @@ int hb_index_kernel_clock(hb_index_t* ix, double out[4]);
  * launch with minus without clusters in ms.  In calibrated mode the shares (hb_index_xcd_weights) belong to the PHYSICAL XCDs 0-7 as
  * HW_REG_XCC_ID numbers them. */
 int hb_index_xcd_stats(const hb_index_t* ix, int fp16_kernel, double out[12]);
+/* The calibration's decisions without a GPU (tests; like hb_schedule_plan* for the planner): a state as an index keeps per kernel family, fed with
+ * the stamp sets of imagined launches.  hb_calibration_new(fp16_kernel) -> handle; hb_calibration_state: the GROUP shares the next launch would
+ * run with (group g = blocks equal to g mod 8) and out[0..11] = rounds, locked, reverts, samples, rejected, moves of the group -> XCD map, cluster
+ * state (0 measuring with, 1 measuring without, 2 decided), cluster choice, launches of the current share set, the XCD of block 0, launches measured
+ * with / without clusters; hb_calibration_feed: one launch's stamps [G][2][4] = per block at its start and end {100 MHz ticks, XCC id, shader
+ * cycles lo, hi}, the group shares it ran with, its shape key {query tiles, bank tiles, workgroups, phases, k, cluster shape q * 16 + b}, whether
+ * that cluster shape was the automatic choice, the launch's part of the search's work -> flags: 1 rebuild the work list, 2 remember the shares, 4
+ * remember the cluster decision, 8 the set was rejected (negative: bad arguments). */
+void* hb_calibration_new(int fp16_kernel);
+void hb_calibration_free(void* h);
+int hb_calibration_state(const void* h, double shares8[8], int64_t out[12]);
+int hb_calibration_feed(void* h, const uint32_t* stamps, int G, const double run_shares8[8], const int key6[6], int auto_cluster, double frac);
 /* use_fp16 searches re-rank their candidates in exact fp32 arithmetic.  In the fragment tiles a bank row is 2 x D/8 sixteen-byte pieces
  * 512 B apart, so that pass pulls eight times the bytes it uses; a second, row-major fp32 copy of the bank lets it read whole lines (a
  * use_fp16 search at 300,000 x 768: 8.0 -> 6.6 ms, k = 90: 18.0 -> 12.4; results identical).  What it saves is a few ms of re-rank per search whatever

@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include "hbird_schedule.h"
+#include "hbird_calibrate.h"
 
 // ---- tile geometry of the kNN kernel (see DESIGN.md "Data layout in HBM") -------------------
 #define HB_RT 32         // rows per fragment tile (MFMA 32x32x2)
@@ -63,29 +64,14 @@ struct hb_index {
     int xcd_share = 0;                                   // clustered work lists: 0 = automatic, 1 = off, 2 = on (hb_index_set_cluster_sharing)
     // work shares per XCD group (blocks equal mod 8): hb_index_set_xcd_weights / calibrated from the workgroups' own time stamps.
     // Two families with shares of their own: [0] the fp32 kernels, [1] the fp16 candidate kernel (power-limited: its XCDs differ by other amounts)
-    struct xcd_cal {
-        double w[8] = {1, 1, 1, 1, 1, 1, 1, 1};          // shares in use
+    struct xcd_cal : hb_xcd_state {                      // (the decisions' state: hbird_calibrate.h; here the HIP side)
         unsigned* stamp_host = nullptr;                  // pinned copy of the last calibrating launch's per-block stamps ...
         hipEvent_t stamp_ev = nullptr;                   // ... complete when this event is
         int stamp_pending = 0;                           // blocks of that launch (0: nothing to read)
-        double stamp_w[8] = {1, 1, 1, 1, 1, 1, 1, 1};    // the shares that launch ran with
+        double stamp_w[8] = {1, 1, 1, 1, 1, 1, 1, 1};    // the GROUP shares that launch ran with
         double stamp_frac = 1.0;                         // ... and its part of the search's work (phased searches stamp their LAST launch)
-        int rounds = 0;
-        int samples = 0, rejected = 0;                   // stamp sets read / thrown away (hb_stamps_summarise)
-        // the guard (hb_xcd_calibrate): shares stay only while launches of the same shape measure faster with them
-        std::array<int, 6> key{{0, 0, 0, 0, 0, 0}}, stamp_key{{0, 0, 0, 0, 0, 0}};   // shape of the launches being compared / of the pending stamps
-        double cur_w[8] = {1, 1, 1, 1, 1, 1, 1, 1}, best_w[8] = {1, 1, 1, 1, 1, 1, 1, 1};
-        double cur_span = 0.0, best_span = 0.0;          // shortest launch (100 MHz ticks, first start to last end) with the current / the best share set
-        int cur_n = 0, locked = 0, reverts = 0;          // locked: 1 = by the guard, 2 = the group -> XCD map kept moving (equal shares)
-        int perm[8] = {0, 1, 2, 3, 4, 5, 6, 7};          // XCD that group g (blocks equal to g mod 8) was last seen on; the shares w[] are per physical XCD
-        int perm_moves = 0;
-        // fp32 family only: the automatic L2-sharing clusters of the biggest searches are kept only where they measure faster (hb_launch_knn)
-        int cl_state = 0;                                // 0 = measuring with clusters, 1 = measuring without, 2 = decided
-        int cl_choice = 1;                               // decided: 1 = clusters, 0 = none
-        int cl_n_on = 0, cl_n_off = 0;
-        std::array<int, 3> cl_shape{{0, 0, 0}};            // (query tiles, bank tiles, k) of the launches being compared
-        double cl_span_on = 0.0, cl_span_off = 0.0;      // shortest qualifying launch with / without clusters (100 MHz ticks)
-        int stamp_auto_cluster = 0;                      // the pending stamps are of a search whose cluster shape was the automatic choice
+        std::array<int, 6> stamp_key{{0, 0, 0, 0, 0, 0}};   // ... its shape
+        int stamp_auto_cluster = 0;                      // ... and whether its cluster shape was the automatic choice
     } xcal[2];
     int64_t sched_builds = 0;                            // work lists built for this index (a re-plan costs host time: 8 ms at 10 M x 768)
     int xcd_balance = 0;                                 // 0 = automatic (big fp32 searches calibrate the shares from their own workgroups' durations), 1 = equal shares, 2 = as set

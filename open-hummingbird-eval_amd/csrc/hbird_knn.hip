@@ -531,53 +531,6 @@ __global__ __launch_bounds__(256) void pool_floor_kernel(const float* __restrict
 static std::mutex g_xcd_mu;
 static std::map<std::pair<int, int>, std::array<double, 8>> g_xcd_known;     // (device, kernel family) -> last calibrated shares
 static std::map<int, int> g_cl_known;                                        // device -> decided: fp32 clusters on (1) / off (0)
-// A launch's stamps, read on the host: per block, at its start and at its end, {100 MHz real-time counter (low word), XCC id, shader-cycle
-// counter lo, hi} (wg_stamp, hbird_knn_dev.h).  -> false when the sample cannot be trusted (the region is zeroed
-// before a stamping launch: a block that never stamped reads 0 / 0; blocks equal mod 8 that did NOT share an XCD, or two such groups on one
-// XCD, say the dispatch order is not what the share groups assume; a duration far from the others' is a wrap or a preempted block).
-// WHICH XCD a group ran on is an output (xcc[g]): HIP promises no placement, block 0 usually lands on XCD 0 but need not
-// (MI355X_MICROARCH.md, "Workgroup dispatch"), and the shares belong to the physical XCDs.
-struct hb_stamp_summary { double med[8]; int xcc[8]; double all; double span_ticks; double ghz_med, ghz_min, ghz_max; };
-static bool hb_stamps_summarise(const unsigned* st, int G, hb_stamp_summary& o) {
-    if (G < 8 || G % 8 != 0) return false;
-    std::vector<double> dur[8], every, ghz;
-    const unsigned s0 = st[0];
-    long long first = 0, last = 0;
-    for (int b = 0; b < G; ++b) {
-        const unsigned* sb = st + 8 * (size_t)b;
-        const unsigned t0 = sb[0], t1 = sb[4], xcc = sb[1];
-        if (t0 == 0u && t1 == 0u) return false;
-        if (xcc > 7u || sb[5] != xcc) return false;
-        if (b < 8) o.xcc[b] = (int)xcc;
-        else if ((int)xcc != o.xcc[b & 7]) return false;
-        const unsigned d = t1 - t0;                       // (mod 2^32: a launch is far shorter than 43 s)
-        if (d == 0u || d > 0x7FFFFFFFu) return false;
-        dur[b & 7].push_back((double)d); every.push_back((double)d);
-        const long long rs = (long long)(int)(t0 - s0), re = rs + (long long)d;
-        if (b == 0) { first = rs; last = re; }
-        first = std::min(first, rs); last = std::max(last, re);
-        const unsigned long long c0 = ((unsigned long long)sb[3] << 32) | sb[2], c1 = ((unsigned long long)sb[7] << 32) | sb[6];
-        if (c1 > c0 && d >= 100u) ghz.push_back((double)(c1 - c0) / (double)d * 0.1);       // cycles per 10 ns tick -> GHz
-    }
-    for (int x = 0, seen = 0; x < 8; ++x) { if (seen & (1 << o.xcc[x])) return false; seen |= 1 << o.xcc[x]; }
-    std::nth_element(every.begin(), every.begin() + every.size() / 2, every.end());
-    const double m_all = every[every.size() / 2];
-    o.all = 0.0;
-    for (int x = 0; x < 8; ++x) {
-        if (dur[x].empty()) return false;
-        std::nth_element(dur[x].begin(), dur[x].begin() + dur[x].size() / 2, dur[x].end());
-        o.med[x] = dur[x][dur[x].size() / 2];
-        if (!(o.med[x] > 0.5 * m_all && o.med[x] < 1.5 * m_all)) return false;
-        o.all += o.med[x] / 8.0;
-    }
-    o.span_ticks = (double)(last - first);
-    o.ghz_med = o.ghz_min = o.ghz_max = 0.0;
-    if (!ghz.empty()) {
-        std::sort(ghz.begin(), ghz.end());
-        o.ghz_med = ghz[ghz.size() / 2]; o.ghz_min = ghz.front(); o.ghz_max = ghz.back();
-    }
-    return true;
-}
 static void hb_xcd_calibrate(hb_index* ix, int fam) {
     hb_index::xcd_cal& c = ix->xcal[fam];
     if (c.rounds == 0 && !c.stamp_pending) {        // a new index starts from what this device is known to need
@@ -595,86 +548,21 @@ static void hb_xcd_calibrate(hb_index* ix, int fam) {
     if (!c.stamp_pending || !c.stamp_ev || !c.stamp_host || hipEventQuery(c.stamp_ev) != hipSuccess) { (void)hipGetLastError(); return; }
     const int G = c.stamp_pending;
     c.stamp_pending = 0;
-    hb_stamp_summary sm;
-    if (!hb_stamps_summarise(c.stamp_host, G, sm)) { ++c.rejected; return; }
-    ++c.samples;
-    // Everything below is in terms of the PHYSICAL XCDs: group g of this launch ran on XCD sm.xcc[g] with the share stamp_w[g].  A launch
-    // whose groups sat on other XCDs than the work list assumed (c.perm) moves the map (and the list is rebuilt for it); a map that keeps
-    // moving makes shares meaningless: after three moves this index keeps equal shares.
-    double run_w[8], med[8];
-    for (int g = 0; g < 8; ++g) { run_w[sm.xcc[g]] = c.stamp_w[g]; med[sm.xcc[g]] = sm.med[g]; }
-    if (!std::equal(sm.xcc, sm.xcc + 8, c.perm)) {
-        std::copy(sm.xcc, sm.xcc + 8, c.perm);
-        ix->sched = hb_schedule();
-        if (++c.perm_moves >= 3) { for (int x = 0; x < 8; ++x) c.w[x] = 1.0; c.locked = 2; }
-    }
-    // The fp32 kernel's automatic L2-sharing clusters (2 x 4 for the biggest searches) cut the L2-miss traffic by 60 % and cost cycles (the
-    // soft sync, more slots, shorter segments).  Whether that pays is a property of the BOX: round 5's driver box -- held at 2.31 GHz by its
-    // power budget -- ran 2.5 % FASTER with them (2314 vs 2374 ms), every box of rounds 5 and 6 that held 2.38-2.39 GHz ran 0.2-0.7 % slower at
-    // the same clock.  So it is measured: launches with calibrated shares are timed with clusters (two), then without (two), by their
-    // spans; the faster form stays for this index and is remembered for the device.  Five searches in all, then nothing changes any more.
-    const std::array<int, 3> shape_now{{c.stamp_key[0], c.stamp_key[1], c.stamp_key[4]}};      // (query tiles, bank tiles, k: spans of one shape only)
-    if (fam == 0 && c.stamp_auto_cluster && c.cl_state < 2 && c.rounds >= 1 && (c.cl_n_on + c.cl_n_off == 0 || shape_now == c.cl_shape)) {
-        const bool clustered = c.stamp_key[5] != 17;      // (cluster shape q * 16 + b; 1 x 1 = 17)
-        c.cl_shape = shape_now;
-        if (c.cl_state == 0 && clustered) {
-            c.cl_span_on = c.cl_n_on ? std::min(c.cl_span_on, sm.span_ticks) : sm.span_ticks;
-            if (++c.cl_n_on >= 2) { c.cl_state = 1; ix->sched = hb_schedule(); }
-        } else if (c.cl_state == 1 && !clustered) {
-            c.cl_span_off = c.cl_n_off ? std::min(c.cl_span_off, sm.span_ticks) : sm.span_ticks;
-            if (++c.cl_n_off >= 2) {
-                c.cl_state = 2; c.cl_choice = c.cl_span_on < c.cl_span_off ? 1 : 0;
-                ix->sched = hb_schedule();
-                std::lock_guard<std::mutex> lock(g_xcd_mu);
-                g_cl_known[ix->device] = c.cl_choice;
-            }
-        }
-    }
-    if (c.locked == 2) return;
-    // The GUARD: shares are kept only while they measure faster.  Launches of one shape (the key) are compared by their span (first start to
-    // last end, the minimum over a share set's launches: clock dips only ever lengthen one); a share set that has had two launches and is still
-    // 0.15 % slower than the best set seen (fp16 family: three launches, 0.8 %) goes, the best set comes back, and this index stops calibrating that family (round 5's driver box
-    // ran 1.6 % slower than the builder's boxes with shares spread +- 2.8 %, and its record could not say whether the shares were the reason).
-    if (c.key != c.stamp_key) { c.key = c.stamp_key; c.best_span = 0.0; c.cur_n = 0; c.locked = 0; }
-    if (c.cur_n > 0 && std::equal(run_w, run_w + 8, c.cur_w)) { c.cur_span = std::min(c.cur_span, sm.span_ticks); ++c.cur_n; }
-    else {
-        if (c.cur_n > 0 && (c.best_span == 0.0 || c.cur_span < c.best_span)) { c.best_span = c.cur_span; std::copy(c.cur_w, c.cur_w + 8, c.best_w); }
-        std::copy(run_w, run_w + 8, c.cur_w); c.cur_span = sm.span_ticks; c.cur_n = 1;
-    }
-    auto remember = [&]() {
+    // the decisions themselves are plain host code (hbird_calibrate.cpp: also fed with synthetic stamps by tests/test_calibrate_cpu.py)
+    hb_stamp_set set;
+    set.stamps = c.stamp_host; set.G = G; set.key = c.stamp_key; set.frac = c.stamp_frac; set.auto_cluster = c.stamp_auto_cluster;
+    for (int x = 0; x < 8; ++x) set.run_shares[x] = c.stamp_w[x];
+    const int flags = hb_xcd_step(c, fam, set);
+    if (flags & HB_CAL_REBUILD) ix->sched = hb_schedule();                     // rebuilt with the new shares / cluster form by the caller
+    if (flags & (HB_CAL_REMEMBER_SHARES | HB_CAL_REMEMBER_CLUSTERS)) {
         std::lock_guard<std::mutex> lock(g_xcd_mu);
-        std::array<double, 8> keep;
-        for (int x = 0; x < 8; ++x) keep[x] = c.w[x];
-        g_xcd_known[{ix->device, fam}] = keep;
-    };
-    // (the fp16 candidate kernel's launches scatter by +- 0.5 % from search to search and its stamps cover the last phase only: three launches and
-    // 0.8 % there -- with the fp32 rule one box of round 6 went back to equal shares on a 0.4 % difference and kept them: 284 ms where shares give 275)
-    const int guard_n = fam ? 3 : 2;
-    const double guard_tol = fam ? 1.008 : 1.0015;
-    if (c.best_span > 0.0 && c.cur_n >= guard_n && c.cur_span > c.best_span * guard_tol && !std::equal(c.cur_w, c.cur_w + 8, c.best_w)) {
-        for (int x = 0; x < 8; ++x) c.w[x] = c.best_w[x];
-        ix->sched = hb_schedule();
-        c.locked = 1; ++c.reverts; ++c.rounds;
-        remember();
-        return;
+        if (flags & HB_CAL_REMEMBER_SHARES) {
+            std::array<double, 8> keep;
+            for (int x = 0; x < 8; ++x) keep[x] = c.w[x];
+            g_xcd_known[{ix->device, fam}] = keep;
+        }
+        if (flags & HB_CAL_REMEMBER_CLUSTERS) g_cl_known[ix->device] = c.cl_choice;
     }
-    if (c.locked) return;
-    // (a duration that is off by e in a launch holding the part f of the work is mended by e x f of the whole share)
-    double w[8], mean = 0.0, change = 0.0;
-    for (int x = 0; x < 8; ++x) { w[x] = run_w[x] * (1.0 + c.stamp_frac * (sm.all / med[x] - 1.0)); mean += w[x] / 8.0; }
-    for (int x = 0; x < 8; ++x) {
-        w[x] = std::min(1.25, std::max(0.8, w[x] / mean));
-        if (fam && c.rounds >= 2) w[x] = 0.5 * (w[x] + c.w[x]);      // the fp16 kernel's durations scatter by +- 0.5 % from search to search: damped ...
-        change = std::max(change, std::fabs(w[x] / c.w[x] - 1.0));
-    }
-    // ... and a new work list (10 M x 768: 8 ms of host time) only for a change that is worth it
-    const double worth = fam ? (c.rounds < 2 ? 0.003 : c.rounds < 4 ? 0.006 : 0.012) : (c.rounds < 2 ? 0.0015 : c.rounds < 6 ? 0.003 : 0.006);   // (fp16: 0.5 % / 0.8 % kept the shares moving: slower; fp32, round 6: 0.3 % for ever re-planned four times in twenty steps)
-    if (change > worth) {
-        for (int x = 0; x < 8; ++x) c.w[x] = w[x];
-        ix->sched = hb_schedule();                            // rebuilt with the new shares by the caller
-        remember();
-    }
-    ++c.rounds;
 }
 // behind a calibrating launch: its per-block stamps -> pinned host memory, read by the next big search of the family if the copy has completed by then
 static int hb_xcd_collect(hb_index* ix, int fam, const unsigned* stamps_dev, const hb_schedule& sc, const double* shares, int n_phases, int nqt, int nbt,

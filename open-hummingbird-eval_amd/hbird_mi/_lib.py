@@ -92,6 +92,10 @@ SIGNATURES = {
     "hb_schedule_plan_weighted": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_double), c_void_p, c_int64, POINTER(c_int64)]),
     "hb_index_kernel_clock": (c_int, [c_void_p, POINTER(c_double)]),
     "hb_index_xcd_stats": (c_int, [c_void_p, c_int, POINTER(c_double)]),
+    "hb_calibration_new": (c_void_p, [c_int]),
+    "hb_calibration_free": (None, [c_void_p]),
+    "hb_calibration_state": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
+    "hb_calibration_feed": (c_int, [c_void_p, c_void_p, c_int, POINTER(c_double), POINTER(c_int), c_int, c_double]),
     "hb_index_set_rerank_copy": (c_int, [c_void_p, c_int]),
     "hb_index_rerank_copy_bytes": (c_int, [c_void_p, POINTER(c_int64)]),
     "hb_index_schedule_info": (c_int, [c_void_p, POINTER(c_int64)]),
@@ -116,10 +120,10 @@ def lib() -> ctypes.CDLL:
                 f"g.build()' or make -C {CSRC_DIR}). There is no CPU fallback.")
         L = ctypes.CDLL(LIB_PATH)
         # HBIRD_PLAN_ONLY=1 (tests/test_sanitizers_cpu.py): LIB_PATH names the host-only sanitizer build of the work-list planner,
-        # which exports the hb_schedule_plan* entry points and hb_last_error only
+        # which exports the hb_schedule_plan* / hb_calibration_* entry points and hb_last_error only
         plan_only = os.environ.get("HBIRD_PLAN_ONLY") == "1"
         for name, (res, args) in SIGNATURES.items():
-            if plan_only and not (name.startswith("hb_schedule_plan") or name == "hb_last_error"):
+            if plan_only and not (name.startswith("hb_schedule_plan") or name.startswith("hb_calibration_") or name == "hb_last_error"):
                 continue
             fn = getattr(L, name)  # AttributeError here = header and library disagree
             fn.restype = res

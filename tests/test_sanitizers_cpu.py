@@ -51,3 +51,6 @@ def test_work_list_planner_under_asan_ubsan():
     out = _run_under_asan(["tests/test_schedule_cpu.py", "-k", "not multi_index_row_planning"],
                           {"HBIRD_HIP_LIB": lib, "HBIRD_PLAN_ONLY": "1"})
     assert " passed" in out
+    # ... and the decisions taken from the workgroups' time stamps (csrc/hbird_calibrate.cpp, in the same host-only library)
+    out = _run_under_asan(["tests/test_calibrate_cpu.py"], {"HBIRD_HIP_LIB": lib, "HBIRD_PLAN_ONLY": "1"})
+    assert " passed" in out
