@@ -273,6 +273,10 @@ void* hb_calibration_new(int fp16_kernel);
 void hb_calibration_free(void* h);
 int hb_calibration_state(const void* h, double shares8[8], int64_t out[12]);
 int hb_calibration_feed(void* h, const uint32_t* stamps, int G, const double run_shares8[8], const int key6[6], int auto_cluster, double frac);
+/* ... and the adaptive use of use_fp16 (mode 2) on a stream of n imagined searches of nq queries: f1[i] / f2[i] = the share of queries that would
+ * fail the first certificate / of those the second pass at search i; out_how[i] = how the index would run search i given what it saw before:
+ * 0 the chain (first pass, second pass for its failures, fp32 for the rest), 1 one pass with k' = 256 for all queries, 2 the fp32 kernel right away. */
+int hb_f16_adapt_replay(int n, const double* f1, const double* f2, int64_t nq, int* out_how);
 /* use_fp16 searches re-rank their candidates in exact fp32 arithmetic.  In the fragment tiles a bank row is 2 x D/8 sixteen-byte pieces
  * 512 B apart, so that pass pulls eight times the bytes it uses; a second, row-major fp32 copy of the bank lets it read whole lines (a
  * use_fp16 search at 300,000 x 768: 8.0 -> 6.6 ms, k = 90: 18.0 -> 12.4; results identical).  What it saves is a few ms of re-rank per search whatever

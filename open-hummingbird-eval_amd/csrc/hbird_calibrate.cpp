@@ -124,6 +124,18 @@ int hb_xcd_step(hb_xcd_state& c, int fam, const hb_stamp_set& s) {
     return flags;
 }
 
+int hb_f16_choose(hb_f16_adapt& a) {
+    const bool probe = (a.searches++ & 15) == 15;
+    if (!probe && a.r12 > 0.5) return HB_F16_FP32;
+    if (!probe && a.r1 > 0.5) return HB_F16_WIDE_FIRST;
+    return HB_F16_CHAIN;
+}
+void hb_f16_observe(hb_f16_adapt& a, int how, int64_t nq, int64_t first_failed, int64_t reached_fp32) {
+    if (nq <= 0 || how == HB_F16_FP32) return;                 // (the fp32 kernel right away: nothing was observed)
+    if (how == HB_F16_CHAIN) a.r1 = 0.5 * a.r1 + 0.5 * (double)first_failed / (double)nq;      // (a wide-first search does not run the first pass)
+    a.r12 = first_failed == 0 ? 0.5 * a.r12 : 0.5 * a.r12 + 0.5 * (double)reached_fp32 / (double)nq;
+}
+
 // ---- test hooks (no GPU): a calibration state fed with synthetic stamp sets -----------------------------------------------------------
 struct hb_calibration { hb_xcd_state st; int fam; };
 extern "C" void* hb_calibration_new(int fp16_kernel) { hb_calibration* h = new hb_calibration(); h->fam = fp16_kernel ? 1 : 0; return h; }
@@ -148,4 +160,21 @@ extern "C" int hb_calibration_feed(void* hv, const uint32_t* stamps, int G, cons
     for (int x = 0; x < 8; ++x) s.run_shares[x] = run_shares8[x];
     for (int x = 0; x < 6; ++x) s.key[x] = key6[x];
     return hb_xcd_step(h->st, h->fam, s);
+}
+// the adaptive use of use_fp16 (mode 2): a fresh state walked through a stream of searches -- per search how it would run (out_how[i]) given
+// what the searches before it saw: failing shares of the first certificate f1[i] and of the second pass f2[i] (of those that entered it)
+extern "C" int hb_f16_adapt_replay(int n, const double* f1, const double* f2, int64_t nq, int* out_how) {
+    if (n < 0 || !f1 || !f2 || !out_how || nq <= 0) return -1;
+    hb_f16_adapt a;
+    for (int i = 0; i < n; ++i) {
+        const int how = hb_f16_choose(a);
+        out_how[i] = how;
+        const int64_t failed1 = (int64_t)std::llround(f1[i] * (double)nq);
+        // chain: the second pass takes the first's failures, its own failures reach fp32; wide-first: the k' = 256 pass runs on all queries and
+        // fails where BOTH would have (f1 x f2 of them)
+        const int64_t first_failed = how == HB_F16_WIDE_FIRST ? (int64_t)std::llround(f1[i] * f2[i] * (double)nq) : failed1;
+        const int64_t fp32 = how == HB_F16_WIDE_FIRST ? first_failed : (int64_t)std::llround(f2[i] * (double)failed1);
+        hb_f16_observe(a, how, nq, first_failed, fp32);
+    }
+    return 0;
 }

@@ -51,3 +51,14 @@ enum { HB_CAL_REBUILD = 1, HB_CAL_REMEMBER_SHARES = 2, HB_CAL_REMEMBER_CLUSTERS 
 // Feed one stamp set to the state: -> flags (HB_CAL_*): the work list must be rebuilt / the shares (the cluster decision) are worth
 // remembering for the device / the set was thrown away.  fam: 0 = the fp32 kernels, 1 = the fp16 candidate kernel.
 int hb_xcd_step(hb_xcd_state& c, int fam, const hb_stamp_set& s);
+
+// ---- use_fp16, adaptive use (mode 2: what the plugin's use_fp16=True selects) ---------------------------------------------------------
+// On a bank whose neighbours sit closer together than fp16 can tell apart most certificates fail, and passes that certify nothing are pure
+// overhead.  The index keeps moving averages of the share of queries that failed the first certificate (r1) and of the share that reached
+// the fp32 kernel (r12): r12 > 1/2 -> the fp32 kernel right away; r1 > 1/2 -> the first pass is skipped, ONE pass with k' = 256 serves all
+// queries; every 16th search walks the whole chain again, so that a bank (or a query stream) that changes is noticed.
+struct hb_f16_adapt { double r1 = 0.0, r12 = 0.0; int searches = 0; };
+enum { HB_F16_CHAIN = 0, HB_F16_WIDE_FIRST = 1, HB_F16_FP32 = 2 };
+int hb_f16_choose(hb_f16_adapt& a);                                                   // how the next search runs (counts it)
+// what that search saw: `first_failed` of `nq` queries failed the first certificate it ran, `reached_fp32` went to the fp32 kernel
+void hb_f16_observe(hb_f16_adapt& a, int how, int64_t nq, int64_t first_failed, int64_t reached_fp32);

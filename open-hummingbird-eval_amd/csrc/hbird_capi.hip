@@ -126,7 +126,7 @@ extern "C" int hb_index_set_tuning(hb_index_t* ix, int workgroups, int panel_til
 extern "C" int hb_index_set_fp16(hb_index_t* ix, int enable) {
     if (!ix) return hb_fail("hb_index_set_fp16: NULL index handle");
     ix->fp16 = enable == 2 ? 2 : (enable ? 1 : 0);   // 2: only where it pays (hb_launch_knn)
-    ix->f16_r1 = ix->f16_r12 = 0.0; ix->f16_searches = 0;
+    ix->f16_adapt = hb_f16_adapt();
     return 0;
 }
 

@@ -93,8 +93,8 @@ struct hb_index {
     int64_t last_fp16_fallbacks = 0;                     // queries of the last use_fp16 search that the fp32 kernel had to answer ...
     int64_t last_fp16_escalated = 0;                     // ... and queries whose first certificate failed (second fp16 pass, k' = 256, seeded floors)
     int fp16_escalation = 0;                             // 0 = on (automatic), 1 = off: uncertified queries go straight to the fp32 kernel (round 5)
-    double f16_r1 = 0.0, f16_r12 = 0.0;                  // moving averages: share of queries failing the first certificate / reaching the fp32 kernel (adaptive use, mode 2)
-    int f16_searches = 0, f16_skipped = 0;
+    hb_f16_adapt f16_adapt;                              // adaptive use of use_fp16 in mode 2 (hbird_calibrate.h): moving averages of the failing shares
+    int f16_skipped = 0;
     const float* ceil_s_dev = nullptr; const unsigned* ceil_i_dev = nullptr;    // a later pass of a search with k > 256 (hb_launch_knn_bigk)
     char* bigk = nullptr; size_t bigk_bytes = 0;         // its workspace: one pass's lists and the ceilings
     int esc_level = 0;                                   // inside hb_launch_knn: 0 = a caller's search, 1 = the second fp16 pass, 2 = the fp32 search of what is left

@@ -668,10 +668,11 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
     // r12 > 1/2 -> the fp32 kernel right away; r1 > 1/2 -> the first pass is skipped, ONE pass with k' = 256 serves all queries; every 16th
     // search walks the whole chain again, so a bank (or a query stream) that changes is noticed.  Same bits on every path.
     bool wide_first = false;
-    if (f16 && esc == 0 && ix->fp16 == 2 && ix->fp16_escalation == 0) {
-        const bool probe = (ix->f16_searches++ & 15) == 15;
-        if (!probe && ix->f16_r12 > 0.5) { f16 = false; ix->f16_skipped = 1; }
-        else if (!probe && ix->f16_r1 > 0.5) wide_first = true;
+    int how16 = HB_F16_CHAIN;
+    if (f16 && esc == 0 && ix->fp16 == 2 && ix->fp16_escalation == 0) {       // (the policy itself: hbird_calibrate.cpp, with CPU tests)
+        how16 = hb_f16_choose(ix->f16_adapt);
+        if (how16 == HB_F16_FP32) { f16 = false; ix->f16_skipped = 1; }
+        else if (how16 == HB_F16_WIDE_FIRST) wide_first = true;
     }
     if (!f16 && esc == 0) { ix->last_fp16_fallbacks = ix->f16_skipped ? nq : 0; ix->last_fp16_escalated = 0; ix->f16_skipped = 0; }      // a plain fp32 search: nothing fell back (the counters are not left over from an earlier search)
     if (f16 && nq > 0 && ix->ntotal > 0) {
@@ -997,8 +998,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
         for (int64_t i = 0; i < nq; ++i) if (!hc[i]) bad.push_back(i);
         const int64_t nf = (int64_t)bad.size();
         if (esc == 0) { ix->last_fp16_escalated = 0; ix->last_fp16_fallbacks = 0; }
-        if (esc == 0 && !wide_first) ix->f16_r1 = 0.5 * ix->f16_r1 + 0.5 * (double)nf / (double)nq;
-        if (esc == 0 && nf == 0) ix->f16_r12 *= 0.5;
+        if (esc == 0 && nf == 0) hb_f16_observe(ix->f16_adapt, how16, nq, 0, 0);
         if (nf > 0) {
             // the second pass needs k' = 256 > the first one's, a bank worth a candidate pass, and is not repeated
             const bool again16 = esc == 0 && ix->fp16_escalation == 0 && kc < 256 && ix->ntotal >= 4096;
@@ -1032,7 +1032,7 @@ int hb_launch_knn(hb_index* ix, const float* q_dev, int64_t nq, int k, int64_t i
             if (!again16) ix->last_fp16_fallbacks = nf;
             if (!rc) rc = hb_launch_knn(ix, d_q, nf, k, id_base, d_fi, d_fd);
             ix->fp16 = saved; ix->time_kernels = saved_t; ix->q_aux = saved_aux; ix->esc_level = saved_esc; ix->seed_dev = saved_seed;
-            if (esc == 0) { ix->last_fp16_escalated = nf; ix->f16_r12 = 0.5 * ix->f16_r12 + 0.5 * (double)ix->last_fp16_fallbacks / (double)nq; }
+            if (esc == 0) { ix->last_fp16_escalated = nf; hb_f16_observe(ix->f16_adapt, how16, nq, nf, ix->last_fp16_fallbacks); }
             if (rc) return -1;
             if (hb_launch_scatter_rows(d_rows, nf, k, d_fi, d_fd, out_idx, out_dist, s)) return -1;
             HB_HIP(hipStreamSynchronize(s));         // `bad` and the workspace are reused by the next call

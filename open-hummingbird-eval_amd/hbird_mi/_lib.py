@@ -96,6 +96,7 @@ SIGNATURES = {
     "hb_calibration_free": (None, [c_void_p]),
     "hb_calibration_state": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
     "hb_calibration_feed": (c_int, [c_void_p, c_void_p, c_int, POINTER(c_double), POINTER(c_int), c_int, c_double]),
+    "hb_f16_adapt_replay": (c_int, [c_int, POINTER(c_double), POINTER(c_double), c_int64, POINTER(c_int)]),
     "hb_index_set_rerank_copy": (c_int, [c_void_p, c_int]),
     "hb_index_rerank_copy_bytes": (c_int, [c_void_p, POINTER(c_int64)]),
     "hb_index_schedule_info": (c_int, [c_void_p, POINTER(c_int64)]),
@@ -123,7 +124,7 @@ def lib() -> ctypes.CDLL:
         # which exports the hb_schedule_plan* / hb_calibration_* entry points and hb_last_error only
         plan_only = os.environ.get("HBIRD_PLAN_ONLY") == "1"
         for name, (res, args) in SIGNATURES.items():
-            if plan_only and not (name.startswith("hb_schedule_plan") or name.startswith("hb_calibration_") or name == "hb_last_error"):
+            if plan_only and not (name.startswith("hb_schedule_plan") or name.startswith("hb_calibration_") or name == "hb_f16_adapt_replay" or name == "hb_last_error"):
                 continue
             fn = getattr(L, name)  # AttributeError here = header and library disagree
             fn.restype = res

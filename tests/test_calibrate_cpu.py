@@ -175,3 +175,29 @@ def test_the_fp16_family_is_damped_and_its_guard_is_wider():
     for _ in range(4):                                           # launches 0.4 % longer than the best seen: tolerated
         cal.feed(chip.launch(w, work=200_000_000.0 * 1.004), w, key=key)
     assert cal.state()[1]["locked"] == 0 and cal.state()[1]["reverts"] == 0
+
+
+def _adapt(f1, f2, nq=21904):
+    n = len(f1)
+    how = (ctypes.c_int * n)()
+    assert _lib.lib().hb_f16_adapt_replay(n, (ctypes.c_double * n)(*f1), (ctypes.c_double * n)(*f2), nq, how) == 0
+    return list(how)
+
+
+def test_use_fp16_adaptive_use_follows_what_the_certificates_say():
+    """Mode 2 of use_fp16 (what the plugin's use_fp16=True selects): the chain while certificates pass; one k' = 256 pass for all queries when
+    most first certificates fail but the wide pass settles them; the fp32 kernel right away when most queries end there anyway -- with a probe
+    of the whole chain every 16th search, through which a bank (or a query stream) that becomes certifiable again is noticed."""
+    CHAIN, WIDE, FP32 = 0, 1, 2
+    assert _adapt([0.0] * 40, [0.0] * 40) == [CHAIN] * 40                        # N(0,1)-like banks: always the chain
+    assert _adapt([0.05] * 40, [0.0] * 40) == [CHAIN] * 40                       # 5 % failing, settled by the second pass: still the chain
+    how = _adapt([1.0] * 40, [0.0] * 40)                                         # all fail the first certificate, the wide pass settles them
+    assert how[0] == CHAIN and how[1] == CHAIN and set(how[2:15]) == {WIDE} and how[15] == CHAIN and set(how[16:31]) == {WIDE}
+    how = _adapt([1.0] * 40, [1.0] * 40)                                         # nothing can be certified: the fp32 kernel, probes at 15 and 31
+    assert how[:2] == [CHAIN, CHAIN] and set(how[2:15]) == {FP32} and how[15] == CHAIN and set(how[16:31]) == {FP32} and how[31] == CHAIN
+    # a stream that becomes certifiable at search 20: the probe at 31 sees it, one more chain search halves the averages below 1/2
+    how = _adapt([1.0] * 20 + [0.0] * 30, [1.0] * 20 + [0.0] * 30)
+    assert set(how[16:31]) == {FP32} and how[31] == CHAIN and set(how[33:]) == {CHAIN}
+    # ... and one that stops being certifiable at search 10 is noticed at once (the chain observes every search)
+    how = _adapt([0.0] * 10 + [1.0] * 20, [0.0] * 10 + [1.0] * 20)
+    assert how[:11] == [CHAIN] * 11 and FP32 in how[11:14] and set(how[14:15]) == {FP32}
