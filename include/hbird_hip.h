@@ -277,6 +277,11 @@ int hb_calibration_feed(void* h, const uint32_t* stamps, int G, const double run
  * fail the first certificate / of those the second pass at search i; out_how[i] = how the index would run search i given what it saw before:
  * 0 the chain (first pass, second pass for its failures, fp32 for the rest), 1 one pass with k' = 256 for all queries, 2 the fp32 kernel right away. */
 int hb_f16_adapt_replay(int n, const double* f1, const double* f2, int64_t nq, int* out_how);
+/* K1 (the fused normalise + fragment-tiled append, also the query re-tiling of every search) has two forms with the same bits: the rows staged
+ * through LDS once (widths that are multiples of 16 up to 1152, 16-byte aligned sources) and the first form for everything else.  form 1 forces
+ * the first form everywhere (process-wide; tests hold the two forms to each other), 0 = automatic, 8 / 16 / 32 = the LDS form with that many rows
+ * per workgroup (A/B runs).  Twice the first form's rate on 500 k-row appends (0.49-0.59 of the HBM roofline at D = 384 / 768 / 1024). */
+int hb_set_layout_form(int form);
 /* use_fp16 searches re-rank their candidates in exact fp32 arithmetic.  In the fragment tiles a bank row is 2 x D/8 sixteen-byte pieces
  * 512 B apart, so that pass pulls eight times the bytes it uses; a second, row-major fp32 copy of the bank lets it read whole lines (a
  * use_fp16 search at 300,000 x 768: 8.0 -> 6.6 ms, k = 90: 18.0 -> 12.4; results identical).  What it saves is a few ms of re-rank per search whatever

@@ -97,6 +97,7 @@ SIGNATURES = {
     "hb_calibration_state": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
     "hb_calibration_feed": (c_int, [c_void_p, c_void_p, c_int, POINTER(c_double), POINTER(c_int), c_int, c_double]),
     "hb_f16_adapt_replay": (c_int, [c_int, POINTER(c_double), POINTER(c_double), c_int64, POINTER(c_int)]),
+    "hb_set_layout_form": (c_int, [c_int]),
     "hb_index_set_rerank_copy": (c_int, [c_void_p, c_int]),
     "hb_index_rerank_copy_bytes": (c_int, [c_void_p, POINTER(c_int64)]),
     "hb_index_schedule_info": (c_int, [c_void_p, POINTER(c_int64)]),

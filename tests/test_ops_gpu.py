@@ -356,3 +356,35 @@ def test_sliding_window_ops_errors(cuda_device):
         ops.upsample_accumulate(lh, 4, acc[..., :2], 0, 0, 16, 16)
     ties = torch.zeros((1, 2, 2, 4), device="cuda")
     assert int(ops.argmax_channels(ties).sum()) == 0             # first maximum wins
+
+
+@pytest.mark.parametrize("D,metric", [(384, 0), (768, 1), (1024, 0), (400, 1), (1536, 0), (16, 1)])
+def test_k1_lds_form_and_first_form_write_the_same_bits(cuda_device, D, metric):
+    """K1 in its two forms (hb_set_layout_form): rows staged through LDS once (D a multiple of 16 up to 1152) against the first form, which
+    D = 400 and D = 1536 keep anyway.  Same tiles (reconstructed rows), same stored norms, same L2 row constants (through the distances of
+    a search) and the same query tiles -- bit for bit, with ragged appends behind a partly filled row tile, unnormalised rows, a NaN row
+    (a zero token through the eps-free normalisation) and host buffers."""
+    from hbird_mi import _lib
+    rng = np.random.default_rng(D)
+    pieces = [rng.standard_normal((n, D)).astype(np.float32) * s for n, s in ((1000, 1.0), (37, 3.0), (2048, 0.2), (5, 1.0), (331, 1.0))]
+    pieces[2][7] = 0.0                                           # normalised: NaN row
+    q = (3.0 * rng.standard_normal((300, D))).astype(np.float32)
+    out = []
+    try:
+        for form in (1, 0, 8, 16, 32):                             # the first form, automatic, and every rows-per-workgroup choice of the LDS form
+            _lib.check(_lib.lib().hb_set_layout_form(form))
+            ix = HipFlatIndex(D, metric, 0)
+            for j, pc in enumerate(pieces):
+                ix.add(torch.from_numpy(pc).cuda() if j % 2 == 0 else pc, normalize=(j != 3))      # device and host paths; piece 3 as it is
+            n = ix.ntotal
+            rows = ix.reconstruct(torch.arange(n, device="cuda")).cpu().numpy()
+            norms = ix.copy_norms().cpu().numpy()
+            idx, dist = ix.search(torch.from_numpy(q).cuda(), 20)
+            out.append((rows, norms, idx.cpu().numpy(), dist.cpu().numpy()))
+    finally:
+        _lib.check(_lib.lib().hb_set_layout_form(0))
+    r1, n1, i1, d1 = out[0]
+    for r0, n0, i0, d0 in out[1:]:
+        assert np.array_equal(r1.view(np.uint32), r0.view(np.uint32))
+        assert np.array_equal(n1.view(np.uint32), n0.view(np.uint32))
+        assert np.array_equal(i1, i0) and np.array_equal(d1.view(np.uint32), d0.view(np.uint32))
