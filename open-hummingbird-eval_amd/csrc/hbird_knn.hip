@@ -511,8 +511,8 @@ __global__ __launch_bounds__(256) void pool_floor_kernel(const float* __restrict
                                                         unsigned* __restrict__ gthr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // (one query per wave: a launch of its own has all the parallelism it wants -- the two-queries-per-wave form that the kNN kernels run
-    // at the phase boundaries of a one-launch search, hbird_knn_dev.h: pool_floor_pair, measured 25 us per boundary SLOWER here)
+    // (one query per wave: a launch of its own has all the parallelism it wants -- a two-queries-per-wave form, one per lane half, built in round 5
+    // for floors computed inside the kNN kernels, measured 25 us per boundary SLOWER here)
     const int64_t q = (int64_t)blockIdx.x * 4 + w;
     if (q >= nq) return;
     pool_floor_query(state_s, cnts, pthr, qt_off, qt_slots, q, kk, klw, reinterpret_cast<float*>(smem) + (size_t)w * per_wave, gthr, lane);
